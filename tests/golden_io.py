@@ -1,0 +1,42 @@
+"""Readers for the committed golden fixtures under tests/golden/."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def normalize(qual_str: str, floor: int) -> bytes:
+    """ASCII-33 and clamp, as the reference test does
+    (src/test/java/com/intel/gkl/pairhmm/PairHmmUnitTest.java:211-214,309-319)."""
+    a = np.frombuffer(qual_str.encode("ascii"), dtype=np.uint8).astype(np.int32) - 33
+    return np.maximum(a, floor).astype(np.uint8).tobytes()
+
+
+def load_testdata():
+    """The reference's own golden file (copied data, 104 single-pair cases):
+    hap, read, readQual, insQual, delQual, gcp, expected log10 likelihood."""
+    cases = []
+    with open(os.path.join(GOLDEN, "pairhmm-testdata.txt")) as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            hap, read, q, i, d, c, exp = line.split()
+            cases.append(dict(hap=hap.encode(), read=read.encode(), q=normalize(q, 6), i=normalize(i, 0),
+                              d=normalize(d, 0), c=normalize(c, 0), expected=float(exp)))
+    return cases
+
+
+def load_ref_vectors():
+    """Vectors generated from the reference's own objects by tests/golden/make_fixtures.py."""
+    with open(os.path.join(GOLDEN, "ref_vectors.json")) as f:
+        return json.load(f)
+
+
+def batch_from_vector(v):
+    from gkl_amd.batch import FlatBatch
+    h = lambda s: np.frombuffer(bytes.fromhex(s), dtype=np.uint8)  # noqa: E731
+    return FlatBatch(v["n_reads"], v["n_haps"], np.array(v["read_off"], np.int64),
+                     np.array(v["hap_off"], np.int64), h(v["read_bases"]), h(v["read_quals"]),
+                     h(v["ins_gop"]), h(v["del_gop"]), h(v["gcp"]), h(v["hap_bases"]))
