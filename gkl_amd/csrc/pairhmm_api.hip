@@ -1,0 +1,643 @@
+// C-ABI implementation (include/gkl_hip_pairhmm.h) of the MI355X PairHMM forward path:
+// context / tables / planning / kernel launches / precision policy / finalisation.
+//
+// Reference counterparts (src/main/native/pairhmm): IntelPairHmm.cc:55-118 (init),
+// :150-169 (batch loop + fp32->fp64 policy + log10), :189-192 (done).  There is no
+// CPU compute path in this library: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gkl_hip_pairhmm.h"
+#include "pairhmm_fwd_kernel.h"
+#include "pairhmm_plan.h"
+#include "pairhmm_tables.h"
+
+using namespace gklhip;
+
+// ------------------------------------------------------------------ errors
+namespace {
+thread_local std::string g_err;
+
+int fail(int status, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return status;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      (void)hipGetLastError();                                                               \
+      return fail(e__ == hipErrorOutOfMemory ? GKLHIP_ERR_OOM : GKLHIP_ERR_HIP, "%s: %s",    \
+                  #expr, hipGetErrorString(e__));                                            \
+    }                                                                                        \
+  } while (0)
+
+// Grow-only device / pinned-host buffers.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return GKLHIP_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    const size_t want = n + n / 4 + 256;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return GKLHIP_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return GKLHIP_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = n + n / 4 + 256;
+    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return GKLHIP_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+}  // namespace
+
+// ------------------------------------------------------------------ small kernels
+namespace gklhip {
+
+// stream_src (host plan) -> stream entries: haplotype base codes / separators / idle.
+__global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8_t* __restrict__ hap_bases,
+                                    uint32_t* __restrict__ stream, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t s = src[i];
+  uint32_t e;
+  if (s >= 0) {
+    const uint8_t b = hap_bases[s];  // pairhmm_common.h:57-61: A0 C1 T2 G3 N4, anything else 0
+    e = b == 'C' ? 1u : b == 'T' ? 2u : b == 'G' ? 3u : b == 'N' ? 4u : 0u;
+  } else if (s == -1) {
+    e = kEntIdle;
+  } else {
+    e = kEntSep | (uint32_t)(-2 - s);
+  }
+  stream[i] = e;
+}
+
+struct FinalizeArgs {
+  const float* raw32;
+  const double* raw64;
+  double* out;
+  uint8_t* used64;
+  int32_t* list;
+  int32_t* count;
+  int64_t n;
+  int mode;            // gklhip_finalize (device modes only) or -1: leave `out` to the host
+  float log10_init_f;  // log10f(2^120), host libm
+  double log10_init32_as_f64;  // log10(2^120) in double
+  double log10_init_d;         // log10(2^1020)
+};
+
+// Precision policy of IntelPairHmm.cc:157-165 on the raw fp32 sums: keep (and
+// finalise) pairs with sum >= 1e-28f, queue the rest for the fp64 kernel.
+__global__ void policy_kernel(FinalizeArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float v = a.raw32[i];
+  if (v < 1e-28f) {  // NaN compares false and stays fp32, like the reference
+    a.used64[i] = 1;
+    const int k = atomicAdd(a.count, 1);
+    a.list[k] = (int32_t)i;
+  } else {
+    a.used64[i] = 0;
+    if (a.mode == GKLHIP_FINALIZE_DEVICE_F64) {
+      a.out[i] = log10((double)v) - a.log10_init32_as_f64;
+    } else if (a.mode == GKLHIP_FINALIZE_DEVICE_REF32) {
+      a.out[i] = (double)((float)log10((double)v) - a.log10_init_f);
+    }
+  }
+}
+
+// log10 of the fp64 sums: all pairs (useDoublePrecision) or the queued ones.
+__global__ void finalize64_kernel(FinalizeArgs a, int use_list) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = use_list ? (int64_t)*a.count : a.n;
+  if (i >= n) return;
+  const int64_t p = use_list ? (int64_t)a.list[i] : i;
+  if (!use_list) a.used64[p] = 1;
+  if (a.mode >= 0) a.out[p] = log10(a.raw64[p]) - a.log10_init_d;
+}
+
+}  // namespace gklhip
+
+// ------------------------------------------------------------------ context
+struct gklhip_ctx {
+  gklhip_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  // tables
+  DevBuf tab32, tab64;
+  DevTables<float> dt32;
+  DevTables<double> dt64;
+  // per-call plan uploads (pinned staging -> device)
+  PinBuf stage;
+  DevBuf plan_dev;
+  hipEvent_t stage_free = nullptr;  // previous call's uploads have left the staging buffer
+  // per-call device scratch
+  DevBuf raw32, raw64, used64, list, counters, stream_buf, read_off_dev, out_dev;
+  // host-API device copies of the batch
+  DevBuf batch_dev;
+  // events
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // last call
+  gklhip_stats stats;
+  int64_t last_pairs = 0;
+  hipStream_t last_stream = nullptr;
+  bool have_last = false;
+  Plan plan;
+};
+
+namespace {
+
+template <typename T>
+int upload_tables(gklhip_ctx* c, const HostTables<T>& h, DevBuf* buf, DevTables<T>* dt) {
+  const size_t n = (size_t)kQuals * 2 + kMmEntries;
+  int st = buf->reserve(n * sizeof(T));
+  if (st) return st;
+  T* base = buf->as<T>();
+  HIP_TRY(hipMemcpy(base, h.ph2pr.data(), kQuals * sizeof(T), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(base + kQuals, h.div3.data(), kQuals * sizeof(T), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(base + 2 * kQuals, h.mm.data(), kMmEntries * sizeof(T), hipMemcpyHostToDevice));
+  dt->ph2pr = base;
+  dt->div3 = base + kQuals;
+  dt->mm = base + 2 * kQuals;
+  (void)c;
+  return GKLHIP_OK;
+}
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Layout of the per-call plan block (identical in pinned staging and on the device).
+struct PlanLayout {
+  size_t lanes, groups, hap_len, hap_pos, hap_orig, hap_sidx, stream_src, y0_32, y0_64, read_off, total;
+};
+PlanLayout layout_for(const Plan& p, int n_reads, int n_haps) {
+  PlanLayout l;
+  size_t o = 0;
+  l.lanes = o; o = align_up(o + p.lanes.size() * sizeof(PlanLane));
+  l.groups = o; o = align_up(o + p.groups.size() * sizeof(PlanGroup));
+  l.hap_len = o; o = align_up(o + (size_t)n_haps * 4);
+  l.hap_pos = o; o = align_up(o + (size_t)n_haps * 4);
+  l.hap_orig = o; o = align_up(o + (size_t)n_haps * 4);
+  l.hap_sidx = o; o = align_up(o + (size_t)n_haps * 4);
+  l.stream_src = o; o = align_up(o + p.stream_src.size() * 4);
+  l.y0_32 = o; o = align_up(o + (size_t)n_haps * 4);
+  l.y0_64 = o; o = align_up(o + (size_t)n_haps * 8);
+  l.read_off = o; o = align_up(o + (size_t)(n_reads + 1) * 8);
+  l.total = o;
+  return l;
+}
+
+int validate(const gklhip_batch* b) {
+  if (!b) return fail(GKLHIP_ERR_INVALID_ARG, "batch is NULL");
+  if (b->n_reads < 0 || b->n_haps < 0) return fail(GKLHIP_ERR_INVALID_ARG, "negative batch size");
+  if (b->n_reads == 0 || b->n_haps == 0) return GKLHIP_OK;
+  if (!b->read_off || !b->hap_off) return fail(GKLHIP_ERR_INVALID_ARG, "offset arrays are NULL");
+  if (!b->read_bases || !b->read_quals || !b->ins_gop || !b->del_gop || !b->gcp || !b->hap_bases)
+    return fail(GKLHIP_ERR_INVALID_ARG, "a batch byte array is NULL");
+  if (b->read_off[0] != 0 || b->hap_off[0] != 0)
+    return fail(GKLHIP_ERR_INVALID_ARG, "offset arrays must start at 0");
+  // The reference does not guard empty reads/haplotypes (division by zero / negative index,
+  // SURVEY appendix A.10); this boundary rejects them.
+  for (int r = 0; r < b->n_reads; r++)
+    if (b->read_off[r + 1] <= b->read_off[r])
+      return fail(GKLHIP_ERR_INVALID_ARG, "read %d is empty or offsets are not increasing", r);
+  for (int h = 0; h < b->n_haps; h++)
+    if (b->hap_off[h + 1] <= b->hap_off[h])
+      return fail(GKLHIP_ERR_INVALID_ARG, "haplotype %d is empty or offsets are not increasing", h);
+  if ((int64_t)b->n_reads * b->n_haps >= (int64_t)1 << 31)
+    return fail(GKLHIP_ERR_UNSUPPORTED, "more than 2^31 pairs in one call");
+  if (b->hap_off[b->n_haps] + b->n_haps + 4096 >= (int64_t)1 << 31)
+    return fail(GKLHIP_ERR_UNSUPPORTED, "haplotype bases exceed 2^31");
+  return GKLHIP_OK;
+}
+
+template <typename T, int RPL>
+void launch_stream(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
+  if (fma) hipLaunchKernelGGL((pairhmm_fwd_stream_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
+  else     hipLaunchKernelGGL((pairhmm_fwd_stream_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
+}
+template <typename T, int RPL>
+void launch_pairs(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
+  if (fma) hipLaunchKernelGGL((pairhmm_fwd_pairs_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
+  else     hipLaunchKernelGGL((pairhmm_fwd_pairs_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
+}
+
+// rows-per-lane choices: a read of length R needs (R+1) rows <= 64*RPL
+int pick_rpl_f32(int max_read, int forced) {
+  if (forced == 8 || forced == 16) return (max_read + 1 <= 64 * forced) ? forced : 0;
+  if (max_read + 1 <= 64 * 8) return 8;
+  if (max_read + 1 <= 64 * 16) return 16;
+  return 0;
+}
+int pick_rpl_f64(int max_read) {
+  if (max_read + 1 <= 64 * 4) return 4;
+  if (max_read + 1 <= 64 * 8) return 8;
+  return 0;
+}
+
+// The whole device-side pipeline on stream `s`; `db` holds DEVICE byte arrays, host offsets.
+int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int finalize_mode, hipStream_t s) {
+  const int n_reads = db->n_reads, n_haps = db->n_haps;
+  const int64_t n_pairs = (int64_t)n_reads * n_haps;
+  gklhip_stats& st = c->stats;
+  memset(&st, 0, sizeof st);
+  st.n_pairs = n_pairs;
+  c->have_last = false;
+  if (n_pairs == 0) return GKLHIP_OK;
+  const bool use_double = c->cfg.use_double != 0;
+  const int fma = c->cfg.fma_mode != 0;
+
+  // ---- plan (host) ----
+  Plan& plan = c->plan;
+  int max_read = 0;
+  for (int r = 0; r < n_reads; r++) max_read = std::max(max_read, (int)(db->read_off[r + 1] - db->read_off[r]));
+  const int rpl64 = pick_rpl_f64(max_read);
+  const int rpl_main = use_double ? rpl64 : pick_rpl_f32(max_read, c->cfg.rows_per_lane);
+  if (rpl_main == 0 || rpl64 == 0)
+    return fail(GKLHIP_ERR_UNSUPPORTED, "read of length %d exceeds the in-register row capacity", max_read);
+  build_plan(n_reads, n_haps, db->read_off, db->hap_off, rpl_main, 4096, &plan);
+  const PlanLayout L = layout_for(plan, n_reads, n_haps);
+
+  // ---- stage + upload plan ----
+  int rc;
+  HIP_TRY(hipEventSynchronize(c->stage_free));
+  if ((rc = c->stage.reserve(L.total))) return rc;
+  if ((rc = c->plan_dev.reserve(L.total))) return rc;
+  unsigned char* hs = c->stage.as<unsigned char>();
+  memcpy(hs + L.lanes, plan.lanes.data(), plan.lanes.size() * sizeof(PlanLane));
+  memcpy(hs + L.groups, plan.groups.data(), plan.groups.size() * sizeof(PlanGroup));
+  memcpy(hs + L.hap_len, plan.hap_len.data(), (size_t)n_haps * 4);
+  memcpy(hs + L.hap_pos, plan.hap_pos.data(), (size_t)n_haps * 4);
+  memcpy(hs + L.hap_orig, plan.hap_orig.data(), (size_t)n_haps * 4);
+  memcpy(hs + L.hap_sidx, plan.hap_sidx.data(), (size_t)n_haps * 4);
+  memcpy(hs + L.stream_src, plan.stream_src.data(), plan.stream_src.size() * 4);
+  {
+    // Y[0][j] = INITIAL_CONSTANT / (NUMBER)haplen, divided on the host (template.h:110,176)
+    float* y32 = reinterpret_cast<float*>(hs + L.y0_32);
+    double* y64 = reinterpret_cast<double*>(hs + L.y0_64);
+    const float i32 = host_tables_f32().initial_constant;
+    const double i64 = host_tables_f64().initial_constant;
+    for (int k = 0; k < n_haps; k++) {
+      y32[k] = i32 / (float)plan.hap_len[k];
+      y64[k] = i64 / (double)plan.hap_len[k];
+    }
+  }
+  memcpy(hs + L.read_off, db->read_off, (size_t)(n_reads + 1) * 8);
+  unsigned char* dp = c->plan_dev.as<unsigned char>();
+  HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipEventRecord(c->stage_free, s));
+
+  // ---- scratch ----
+  if ((rc = c->raw32.reserve((size_t)n_pairs * 4))) return rc;
+  if ((rc = c->raw64.reserve((size_t)n_pairs * 8))) return rc;
+  if ((rc = c->used64.reserve((size_t)n_pairs))) return rc;
+  if ((rc = c->list.reserve((size_t)n_pairs * 4))) return rc;
+  if ((rc = c->counters.reserve(64))) return rc;
+  if ((rc = c->stream_buf.reserve(plan.stream_src.size() * 4))) return rc;
+  HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, s));
+
+  const bool ev = c->cfg.record_events != 0;
+  if (ev) HIP_TRY(hipEventRecord(c->ev[0], s));
+
+  // ---- haplotype streams ----
+  const int n_stream = (int)plan.stream_src.size();
+  hipLaunchKernelGGL(build_stream_kernel, dim3((n_stream + 255) / 256), dim3(256), 0, s,
+                     reinterpret_cast<const int32_t*>(dp + L.stream_src), db->hap_bases,
+                     c->stream_buf.as<uint32_t>(), n_stream);
+
+  DevBatch b;
+  b.read_bases = db->read_bases; b.read_quals = db->read_quals; b.ins = db->ins_gop;
+  b.del = db->del_gop; b.gcp = db->gcp;
+  b.read_off = reinterpret_cast<const int64_t*>(dp + L.read_off);
+  b.n_reads = n_reads; b.n_haps = n_haps;
+
+  auto fill_common = [&](auto& a) {
+    a.b = b;
+    a.stream = c->stream_buf.as<uint32_t>();
+    a.hap_len = reinterpret_cast<const int32_t*>(dp + L.hap_len);
+    a.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos);
+    a.hap_orig = reinterpret_cast<const int32_t*>(dp + L.hap_orig);
+    a.hap_sidx = reinterpret_cast<const int32_t*>(dp + L.hap_sidx);
+    a.groups = reinterpret_cast<const HapGroup*>(dp + L.groups);
+    a.n_groups = (int)plan.groups.size();
+    a.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.lanes);
+    a.n_chunks = plan.n_chunks;
+    a.pair_list = c->list.as<int32_t>();
+    a.pair_count = c->counters.as<int32_t>();
+    a.pair_next = c->counters.as<int32_t>() + 1;
+  };
+
+  FinalizeArgs fa;
+  fa.raw32 = c->raw32.as<float>(); fa.raw64 = c->raw64.as<double>(); fa.out = out_dev;
+  fa.used64 = c->used64.as<uint8_t>(); fa.list = c->list.as<int32_t>();
+  fa.count = c->counters.as<int32_t>(); fa.n = n_pairs; fa.mode = finalize_mode;
+  fa.log10_init_f = host_tables_f32().log10_initial;
+  fa.log10_init32_as_f64 = std::log10(std::ldexp(1.0, 120));
+  fa.log10_init_d = host_tables_f64().log10_initial;
+
+  const int n_main_blocks = plan.n_chunks * (int)plan.groups.size();
+  st.n_chunks = plan.n_chunks;
+  st.n_hap_groups = (int)plan.groups.size();
+  st.rows_per_lane = rpl_main;
+  st.lane_fill = plan.n_chunks ? (float)((double)plan.useful_rows / ((double)plan.n_chunks * 64 * rpl_main)) : 0.f;
+  {
+    int64_t rl = db->read_off[n_reads], hl = db->hap_off[n_haps];
+    st.cells = rl * hl;
+  }
+
+  if (ev) HIP_TRY(hipEventRecord(c->ev[1], s));
+  if (use_double) {
+    FwdArgs<double> a{};
+    fill_common(a);
+    a.tab = c->dt64;
+    a.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
+    a.raw = c->raw64.as<double>();
+    if (rpl_main == 4) launch_stream<double, 4>(a, fma, n_main_blocks, s);
+    else               launch_stream<double, 8>(a, fma, n_main_blocks, s);
+    if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
+    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
+    if (ev) { HIP_TRY(hipEventRecord(c->ev[3], s)); HIP_TRY(hipEventRecord(c->ev[4], s)); }
+  } else {
+    FwdArgs<float> a{};
+    fill_common(a);
+    a.tab = c->dt32;
+    a.y0 = reinterpret_cast<const float*>(dp + L.y0_32);
+    a.raw = c->raw32.as<float>();
+    if (rpl_main == 8) launch_stream<float, 8>(a, fma, n_main_blocks, s);
+    else               launch_stream<float, 16>(a, fma, n_main_blocks, s);
+    if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
+    hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa);
+    // fp64 recomputation of the queued pairs (persistent wavefronts; count stays on the device)
+    FwdArgs<double> d{};
+    fill_common(d);
+    d.tab = c->dt64;
+    d.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
+    d.raw = c->raw64.as<double>();
+    const int n_persist = (int)std::min<int64_t>(n_pairs, 256 * 10);
+    if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
+    if (rpl64 == 4) launch_pairs<double, 4>(d, fma, n_persist, s);
+    else            launch_pairs<double, 8>(d, fma, n_persist, s);
+    if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
+    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
+  }
+  if (ev) HIP_TRY(hipEventRecord(c->ev[5], s));
+  HIP_TRY(hipGetLastError());
+
+  c->last_pairs = n_pairs;
+  c->last_stream = s;
+  c->have_last = true;
+
+  if (ev) {
+    HIP_TRY(hipEventSynchronize(c->ev[5]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st.ms_fwd_main = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); st.ms_fwd_fallback = use_double ? 0.f : ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[5])); st.ms_total_device = ms;
+    int32_t cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    st.n_fallback = use_double ? n_pairs : cnt[0];
+  } else {
+    st.n_fallback = -1;  // unknown without a sync; gklhip_get_raw fills it in
+  }
+  return GKLHIP_OK;
+}
+
+void finalize_on_host(const float* raw32, const double* raw64, const uint8_t* used, double* out,
+                      int64_t n, int threads) {
+  // IntelPairHmm.cc:159-165 verbatim in meaning: host libm log10f / log10.
+  const float lf = host_tables_f32().log10_initial;
+  const double ld = host_tables_f64().log10_initial;
+  auto work = [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++) {
+      if (used[i]) out[i] = log10(raw64[i]) - ld;
+      else         out[i] = (double)(log10f(raw32[i]) - lf);
+    }
+  };
+  if (threads <= 1 || n < 16384) { work(0, n); return; }
+  std::vector<std::thread> pool;
+  const int64_t per = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; t++) {
+    const int64_t lo = t * per, hi = std::min<int64_t>(n, lo + per);
+    if (lo >= hi) break;
+    pool.emplace_back(work, lo, hi);
+  }
+  for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int gklhip_abi_version(void) { return GKLHIP_ABI_VERSION; }
+
+const char* gklhip_last_error(void) { return g_err.c_str(); }
+
+const char* gklhip_strerror(int status) {
+  switch (status) {
+    case GKLHIP_OK: return "ok";
+    case GKLHIP_ERR_INVALID_ARG: return "invalid argument";
+    case GKLHIP_ERR_NO_DEVICE: return "no usable HIP device";
+    case GKLHIP_ERR_OOM: return "out of memory";
+    case GKLHIP_ERR_HIP: return "HIP runtime error";
+    case GKLHIP_ERR_UNSUPPORTED: return "unsupported input";
+    default: return "unknown status";
+  }
+}
+
+int gklhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
+  if (!out_ctx) return fail(GKLHIP_ERR_INVALID_ARG, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  gklhip_config c0;
+  memset(&c0, 0, sizeof c0);
+  c0.abi_version = GKLHIP_ABI_VERSION; c0.device = -1; c0.max_threads = 1; c0.fma_mode = 1; c0.finalize = -1;
+  if (cfg) {
+    if (cfg->abi_version != GKLHIP_ABI_VERSION)
+      return fail(GKLHIP_ERR_INVALID_ARG, "ABI version %d, library is %d", cfg->abi_version, GKLHIP_ABI_VERSION);
+    c0 = *cfg;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(GKLHIP_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU compute path)");
+  }
+  int dev = c0.device;
+  if (dev < 0) { HIP_TRY(hipGetDevice(&dev)); }
+  if (dev >= ndev) return fail(GKLHIP_ERR_INVALID_ARG, "device %d of %d", dev, ndev);
+  HIP_TRY(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(GKLHIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
+  gklhip_ctx* c = new (std::nothrow) gklhip_ctx();
+  if (!c) return fail(GKLHIP_ERR_OOM, "context allocation failed");
+  c->cfg = c0;
+  c->device = dev;
+  memset(&c->stats, 0, sizeof c->stats);
+  int rc = GKLHIP_OK;
+  auto bail = [&](int status) { gklhip_done(c); return status; };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  if (hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  if (hipEventRecord(c->stage_free, c->stream) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventRecord failed"));
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  if ((rc = upload_tables(c, host_tables_f32(), &c->tab32, &c->dt32))) return bail(rc);
+  if ((rc = upload_tables(c, host_tables_f64(), &c->tab64, &c->dt64))) return bail(rc);
+  *out_ctx = c;
+  return GKLHIP_OK;
+}
+
+int gklhip_done(gklhip_ctx* c) {
+  if (!c) return GKLHIP_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev, &c->raw32, &c->raw64, &c->used64, &c->list,
+                    &c->counters, &c->stream_buf, &c->read_off_dev, &c->out_dev, &c->batch_dev})
+    b->release();
+  c->stage.release();
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stage_free) (void)hipEventDestroy(c->stage_free);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return GKLHIP_OK;
+}
+
+int gklhip_compute_device(gklhip_ctx* c, const gklhip_batch* dev_batch, double* out_dev, void* hip_stream) {
+  if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
+  int rc = validate(dev_batch);
+  if (rc) return rc;
+  if (!out_dev && (int64_t)dev_batch->n_reads * dev_batch->n_haps > 0)
+    return fail(GKLHIP_ERR_INVALID_ARG, "output array is NULL");
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  int mode = c->cfg.finalize;
+  if (mode != GKLHIP_FINALIZE_DEVICE_F64 && mode != GKLHIP_FINALIZE_DEVICE_REF32) mode = GKLHIP_FINALIZE_DEVICE_F64;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);  // NULL = HIP's default stream
+  return run_device(c, dev_batch, out_dev, mode, s);
+}
+
+int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
+  if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
+  int rc = validate(hb);
+  if (rc) return rc;
+  const int64_t n_pairs = (int64_t)hb->n_reads * hb->n_haps;
+  if (n_pairs == 0) return GKLHIP_OK;
+  if (!out_host) return fail(GKLHIP_ERR_INVALID_ARG, "output array is NULL");
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  // H2D of the six byte arrays (one allocation, 256-byte aligned sub-buffers)
+  const size_t rl = (size_t)hb->read_off[hb->n_reads], hl = (size_t)hb->hap_off[hb->n_haps];
+  const size_t stride = align_up(rl);
+  if ((rc = c->batch_dev.reserve(5 * stride + align_up(hl)))) return rc;
+  unsigned char* d = c->batch_dev.as<unsigned char>();
+  const uint8_t* srcs[5] = {hb->read_bases, hb->read_quals, hb->ins_gop, hb->del_gop, hb->gcp};
+  for (int i = 0; i < 5; i++) HIP_TRY(hipMemcpyAsync(d + i * stride, srcs[i], rl, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d + 5 * stride, hb->hap_bases, hl, hipMemcpyHostToDevice, s));
+  gklhip_batch db = *hb;
+  db.read_bases = d; db.read_quals = d + stride; db.ins_gop = d + 2 * stride;
+  db.del_gop = d + 3 * stride; db.gcp = d + 4 * stride; db.hap_bases = d + 5 * stride;
+  const int mode = c->cfg.finalize;
+  const bool on_device = (mode == GKLHIP_FINALIZE_DEVICE_F64 || mode == GKLHIP_FINALIZE_DEVICE_REF32);
+  if (on_device) {
+    if ((rc = c->out_dev.reserve((size_t)n_pairs * 8))) return rc;
+    if ((rc = run_device(c, &db, c->out_dev.as<double>(), mode, s))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, c->out_dev.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return GKLHIP_OK;
+  }
+  // reference-exact finalisation on the host
+  if ((rc = run_device(c, &db, nullptr, -1, s))) return rc;
+  std::vector<float> r32((size_t)n_pairs);
+  std::vector<double> r64((size_t)n_pairs);
+  std::vector<uint8_t> used((size_t)n_pairs);
+  if (!c->cfg.use_double)
+    HIP_TRY(hipMemcpyAsync(r32.data(), c->raw32.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(r64.data(), c->raw64.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(used.data(), c->used64.p, (size_t)n_pairs, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int threads = c->cfg.max_threads;
+  if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  finalize_on_host(r32.data(), r64.data(), used.data(), out_host, n_pairs, threads);
+  int64_t nf = 0;
+  for (uint8_t u : used) nf += u;
+  c->stats.n_fallback = nf;
+  return GKLHIP_OK;
+}
+
+int gklhip_get_stats(gklhip_ctx* c, gklhip_stats* out) {
+  if (!c || !out) return fail(GKLHIP_ERR_INVALID_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lock(c->mu);
+  *out = c->stats;
+  return GKLHIP_OK;
+}
+
+int gklhip_get_raw(gklhip_ctx* c, float* raw32, double* raw64, uint8_t* used64) {
+  if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->have_last) return fail(GKLHIP_ERR_INVALID_ARG, "no completed call to read back");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->last_stream;
+  const size_t n = (size_t)c->last_pairs;
+  if (raw32 && !c->cfg.use_double) HIP_TRY(hipMemcpyAsync(raw32, c->raw32.p, n * 4, hipMemcpyDeviceToHost, s));
+  if (raw64) HIP_TRY(hipMemcpyAsync(raw64, c->raw64.p, n * 8, hipMemcpyDeviceToHost, s));
+  if (used64) HIP_TRY(hipMemcpyAsync(used64, c->used64.p, n, hipMemcpyDeviceToHost, s));
+  int32_t cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  c->stats.n_fallback = c->cfg.use_double ? (int64_t)n : cnt[0];
+  return GKLHIP_OK;
+}
+
+int64_t gklhip_get_table_f32(int which, float* dst, int64_t cap) {
+  const HostTables<float>& t = host_tables_f32();
+  const std::vector<float>* v = which == 0 ? &t.ph2pr : which == 1 ? &t.mm : which == 2 ? &t.div3 : nullptr;
+  if (!v) return -1;
+  if (dst) memcpy(dst, v->data(), sizeof(float) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
+  return (int64_t)v->size();
+}
+int64_t gklhip_get_table_f64(int which, double* dst, int64_t cap) {
+  const HostTables<double>& t = host_tables_f64();
+  const std::vector<double>* v = which == 0 ? &t.ph2pr : which == 1 ? &t.mm : which == 2 ? &t.div3 : nullptr;
+  if (!v) return -1;
+  if (dst) memcpy(dst, v->data(), sizeof(double) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
+  return (int64_t)v->size();
+}
+
+}  // extern "C"

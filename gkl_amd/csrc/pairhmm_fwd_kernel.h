@@ -1,0 +1,381 @@
+// PairHMM forward recurrence for gfx950 (MI355X) -- device code.
+//
+// What it computes (per (read, haplotype) pair) is the reference's
+// compute_full_prob_* (reference src/main/native/pairhmm/avx-pairhmm-template.h:
+// 235-372): the scaled likelihood  sum_j M[R][j] + sum_j X[R][j]  of the M/X/Y
+// forward recurrence (computeMXY, :208-223) with the per-row transition
+// probabilities of initializeVectors (:106-152) and the match/mismatch prior of
+// stripeINITIALIZATION (:181-183).  Results are bit-identical to GKL's objects:
+// the operation order and FMA pattern are the reference's (FMA=true: the gcc-11
+// contraction of the AVX-512 TU; FMA=false: the unfused AVX TU), the tables come
+// from the host, and fp32 denormals are flushed like MXCSR.FTZ does.
+//
+// How it is mapped to the machine is new (the reference's stripe/bit-mask SIMD
+// scheme, :26-98,160-202, is not reproduced):
+//
+//   * A wavefront is a 64-lane systolic array.  Each lane owns RPL consecutive
+//     read rows in registers (state M/X/Y + five transition probabilities per
+//     row); a 64-lane "chunk" holds several reads packed back to back.
+//   * Haplotypes are *streamed* through the array: lane L works on stream
+//     position t-L at step t, so the three-term dependency (diagonal, up, left)
+//     only ever crosses from lane L-1 to lane L, as one DPP wave_shr:1 per value.
+//     Many haplotypes are chained in one stream (separator entries reset the
+//     column state and emit results), so the 64-step pipeline fill is paid once
+//     per job instead of once per pair.
+//   * Row 0 of each read (M=X=0, Y=2^120/H) is a "pad" row with degenerate
+//     transition probabilities, so a read boundary inside the array costs no
+//     instructions; lanes that start a read zero their incoming values with a
+//     per-lane AND mask (isolates pairs from each other, NaN/Inf included).
+//   * The match/mismatch prior is a 6 x rows table in LDS indexed by the
+//     haplotype base code of the lane's current column: one ds_read_b128 per
+//     four rows replaces a compare+select per cell.
+//   * No MFMA: this is a recurrence, not a contraction.  The roofline is the fp32
+//     (fp64) vector FMA rate; HBM traffic is ~1 KB per pair.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gklhip {
+
+constexpr uint32_t kEntIdle = 5u;           // stream entry: idle column (prior row of zeros)
+constexpr uint32_t kEntSep = 0x80000000u;   // stream entry: separator | stream-order hap index
+constexpr int kLanes = 64;
+
+template <typename T>
+struct DevTables {
+  const T* ph2pr;  // [128]
+  const T* div3;   // [128]
+  const T* mm;     // [8256]
+};
+
+struct DevBatch {
+  const uint8_t* read_bases;
+  const uint8_t* read_quals;
+  const uint8_t* ins;
+  const uint8_t* del;
+  const uint8_t* gcp;
+  const int64_t* read_off;  // device copy, [n_reads+1]
+  int32_t n_reads, n_haps;
+};
+
+// One haplotype stream: haps [hap_begin, hap_end) in stream order, their columns
+// and separators starting at stream[stream_begin], followed by >= 64 idle entries.
+struct HapGroup {
+  int32_t hap_begin, hap_end, stream_begin, pad_;
+};
+
+struct LaneSlot {  // one lane of a chunk: which read it holds, and which RPL-row block of it
+  int32_t read;    // -1 = idle lane
+  int32_t block;   // 0 .. n_blocks-1
+};
+
+template <typename T>
+struct FwdArgs {
+  DevBatch b;
+  DevTables<T> tab;
+  const uint32_t* stream;
+  const int32_t* hap_len;   // [n_haps] stream order
+  const int32_t* hap_pos;   // [n_haps] stream index of column 1, stream order
+  const int32_t* hap_orig;  // [n_haps] stream order -> caller's hap index
+  const int32_t* hap_sidx;  // [n_haps] caller's hap index -> stream order
+  const T* y0;              // [n_haps] stream order: INITIAL_CONSTANT / (T)haplen (host-computed)
+  const HapGroup* groups;
+  int32_t n_groups;
+  const LaneSlot* chunk_lanes;  // [n_chunks * 64]
+  int32_t n_chunks;
+  T* raw;  // [n_reads * n_haps], r-major, scaled likelihood sums
+  // pair-list mode (fp64 fallback): entries are pair indices r*n_haps + h
+  const int32_t* pair_list;
+  const int32_t* pair_count;
+  int32_t* pair_next;
+};
+
+// ---- cross-lane helpers -----------------------------------------------------
+// wave_shr:1 (DPP ctrl 0x138): lane L reads lane L-1 across the whole wavefront;
+// lane 0 keeps `old` (bound_ctrl off) or reads 0 (bound_ctrl on).
+__device__ __forceinline__ uint32_t dpp_shr1_keep(uint32_t old, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dpp_shr1_zero(uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x138, 0xf, 0xf, true);
+}
+// value of the lane above, ANDed with this lane's mask (0 for lanes that start a
+// read or are idle, ~0 otherwise).
+__device__ __forceinline__ float recv_above(float v, uint32_t lmask) {
+  return __uint_as_float(dpp_shr1_zero(__float_as_uint(v)) & lmask);
+}
+__device__ __forceinline__ double recv_above(double v, uint32_t lmask) {
+  const uint64_t u = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = dpp_shr1_zero((uint32_t)u) & lmask;
+  const uint32_t hi = dpp_shr1_zero((uint32_t)(u >> 32)) & lmask;
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// a*b + c*d in the reference's two patterns (c*d is the term rounded first).
+template <bool FMA, typename T>
+__device__ __forceinline__ T mul_add2(T a, T b, T c, T d) {
+  if (FMA) return fma_t(a, b, c * d);  // fma(a, b, c*d)
+  return c * d + a * b;
+}
+// M-state inner sum: ((Md*pMM + Xd*pGAPM) + Yd*pGAPM)   (template.h:213)
+template <bool FMA, typename T>
+__device__ __forceinline__ T m_inner(T md, T xd, T yd, T pmm, T pgapm) {
+  if (FMA) return fma_t(yd, pgapm, fma_t(xd, pgapm, md * pmm));
+  return (md * pmm + xd * pgapm) + yd * pgapm;
+}
+
+// ---- the per-wave job ---------------------------------------------------------
+template <typename T, int RPL, bool FMA>
+struct WaveJob {
+  static constexpr int kVecBytes = 16;
+  static constexpr int kPerVec = kVecBytes / (int)sizeof(T);        // rows per 16-byte LDS vector
+  static constexpr int kPlanes = RPL / kPerVec;                      // 16-byte vectors per lane per code
+  static constexpr int kRowBytes = kPlanes * kLanes * kVecBytes;     // one base code, all rows
+  static constexpr int kLdsBytes = 6 * kRowBytes;
+  static_assert(RPL % kPerVec == 0, "RPL must fill whole 16-byte vectors");
+  using Vec = T __attribute__((ext_vector_type(kPerVec)));
+
+  // registers
+  T M[RPL], X[RPL], Y[RPL];
+  T pMM[RPL], pGAPM[RPL], pMX[RPL], pXX[RPL], pMY[RPL];
+  T dM, dX, dY;       // row above at the previous column (diagonal inputs)
+  T sM, sX;           // running sums of the lane's bottom row
+  uint32_t ent;       // this lane's current stream entry
+  uint32_t lmask;     // 0 if this lane starts a read / is idle
+  int32_t out_read;   // read whose LAST row is this lane's bottom row, else -1
+  int32_t padb_slot;  // slot of the Y0-holding pad row in this lane, else -1
+  unsigned char* lds; // this wave's prior table
+
+  // Load one lane's rows: transition probabilities in registers, priors in LDS.
+  // Read layout inside a chunk: n_blocks = ceil((R+1)/RPL) lanes, p = n_blocks*RPL-R
+  // pad rows first (p-1 all-zero rows, then the Y0 row), then the R real rows, so the
+  // read's last row is always the bottom row of its last lane.
+  __device__ __forceinline__ void setup(const FwdArgs<T>& a, int lane, LaneSlot slot) {
+    int R = 0, first = 0;
+    int64_t roff = 0;
+    out_read = -1;
+    padb_slot = -1;
+    lmask = 0u;
+    if (slot.read >= 0) {
+      roff = a.b.read_off[slot.read];
+      R = (int)(a.b.read_off[slot.read + 1] - roff);
+      const int n_blocks = (R + RPL) / RPL;  // ceil((R+1)/RPL)
+      const int pads = n_blocks * RPL - R;
+      first = slot.block * RPL - pads;       // read-row index (0-based) of slot 0; negative = pad
+      if (slot.block == n_blocks - 1) out_read = slot.read;
+      if (slot.block != 0) lmask = ~0u;
+    }
+    T match[RPL], mism[RPL];
+    int code[RPL];
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+      const int v = first + s;
+      pMM[s] = pGAPM[s] = pMX[s] = pXX[s] = pMY[s] = T(0);
+      match[s] = mism[s] = T(0);
+      code[s] = 0;
+      if (slot.read >= 0 && v >= 0) {
+        const int64_t at = roff + v;
+        const int qi = a.b.ins[at] & 127, qd = a.b.del[at] & 127, qc = a.b.gcp[at] & 127;
+        const int qq = a.b.read_quals[at] & 127;
+        const int mx = qi > qd ? qi : qd, mn = qi > qd ? qd : qi;
+        pMM[s] = a.tab.mm[((mx * (mx + 1)) >> 1) + mn];
+        const T pc = a.tab.ph2pr[qc];
+        pGAPM[s] = T(1) - pc;
+        pMX[s] = a.tab.ph2pr[qi];
+        pXX[s] = pc;  // == pYY
+        pMY[s] = a.tab.ph2pr[qd];
+        match[s] = T(1) - a.tab.ph2pr[qq];
+        mism[s] = a.tab.div3[qq];
+        const uint8_t bb = a.b.read_bases[at];
+        code[s] = bb == 'C' ? 1 : bb == 'T' ? 2 : bb == 'G' ? 3 : bb == 'N' ? 4 : 0;
+      } else if (slot.read >= 0 && v == -1) {
+        pXX[s] = T(1);  // pad row holding Y0: Y stays constant, M = X = 0
+        padb_slot = s;
+        code[s] = -1;
+      } else {
+        code[s] = -1;
+      }
+    }
+    // prior table: [base code 0..5][plane][lane][kPerVec rows]
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#pragma unroll
+      for (int pl = 0; pl < kPlanes; pl++) {
+        Vec v;
+#pragma unroll
+        for (int k = 0; k < kPerVec; k++) {
+          const int s = pl * kPerVec + k;
+          const bool real = code[s] >= 0;
+          const bool hit = (c == code[s]) || (c == 4) || (code[s] == 4);
+          v[k] = (c == 5 || !real) ? T(0) : (hit ? match[s] : mism[s]);
+        }
+        *reinterpret_cast<Vec*>(lds + c * kRowBytes + pl * (kLanes * kVecBytes) + lane * kVecBytes) = v;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void reset_state(T y0) {
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+      M[s] = X[s] = T(0);
+      Y[s] = (s == padb_slot) ? y0 : T(0);
+    }
+    dM = dX = dY = T(0);
+    sM = sX = T(0);
+    ent = kEntIdle;
+  }
+
+  __device__ __forceinline__ void load_priors(uint32_t code, int lane, T* pr) const {
+    const unsigned char* p = lds + code * (uint32_t)kRowBytes + (uint32_t)lane * kVecBytes;
+#pragma unroll
+    for (int pl = 0; pl < kPlanes; pl++) {
+      const Vec v = *reinterpret_cast<const Vec*>(p + pl * (kLanes * kVecBytes));
+#pragma unroll
+      for (int k = 0; k < kPerVec; k++) pr[pl * kPerVec + k] = v[k];
+    }
+  }
+
+  // One anti-diagonal step of the recurrence for this lane's RPL rows.
+  __device__ __forceinline__ void advance(const T* pr, T rM, T rX, T* nM, T* nX, T* nY) const {
+    nM[0] = m_inner<FMA>(dM, dX, dY, pMM[0], pGAPM[0]) * pr[0];
+#pragma unroll
+    for (int s = 1; s < RPL; s++)
+      nM[s] = m_inner<FMA>(M[s - 1], X[s - 1], Y[s - 1], pMM[s], pGAPM[s]) * pr[s];
+#pragma unroll
+    for (int s = 0; s < RPL; s++) nY[s] = mul_add2<FMA>(Y[s], pXX[s], M[s], pMY[s]);  // (:222)
+    nX[0] = mul_add2<FMA>(rX, pXX[0], rM, pMX[0]);                                      // (:219)
+#pragma unroll
+    for (int s = 1; s < RPL; s++) nX[s] = mul_add2<FMA>(nX[s - 1], pXX[s], nM[s - 1], pMX[s]);
+  }
+
+  // Fast step: every lane is inside a haplotype (entry = base code 0..4).
+  __device__ __forceinline__ void step_fast(uint32_t entry, int lane) {
+    ent = dpp_shr1_keep(entry, ent);
+    const T rM = recv_above(M[RPL - 1], lmask);
+    const T rX = recv_above(X[RPL - 1], lmask);
+    const T rY = recv_above(Y[RPL - 1], lmask);
+    T pr[RPL], nM[RPL], nX[RPL], nY[RPL];
+    load_priors(ent, lane, pr);
+    advance(pr, rM, rX, nM, nX, nY);
+#pragma unroll
+    for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
+    dM = rM; dX = rX; dY = rY;
+    sM = sM + nM[RPL - 1];  // ascending-column sums (:354-369)
+    sX = sX + nX[RPL - 1];
+  }
+
+  // General step: lanes may be idle, inside a haplotype, or on a separator (end of
+  // haplotype: emit the result, go back to the column-0 state of the next one).
+  __device__ __forceinline__ void step_any(const FwdArgs<T>& a, uint32_t entry, int lane,
+                                           int hap_begin, int hap_end) {
+    ent = dpp_shr1_keep(entry, ent);
+    const T rM = recv_above(M[RPL - 1], lmask);
+    const T rX = recv_above(X[RPL - 1], lmask);
+    const T rY = recv_above(Y[RPL - 1], lmask);
+    const bool sep = (int32_t)ent < 0;
+    const uint32_t code = sep ? kEntIdle : ent;
+    T pr[RPL], nM[RPL], nX[RPL], nY[RPL];
+    load_priors(code, lane, pr);
+    advance(pr, rM, rX, nM, nX, nY);
+    if (sep) {
+      const int k = (int)(ent & 0x7fffffffu);
+      const bool mine = (k >= hap_begin) && (k < hap_end);
+      if (mine && out_read >= 0)
+        a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
+      const T y0n = (mine && k + 1 < hap_end) ? a.y0[k + 1] : T(0);
+#pragma unroll
+      for (int s = 0; s < RPL; s++) {
+        M[s] = T(0);
+        X[s] = T(0);
+        Y[s] = (s == padb_slot) ? y0n : T(0);
+      }
+      sM = T(0);
+      sX = T(0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
+      sM = sM + nM[RPL - 1];
+      sX = sX + nX[RPL - 1];
+    }
+    dM = rM; dX = rX; dY = rY;
+  }
+
+  // Stream haplotypes [hap_begin, hap_end) (stream order) through the loaded rows.
+  __device__ __forceinline__ void run(const FwdArgs<T>& a, int lane, int hap_begin, int hap_end) {
+    constexpr int U = 8;
+    const int sb = a.hap_pos[hap_begin];
+    const uint32_t* __restrict__ sp = a.stream + sb;
+    reset_state(a.y0[hap_begin]);
+    int t = 0;
+    int fast_from = kLanes - 1;  // the fill: lanes still idle until t = 63
+    for (int k = hap_begin; k < hap_end; k++) {
+      const int sep_at = a.hap_pos[k] - sb + a.hap_len[k];  // stream-relative separator position
+      const int slow_end = fast_from < sep_at ? fast_from : sep_at;
+      for (; t < slow_end; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
+      for (; t + U <= sep_at; t += U) {
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = sp[t + u];
+#pragma unroll
+        for (int u = 0; u < U; u++) step_fast(e[u], lane);
+      }
+      for (; t < sep_at; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
+      fast_from = sep_at + kLanes;
+    }
+    for (; t < fast_from; t++) step_any(a, sp[t], lane, hap_begin, hap_end);  // drain
+  }
+};
+
+// ---- kernels -------------------------------------------------------------------
+// Main pass: block (one wavefront) = (chunk of packed reads) x (haplotype group).
+template <typename T, int RPL, bool FMA>
+__global__ __launch_bounds__(64) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
+  using Job = WaveJob<T, RPL, FMA>;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
+  const int lane = threadIdx.x;
+  const int chunk = blockIdx.x / a.n_groups;
+  const int g = blockIdx.x - chunk * a.n_groups;
+  const HapGroup grp = a.groups[g];
+  Job job;
+  job.lds = lds;
+  job.setup(a, lane, a.chunk_lanes[(int64_t)chunk * kLanes + lane]);
+  __syncthreads();
+  job.run(a, lane, grp.hap_begin, grp.hap_end);
+}
+
+// Pair-list pass (fp64 recomputation of underflowed pairs): persistent wavefronts
+// pull (read, hap) pairs from a device-resident list; the read occupies the first
+// n_blocks lanes, one haplotype is streamed.
+template <typename T, int RPL, bool FMA>
+__global__ __launch_bounds__(64) void pairhmm_fwd_pairs_kernel(FwdArgs<T> a) {
+  using Job = WaveJob<T, RPL, FMA>;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
+  const int lane = threadIdx.x;
+  const int n = *a.pair_count;
+  Job job;
+  job.lds = lds;
+  for (;;) {
+    int idx = 0;
+    if (lane == 0) idx = atomicAdd(a.pair_next, 1);
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    if (idx >= n) break;
+    const int p = a.pair_list[idx];
+    const int r = p / a.b.n_haps;
+    const int h = p - r * a.b.n_haps;
+    const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+    const int n_blocks = (R + RPL) / RPL;
+    LaneSlot slot;
+    slot.read = lane < n_blocks ? r : -1;
+    slot.block = lane;
+    __syncthreads();  // previous job's LDS reads are done
+    job.setup(a, lane, slot);
+    __syncthreads();
+    const int k = a.hap_sidx[h];
+    job.run(a, lane, k, k + 1);
+  }
+}
+
+}  // namespace gklhip

@@ -1,0 +1,108 @@
+#include "pairhmm_plan.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace gklhip {
+
+namespace {
+constexpr int kLanes = 64;
+}
+
+void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off,
+                int rows_per_lane, int target_cols, Plan* out) {
+  Plan& p = *out;
+  p = Plan();
+  p.rows_per_lane = rows_per_lane;
+
+  // ---- haplotype streams: caller order, cut into groups of ~target_cols columns ----
+  p.hap_len.resize(n_haps);
+  p.hap_pos.resize(n_haps);
+  p.hap_orig.resize(n_haps);
+  p.hap_sidx.resize(n_haps);
+  int64_t total_cols = 0;
+  for (int h = 0; h < n_haps; h++) {
+    const int len = (int)(hap_off[h + 1] - hap_off[h]);
+    p.hap_len[h] = len;
+    p.hap_orig[h] = h;
+    p.hap_sidx[h] = h;
+    p.max_hap_len = std::max(p.max_hap_len, len);
+    total_cols += len + 1;
+  }
+  if (target_cols < 256) target_cols = 256;
+  int n_groups = (int)((total_cols + target_cols - 1) / target_cols);
+  n_groups = std::max(1, std::min(n_groups, n_haps));
+  const int64_t per_group = (total_cols + n_groups - 1) / n_groups;
+  p.stream_src.reserve((size_t)total_cols + (size_t)(n_groups + 1) * kLanes);
+  {
+    int h = 0;
+    while (h < n_haps) {
+      PlanGroup g;
+      g.hap_begin = h;
+      g.stream_begin = (int32_t)p.stream_src.size();
+      g.pad_ = 0;
+      int64_t cols = 0;
+      // at least one haplotype per group; stop once the group reached its share
+      do {
+        p.hap_pos[h] = (int32_t)p.stream_src.size();
+        const int64_t base = hap_off[h];
+        for (int c = 0; c < p.hap_len[h]; c++) p.stream_src.push_back((int32_t)(base + c));
+        p.stream_src.push_back(-2 - h);  // separator of stream-order hap h
+        cols += p.hap_len[h] + 1;
+        h++;
+      } while (h < n_haps && cols < per_group);
+      g.hap_end = h;
+      for (int i = 0; i < kLanes; i++) p.stream_src.push_back(-1);  // drain room
+      p.groups.push_back(g);
+    }
+  }
+
+  // ---- read packing: best-fit decreasing into 64-lane chunks ----
+  for (int r = 0; r < n_reads; r++)
+    p.max_read_len = std::max(p.max_read_len, (int)(read_off[r + 1] - read_off[r]));
+  if (rows_per_lane <= 0 || n_reads == 0) return;
+  const int rpl = rows_per_lane;
+  std::vector<int32_t> order(n_reads);
+  std::iota(order.begin(), order.end(), 0);
+  std::vector<int32_t> need(n_reads);
+  for (int r = 0; r < n_reads; r++) {
+    const int R = (int)(read_off[r + 1] - read_off[r]);
+    need[r] = blocks_for(R, rpl);
+    p.useful_rows += R;
+  }
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return need[a] > need[b]; });
+  // open[c] = chunks that still have exactly c free lanes
+  std::vector<std::vector<int32_t>> open(kLanes + 1);
+  std::vector<int32_t> used_lanes;  // per chunk
+  std::vector<std::vector<int32_t>> members;
+  for (int32_t r : order) {
+    const int n = need[r];  // 1..64 (caller guarantees the read fits a chunk)
+    int c = n;
+    while (c <= kLanes && open[c].empty()) c++;
+    int chunk;
+    if (c > kLanes) {
+      chunk = (int)used_lanes.size();
+      used_lanes.push_back(0);
+      members.emplace_back();
+      c = kLanes;
+    } else {
+      chunk = open[c].back();
+      open[c].pop_back();
+    }
+    members[chunk].push_back(r);
+    used_lanes[chunk] += n;
+    const int left = c - n;
+    if (left > 0) open[left].push_back(chunk);
+  }
+  p.n_chunks = (int)used_lanes.size();
+  p.lanes.assign((size_t)p.n_chunks * kLanes, PlanLane{-1, 0});
+  for (int ch = 0; ch < p.n_chunks; ch++) {
+    int lane = 0;
+    for (int32_t r : members[ch]) {
+      for (int b = 0; b < need[r]; b++) p.lanes[(size_t)ch * kLanes + lane++] = PlanLane{r, b};
+    }
+  }
+}
+
+}  // namespace gklhip

@@ -1,0 +1,46 @@
+// Host-side work planning for one batch: which reads share a wavefront, and how
+// the haplotypes are chained into streams.  Pure C++ (no HIP), so it is unit-tested
+// on CPU through the C ABI's plan introspection and reused by every launch path.
+//
+// There is no counterpart in the reference: its batch loop is one OpenMP
+// `schedule(dynamic,1)` over independent pairs (IntelPairHmm.cc:151-154).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace gklhip {
+
+struct PlanLane {
+  int32_t read;   // -1 = idle
+  int32_t block;  // RPL-row block of the read held by this lane
+};
+
+struct PlanGroup {
+  int32_t hap_begin, hap_end, stream_begin, pad_;
+};
+
+struct Plan {
+  int rows_per_lane = 0;
+  int n_chunks = 0;
+  std::vector<PlanLane> lanes;      // [n_chunks*64]
+  std::vector<PlanGroup> groups;
+  std::vector<int32_t> hap_len;     // stream order
+  std::vector<int32_t> hap_pos;     // stream index of column 1
+  std::vector<int32_t> hap_orig;    // stream order -> caller index
+  std::vector<int32_t> hap_sidx;    // caller index -> stream order
+  // stream source: >= 0 index into hap_bases; -1 idle; <= -2 separator of stream hap (-2-k)
+  std::vector<int32_t> stream_src;
+  int64_t useful_rows = 0;
+  int max_read_len = 0;
+  int max_hap_len = 0;
+};
+
+// Lanes a read of length R occupies at RPL rows per lane: its R rows plus >= 1 pad row.
+inline int blocks_for(int R, int rpl) { return (R + rpl) / rpl; }
+
+// Build the haplotype streams (always) and, when rows_per_lane > 0, the read packing.
+// target_cols: desired columns per haplotype group (job length).
+void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off,
+                int rows_per_lane, int target_cols, Plan* out);
+
+}  // namespace gklhip

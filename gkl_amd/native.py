@@ -1,0 +1,219 @@
+"""ctypes binding of the C ABI (include/gkl_hip_pairhmm.h) -- the only way Python reaches
+the HIP kernels.  There is no fallback: if ``libgklhip_pairhmm.so`` is missing or no
+gfx950 device is visible, everything here raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .batch import FlatBatch
+from .errors import IllegalArgumentException, OutOfMemoryError, RuntimeException
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libgklhip_pairhmm.so")
+
+ABI_VERSION = 1
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_HIP, ERR_UNSUPPORTED = range(6)
+FINALIZE_REFERENCE_HOST, FINALIZE_DEVICE_F64, FINALIZE_DEVICE_REF32 = 0, 1, 2
+
+_u8p = C.POINTER(C.c_uint8)
+_i64p = C.POINTER(C.c_int64)
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("use_double", C.c_int32),
+                ("max_threads", C.c_int32), ("fma_mode", C.c_int32), ("finalize", C.c_int32),
+                ("record_events", C.c_int32), ("rows_per_lane", C.c_int32)]
+
+
+class CBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_haps", C.c_int32), ("read_off", _i64p), ("hap_off", _i64p),
+                ("read_bases", C.c_void_p), ("read_quals", C.c_void_p), ("ins_gop", C.c_void_p),
+                ("del_gop", C.c_void_p), ("gcp", C.c_void_p), ("hap_bases", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_pairs", C.c_int64), ("n_fallback", C.c_int64), ("cells", C.c_int64),
+                ("cells_fp64", C.c_int64), ("n_chunks", C.c_int32), ("n_hap_groups", C.c_int32),
+                ("rows_per_lane", C.c_int32), ("n_long_pairs", C.c_int32), ("ms_fwd_main", C.c_float),
+                ("ms_fwd_fallback", C.c_float), ("ms_total_device", C.c_float), ("lane_fill", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the product library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeException(f"{p} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    lib.gklhip_abi_version.restype = C.c_int
+    lib.gklhip_device_count.restype = C.c_int
+    lib.gklhip_strerror.restype = C.c_char_p
+    lib.gklhip_strerror.argtypes = [C.c_int]
+    lib.gklhip_last_error.restype = C.c_char_p
+    lib.gklhip_init.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.gklhip_init.restype = C.c_int
+    lib.gklhip_done.argtypes = [C.c_void_p]
+    lib.gklhip_done.restype = C.c_int
+    lib.gklhip_compute.argtypes = [C.c_void_p, C.POINTER(CBatch), C.c_void_p]
+    lib.gklhip_compute.restype = C.c_int
+    lib.gklhip_compute_device.argtypes = [C.c_void_p, C.POINTER(CBatch), C.c_void_p, C.c_void_p]
+    lib.gklhip_compute_device.restype = C.c_int
+    lib.gklhip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    lib.gklhip_get_stats.restype = C.c_int
+    lib.gklhip_get_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gklhip_get_raw.restype = C.c_int
+    lib.gklhip_get_table_f32.argtypes = [C.c_int, C.c_void_p, C.c_int64]
+    lib.gklhip_get_table_f32.restype = C.c_int64
+    lib.gklhip_get_table_f64.argtypes = [C.c_int, C.c_void_p, C.c_int64]
+    lib.gklhip_get_table_f64.restype = C.c_int64
+    if lib.gklhip_abi_version() != ABI_VERSION:
+        raise RuntimeException("libgklhip_pairhmm.so ABI mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _raise(lib, status: int):
+    msg = (lib.gklhip_last_error() or b"").decode() or lib.gklhip_strerror(status).decode()
+    if status == ERR_INVALID_ARG:
+        raise IllegalArgumentException(msg)
+    if status == ERR_OOM:
+        raise OutOfMemoryError(msg)
+    raise RuntimeException(f"{lib.gklhip_strerror(status).decode()}: {msg}")
+
+
+def host_table(which: int, dtype) -> np.ndarray:
+    """Lookup tables exactly as the library uploads them (0 ph2pr, 1 matchToMatch, 2 ph2pr/3)."""
+    lib = load_library()
+    if np.dtype(dtype) == np.float32:
+        n = lib.gklhip_get_table_f32(which, None, 0)
+        a = np.empty(n, np.float32)
+        lib.gklhip_get_table_f32(which, a.ctypes.data, n)
+    else:
+        n = lib.gklhip_get_table_f64(which, None, 0)
+        a = np.empty(n, np.float64)
+        lib.gklhip_get_table_f64(which, a.ctypes.data, n)
+    return a
+
+
+@dataclass
+class DeviceBatch:
+    """A FlatBatch whose byte arrays live in HBM (torch uint8 tensors own the memory)."""
+    host: FlatBatch
+    tensors: tuple  # read_bases, read_quals, ins, del, gcp, hap_bases
+    read_off: np.ndarray
+    hap_off: np.ndarray
+
+    @staticmethod
+    def upload(batch: FlatBatch, device="cuda:0") -> "DeviceBatch":
+        import torch
+        ts = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in
+                   (batch.read_bases, batch.read_quals, batch.ins_gop, batch.del_gop, batch.gcp,
+                    batch.hap_bases))
+        return DeviceBatch(batch, ts, np.ascontiguousarray(batch.read_off, np.int64),
+                           np.ascontiguousarray(batch.hap_off, np.int64))
+
+    def c_batch(self) -> CBatch:
+        t = self.tensors
+        return CBatch(self.host.n_reads, self.host.n_haps, self.read_off.ctypes.data_as(_i64p),
+                      self.hap_off.ctypes.data_as(_i64p), *[x.data_ptr() for x in t])
+
+
+class PairHmmContext:
+    """One gklhip context (= one initNative)."""
+
+    def __init__(self, use_double: bool = False, max_threads: int = 1, device: int = -1,
+                 fma_mode: int = 1, finalize: int = -1, record_events: bool = False,
+                 rows_per_lane: int = 0, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        cfg = Config(ABI_VERSION, device, int(use_double), int(max_threads), int(fma_mode),
+                     int(finalize), int(record_events), int(rows_per_lane))
+        h = C.c_void_p()
+        st = self.lib.gklhip_init(C.byref(cfg), C.byref(h))
+        if st != OK:
+            _raise(self.lib, st)
+        self.handle = h
+        self.use_double = bool(use_double)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gklhip_done(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- host buffers in / out: what the JNI shim does --
+    def compute(self, batch: FlatBatch, out: Optional[np.ndarray] = None) -> np.ndarray:
+        n = batch.n_pairs
+        if out is None:
+            out = np.empty(n, np.float64)
+        if out.dtype != np.float64 or out.size < n or not out.flags.c_contiguous:
+            raise IllegalArgumentException("likelihood array must be contiguous float64 of n_reads*n_haps")
+        keep = [np.ascontiguousarray(a, np.uint8) for a in
+                (batch.read_bases, batch.read_quals, batch.ins_gop, batch.del_gop, batch.gcp,
+                 batch.hap_bases)]
+        ro = np.ascontiguousarray(batch.read_off, np.int64)
+        ho = np.ascontiguousarray(batch.hap_off, np.int64)
+        cb = CBatch(batch.n_reads, batch.n_haps, ro.ctypes.data_as(_i64p), ho.ctypes.data_as(_i64p),
+                    *[a.ctypes.data for a in keep])
+        st = self.lib.gklhip_compute(self.handle, C.byref(cb), out.ctypes.data)
+        if st != OK:
+            _raise(self.lib, st)
+        return out
+
+    # -- everything resident in HBM; `out` is a torch float64 CUDA tensor --
+    def compute_device(self, dbatch: DeviceBatch, out=None, stream=None):
+        import torch
+        n = dbatch.host.n_pairs
+        if out is None:
+            out = torch.empty(n, dtype=torch.float64, device=dbatch.tensors[0].device)
+        if stream is None:
+            stream = torch.cuda.current_stream(out.device)
+        cb = dbatch.c_batch()
+        st = self.lib.gklhip_compute_device(self.handle, C.byref(cb), out.data_ptr(), stream.cuda_stream)
+        if st != OK:
+            _raise(self.lib, st)
+        return out
+
+    def stats(self) -> dict:
+        s = Stats()
+        st = self.lib.gklhip_get_stats(self.handle, C.byref(s))
+        if st != OK:
+            _raise(self.lib, st)
+        return s.as_dict()
+
+    def raw(self, n_pairs: int):
+        """Raw scaled sums of the last call: (raw32, raw64, used64)."""
+        r32 = np.zeros(n_pairs, np.float32)
+        r64 = np.zeros(n_pairs, np.float64)
+        u = np.zeros(n_pairs, np.uint8)
+        st = self.lib.gklhip_get_raw(self.handle, r32.ctypes.data, r64.ctypes.data, u.ctypes.data)
+        if st != OK:
+            _raise(self.lib, st)
+        return r32, r64, u

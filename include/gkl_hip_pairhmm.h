@@ -1,0 +1,141 @@
+/*
+ * gkl_hip_pairhmm.h -- C ABI of the MI355X-native PairHMM forward hot path.
+ *
+ * This is the drop-in boundary.  Everything below is plain C: pointers, sizes and
+ * status codes -- no JNI, no torch, no C++ types.  The JNI symbols that GKL's Java
+ * class com.intel.gkl.pairhmm.IntelPairHmm binds (libgkl_pairhmm.so, see
+ * include/gkl_pairhmm_jni.h) are thin shims over these entry points, and so is
+ * the ctypes binding in gkl_amd/native.py.
+ *
+ * What each entry point replaces in the reference (paths under
+ * /root/reference/src/main/native/pairhmm):
+ *
+ *   gklhip_init            initNative: IntelPairHmm.cc:55-118 (globals g_use_double,
+ *                          g_max_threads, FTZ, kernel choice) + the static Context<T>
+ *                          table objects of IntelPairHmm.cc:44-45 / Context.h:133-189
+ *   gklhip_compute         computeLikelihoodsNative after marshalling:
+ *                          IntelPairHmm.cc:150-169 (batch loop, fp32->fp64 policy,
+ *                          log10) calling compute_full_prob_* of
+ *                          avx-pairhmm-template.h:235-372
+ *   gklhip_compute_device  same, with the batch already resident in HBM
+ *   gklhip_done            doneNative: IntelPairHmm.cc:189-192
+ *
+ * The flat batch replaces the std::vector<testcase> that JavaData::getData builds
+ * (JavaData.h:65-111; testcase = pairhmm_common.h:43-47): reads x haplotypes cross
+ * product, r-major, result index r*n_haps + h (JavaData.h:94-105, IntelPairHmm.cc:167).
+ */
+#ifndef GKL_HIP_PAIRHMM_H
+#define GKL_HIP_PAIRHMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GKLHIP_ABI_VERSION 1
+
+typedef struct gklhip_ctx gklhip_ctx; /* opaque; one per initNative */
+
+typedef enum {
+  GKLHIP_OK = 0,
+  GKLHIP_ERR_INVALID_ARG = 1, /* -> java/lang/IllegalArgumentException */
+  GKLHIP_ERR_NO_DEVICE = 2,   /* no usable gfx950 device: fails loudly, no CPU fallback */
+  GKLHIP_ERR_OOM = 3,         /* -> java/lang/OutOfMemoryError */
+  GKLHIP_ERR_HIP = 4,         /* any other HIP runtime failure -> java/lang/RuntimeException */
+  GKLHIP_ERR_UNSUPPORTED = 5
+} gklhip_status;
+
+/* How raw kernel sums become log10 likelihoods (IntelPairHmm.cc:159-165). */
+typedef enum {
+  /* Exactly the reference's arithmetic, evaluated on the HOST with the host libm:
+   * fp32 pairs (double)(log10f(raw) - log10f(2^120)), fp64 pairs
+   * log10(raw) - log10(2^1020).  Bit-identical to GKL given bit-identical sums.
+   * Default of gklhip_compute (host buffers). */
+  GKLHIP_FINALIZE_REFERENCE_HOST = 0,
+  /* Evaluated on the device in double: log10((double)raw) - log10(2^{120|1020}).
+   * Never further from the reference's fp64 path than the fp32 recurrence itself
+   * (the reference's log10f adds up to 3.8e-6 absolute). Default of
+   * gklhip_compute_device. */
+  GKLHIP_FINALIZE_DEVICE_F64 = 1,
+  /* Device emulation of the reference formula: float-rounded log10 and float
+   * subtraction; within 1 float ulp (3.8e-6) of GKLHIP_FINALIZE_REFERENCE_HOST. */
+  GKLHIP_FINALIZE_DEVICE_REF32 = 2
+} gklhip_finalize;
+
+typedef struct {
+  int32_t abi_version;  /* GKLHIP_ABI_VERSION */
+  int32_t device;       /* HIP device ordinal, -1 = current device */
+  int32_t use_double;   /* PairHMMNativeArguments.useDoublePrecision (IntelPairHmm.cc:70) */
+  int32_t max_threads;  /* maxNumberOfThreads: host threads for the reference-exact finalize */
+  int32_t fma_mode;     /* 1 = arithmetic of GKL's AVX-512 objects (gcc-contracted FMA; default),
+                           0 = arithmetic of GKL's AVX objects (separate mul/add) */
+  int32_t finalize;     /* gklhip_finalize for gklhip_compute_device; -1 = default */
+  int32_t record_events;/* 1 = bracket kernels with HIP events (gklhip_get_stats) */
+  int32_t rows_per_lane;/* 0 = auto; otherwise force the fp32 kernel variant (8 or 16) */
+} gklhip_config;
+
+/* Flat structure-of-arrays batch. Offsets always live on the host; the byte
+ * arrays live on the host for gklhip_compute and in HBM for gklhip_compute_device.
+ * Quals are raw Phred bytes; they are masked with &127 like
+ * avx-pairhmm-template.h:134-136,149. */
+typedef struct {
+  int32_t n_reads;
+  int32_t n_haps;
+  const int64_t* read_off;   /* [n_reads+1], read_off[0] == 0 */
+  const int64_t* hap_off;    /* [n_haps+1],  hap_off[0] == 0 */
+  const uint8_t* read_bases; /* [read_off[n_reads]]  ReadDataHolder.readBases    */
+  const uint8_t* read_quals; /*                      ReadDataHolder.readQuals    */
+  const uint8_t* ins_gop;    /*                      ReadDataHolder.insertionGOP */
+  const uint8_t* del_gop;    /*                      ReadDataHolder.deletionGOP  */
+  const uint8_t* gcp;        /*                      ReadDataHolder.overallGCP   */
+  const uint8_t* hap_bases;  /* [hap_off[n_haps]]    HaplotypeDataHolder.haplotypeBases */
+} gklhip_batch;
+
+typedef struct {
+  int64_t n_pairs;
+  int64_t n_fallback;      /* pairs recomputed in fp64 (raw fp32 sum < 1e-28f) */
+  int64_t cells;           /* sum of rslen*haplen over all pairs */
+  int64_t cells_fp64;      /* same over the fp64-recomputed pairs */
+  int32_t n_chunks;        /* 64-lane read packs of the fp32 (or all-fp64) pass */
+  int32_t n_hap_groups;
+  int32_t rows_per_lane;
+  int32_t n_long_pairs;    /* pairs routed to the striped long-read kernel */
+  float ms_fwd_main;       /* HIP-event time of the main forward kernel (record_events) */
+  float ms_fwd_fallback;   /* HIP-event time of the fp64 fallback kernel */
+  float ms_total_device;   /* first launch .. last kernel of the call */
+  float lane_fill;         /* useful rows / (chunks * 64 * rows_per_lane) of the main pass */
+} gklhip_stats;
+
+/* Lifecycle. */
+int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx);
+int gklhip_done(gklhip_ctx* ctx);
+
+/* Host buffers in, host doubles out (n_reads*n_haps). What the JNI shim calls. */
+int gklhip_compute(gklhip_ctx* ctx, const gklhip_batch* host_batch, double* out_host);
+
+/* Byte arrays and `out_dev` in HBM; launches on `hip_stream` (a hipStream_t; NULL = HIP's
+ * default stream) and returns without a host sync when record_events==0. */
+int gklhip_compute_device(gklhip_ctx* ctx, const gklhip_batch* dev_batch, double* out_dev,
+                          void* hip_stream);
+
+/* Introspection (tests, bench). */
+int gklhip_get_stats(gklhip_ctx* ctx, gklhip_stats* out);
+/* Raw sums of the last call, copied to host arrays of n_pairs entries (any may be NULL).
+ * raw64 is meaningful where used64 != 0. Synchronises the stream. */
+int gklhip_get_raw(gklhip_ctx* ctx, float* raw32, double* raw64, uint8_t* used64);
+/* Host-built lookup tables exactly as uploaded: which = 0 ph2pr[128],
+ * 1 matchToMatch triangle for quals 0..127 [8256], 2 ph2pr/3 [128]. Returns count. */
+int64_t gklhip_get_table_f32(int which, float* dst, int64_t cap);
+int64_t gklhip_get_table_f64(int which, double* dst, int64_t cap);
+
+const char* gklhip_strerror(int status);
+/* Thread-local detail message of the last failing call on this thread. */
+const char* gklhip_last_error(void);
+int gklhip_device_count(void);
+int gklhip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKL_HIP_PAIRHMM_H */
