@@ -57,6 +57,13 @@ def load_library(path: Optional[str] = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    try:
+        # PyTorch-ROCm wheels bundle their own libamdhip64; whichever HIP runtime is loaded
+        # first owns the device, so let torch's load first and share it (torch is only used
+        # for device memory / streams / torch.distributed, never for compute).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise RuntimeException(f"{p} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
