@@ -1,0 +1,109 @@
+// Clean-room subset of the Java Native Interface, for hosts without a JDK.
+//
+// This build container (and the GPU boxes) have no JDK, hence no <jni.h>.  The JNI
+// function table is a stable binary interface fixed by the JNI specification
+// ("JNI Functions", Interface Function Table): JNIEnv is a pointer to a pointer to
+// an array of function pointers whose INDICES never change.  Only those indices and
+// the primitive type widths are needed to call into a JVM, so this header declares
+// the table as an indexed array plus typed accessors for the handful of functions
+// the PairHMM shim uses.  When a real <jni.h> is available, define
+// GKL_USE_SYSTEM_JNI and it is used instead (include/gkl_pairhmm_jni.h).
+//
+// Slots used (spec index): FindClass 6, ThrowNew 14, ExceptionClear 17,
+// DeleteLocalRef 23, GetFieldID 94, GetObjectField 95, GetArrayLength 171,
+// GetObjectArrayElement 173, GetByteArrayRegion 200, SetDoubleArrayRegion 214,
+// ExceptionCheck 228.
+#pragma once
+#include <stdint.h>
+
+extern "C" {
+
+typedef uint8_t jboolean;
+typedef int8_t jbyte;
+typedef uint16_t jchar;
+typedef int16_t jshort;
+typedef int32_t jint;
+typedef int64_t jlong;
+typedef float jfloat;
+typedef double jdouble;
+typedef jint jsize;
+
+struct _jobject;
+typedef struct _jobject* jobject;
+typedef jobject jclass;
+typedef jobject jthrowable;
+typedef jobject jstring;
+typedef jobject jarray;
+typedef jarray jobjectArray;
+typedef jarray jbyteArray;
+typedef jarray jdoubleArray;
+struct _jfieldID;
+typedef struct _jfieldID* jfieldID;
+
+#define JNI_FALSE 0
+#define JNI_TRUE 1
+#define JNI_OK 0
+#define JNI_VERSION_1_8 0x00010008
+
+#define JNIEXPORT __attribute__((visibility("default")))
+#define JNICALL
+
+enum {
+  kJniSlotFindClass = 6,
+  kJniSlotThrowNew = 14,
+  kJniSlotExceptionClear = 17,
+  kJniSlotDeleteLocalRef = 23,
+  kJniSlotGetFieldID = 94,
+  kJniSlotGetObjectField = 95,
+  kJniSlotGetArrayLength = 171,
+  kJniSlotGetObjectArrayElement = 173,
+  kJniSlotGetByteArrayRegion = 200,
+  kJniSlotSetDoubleArrayRegion = 214,
+  kJniSlotExceptionCheck = 228,
+  kJniSlotCount = 235  // JNI 9+: GetModule is 233, IsVirtualThread (21) is 234
+};
+
+struct JNINativeInterface_ {
+  void* slot[kJniSlotCount];
+};
+
+// In C++ the real JNIEnv is `struct JNIEnv_ { const JNINativeInterface_* functions; ... }`
+struct JNIEnv_ {
+  const struct JNINativeInterface_* functions;
+};
+typedef struct JNIEnv_ JNIEnv;
+
+}  // extern "C"
+
+namespace gkljni {
+template <typename F>
+inline F fn(JNIEnv* env, int slot) { return reinterpret_cast<F>(env->functions->slot[slot]); }
+
+inline jclass FindClass(JNIEnv* e, const char* name) {
+  return fn<jclass (*)(JNIEnv*, const char*)>(e, kJniSlotFindClass)(e, name);
+}
+inline jint ThrowNew(JNIEnv* e, jclass c, const char* msg) {
+  return fn<jint (*)(JNIEnv*, jclass, const char*)>(e, kJniSlotThrowNew)(e, c, msg);
+}
+inline void ExceptionClear(JNIEnv* e) { fn<void (*)(JNIEnv*)>(e, kJniSlotExceptionClear)(e); }
+inline jboolean ExceptionCheck(JNIEnv* e) { return fn<jboolean (*)(JNIEnv*)>(e, kJniSlotExceptionCheck)(e); }
+inline void DeleteLocalRef(JNIEnv* e, jobject o) { fn<void (*)(JNIEnv*, jobject)>(e, kJniSlotDeleteLocalRef)(e, o); }
+inline jfieldID GetFieldID(JNIEnv* e, jclass c, const char* name, const char* sig) {
+  return fn<jfieldID (*)(JNIEnv*, jclass, const char*, const char*)>(e, kJniSlotGetFieldID)(e, c, name, sig);
+}
+inline jobject GetObjectField(JNIEnv* e, jobject o, jfieldID f) {
+  return fn<jobject (*)(JNIEnv*, jobject, jfieldID)>(e, kJniSlotGetObjectField)(e, o, f);
+}
+inline jsize GetArrayLength(JNIEnv* e, jarray a) {
+  return fn<jsize (*)(JNIEnv*, jarray)>(e, kJniSlotGetArrayLength)(e, a);
+}
+inline jobject GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) {
+  return fn<jobject (*)(JNIEnv*, jobjectArray, jsize)>(e, kJniSlotGetObjectArrayElement)(e, a, i);
+}
+inline void GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, jbyte* buf) {
+  fn<void (*)(JNIEnv*, jbyteArray, jsize, jsize, jbyte*)>(e, kJniSlotGetByteArrayRegion)(e, a, start, len, buf);
+}
+inline void SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
+  fn<void (*)(JNIEnv*, jdoubleArray, jsize, jsize, const jdouble*)>(e, kJniSlotSetDoubleArrayRegion)(e, a, start, len, buf);
+}
+}  // namespace gkljni

@@ -1,0 +1,93 @@
+"""Multi-GPU sharding of one PairHMM batch: one process per GPU, reads split into contiguous
+ranges, haplotypes replicated, ONE exchange step (gather of the double results to rank 0).
+
+The reference has no distributed path (its only parallelism is an OpenMP loop over pairs,
+src/main/native/pairhmm/IntelPairHmm.cc:151-154); (read, haplotype) pairs are independent, so
+the shard needs no data-path collective -- only the final gather (RCCL over xGMI when the
+backend is "nccl"; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from .batch import FlatBatch
+
+
+def partition_reads(read_lens: Sequence[int], n_parts: int) -> List[int]:
+    """Boundaries b[0]=0 <= ... <= b[n_parts]=n_reads of contiguous read ranges with balanced
+    work.  Work of a read is its length (cells = rslen * sum(haplen), and every shard sees all
+    haplotypes), so this balances cells, not read counts."""
+    lens = np.asarray(read_lens, dtype=np.int64)
+    n = lens.size
+    if n_parts <= 0:
+        raise ValueError("n_parts must be positive")
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    total = int(cum[-1])
+    bounds = [0]
+    for p in range(1, n_parts):
+        target = total * p / n_parts
+        i = int(np.searchsorted(cum, target, side="left"))
+        # choose the closer of the two neighbouring cut points
+        if i > 0 and (i > n or abs(cum[i - 1] - target) <= abs(cum[min(i, n)] - target)):
+            i -= 1
+        bounds.append(min(max(i, bounds[-1]), n))
+    bounds.append(n)
+    return bounds
+
+
+def shard_batch(batch: FlatBatch, rank: int, world: int):
+    """The slice of `batch` rank `rank` computes, plus all boundaries."""
+    bounds = partition_reads(batch.read_lens, world)
+    return batch.read_slice(bounds[rank], bounds[rank + 1]), bounds
+
+
+def gather_to_root(local, rows_per_rank: Sequence[int], n_haps: int, dist_module=None, root: int = 0):
+    """Gather each rank's [rows_g * n_haps] double results on `root`, in rank order.
+
+    `local` is a 1-D torch float64 tensor (CPU for gloo, CUDA for nccl/RCCL).  Slices are
+    padded to the largest shard so one fixed-size gather serves (8 B x pairs/G per rank; at
+    1 M pairs over 8 GPUs that is 1 MB per xGMI link, far below the per-link bandwidth).
+    Returns the concatenated tensor on root, None elsewhere."""
+    import torch
+    dist = dist_module
+    if dist is None:
+        import torch.distributed as dist
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if world == 1:
+        return local
+    max_n = max(rows_per_rank) * n_haps
+    buf = local
+    if local.numel() != max_n:
+        buf = torch.zeros(max_n, dtype=local.dtype, device=local.device)
+        buf[:local.numel()] = local
+    if rank == root:
+        parts = [torch.empty(max_n, dtype=local.dtype, device=local.device) for _ in range(world)]
+        dist.gather(buf, gather_list=parts, dst=root)
+        return torch.cat([p[: rows_per_rank[g] * n_haps] for g, p in enumerate(parts)])
+    dist.gather(buf, gather_list=None, dst=root)
+    return None
+
+
+def compute_sharded(batch: FlatBatch, compute_local: Callable, device: str = "cpu",
+                    dist_module=None) -> Optional[np.ndarray]:
+    """Shard `batch` over the initialised process group, run `compute_local(shard) -> float64
+    array/tensor of shard.n_pairs` on every rank, gather on rank 0 and return the full
+    r-major result there (None on other ranks)."""
+    import torch
+    dist = dist_module
+    if dist is None:
+        import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    shard, bounds = shard_batch(batch, rank, world)
+    rows = [bounds[g + 1] - bounds[g] for g in range(world)]
+    local = compute_local(shard)
+    if not torch.is_tensor(local):
+        local = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+    local = local.to(device)
+    full = gather_to_root(local, rows, batch.n_haps, dist)
+    if full is None:
+        return None
+    return full.cpu().numpy()

@@ -41,7 +41,10 @@ def _edit(rng, seq: np.ndarray, k: int) -> np.ndarray:
 
 
 def make_batch(kind: str = "hc", n_reads: int = 10000, n_haps: int = 128, seed: int = DEFAULT_SEED,
-               read_len=(50, 250), hap_len=(100, 500), max_edits: int = 5) -> FlatBatch:
+               read_len=(50, 250), hap_len=(100, 500), max_edits: int = 5,
+               read_seed: int | None = None) -> FlatBatch:
+    """``seed`` fixes the window and the haplotypes; ``read_seed`` (default: continue the same
+    stream) draws the reads, so several shards can share one haplotype set."""
     if kind not in ("hc", "region", "mixed"):
         raise ValueError(f"unknown synthetic workload {kind!r}")
     rng = np.random.RandomState(seed)
@@ -68,6 +71,8 @@ def make_batch(kind: str = "hc", n_reads: int = 10000, n_haps: int = 128, seed: 
             h = h[:hmax]
         haps.append(h)
 
+    if read_seed is not None:
+        rng = np.random.RandomState(read_seed)
     hap_pick = rng.randint(0, n_haps, size=n_reads)
     want_len = rng.randint(rmin, rmax + 1, size=n_reads)
     rb, rq, ri, rd, lens = [], [], [], [], []

@@ -1,0 +1,50 @@
+/*
+ * gkl_pairhmm_jni.h -- the JNI symbols of libgkl_pairhmm.so, i.e. exactly what GKL's
+ * com.intel.gkl.pairhmm.IntelPairHmm binds (reference
+ * src/main/java/com/intel/gkl/pairhmm/IntelPairHmm.java:157-166; native prototypes
+ * src/main/native/pairhmm/IntelPairHmm.h:38-55; bodies IntelPairHmm.cc:55-57,125-127,189-190).
+ * IntelPairHmmOMP binds the same names (it only changes the library name,
+ * IntelPairHmmOMP.java:29-35), so the same file also serves as libgkl_pairhmm_omp.so.
+ *
+ * Each symbol is a thin shim (gkl_amd/csrc/jni_shim.cpp) over the C ABI of
+ * include/gkl_hip_pairhmm.h.  Define GKL_USE_SYSTEM_JNI to compile against a JDK's
+ * <jni.h>; otherwise the clean-room subset in gkl_amd/csrc/jni_min.h is used (this
+ * image has no JDK).
+ */
+#ifndef GKL_PAIRHMM_JNI_H
+#define GKL_PAIRHMM_JNI_H
+
+#ifdef GKL_USE_SYSTEM_JNI
+#include <jni.h>
+#else
+#include "../gkl_amd/csrc/jni_min.h"
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* static native void initNative(Class<?> readDataHolderClass, Class<?> haplotypeDataHolderClass,
+ *                               boolean doublePrecision, int maxThreads)
+ * Replaces IntelPairHmm.cc:55-118. Caches the six byte[] field IDs (JavaData.h:55-62; failure ->
+ * IllegalArgumentException "Unable to get field ID"), then gklhip_init(). No usable gfx950
+ * device -> java/lang/RuntimeException (there is no CPU path to fall back to). */
+JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
+    JNIEnv* env, jclass cls, jclass readDataHolder, jclass haplotypeDataHolder,
+    jboolean use_double, jint max_threads);
+
+/* native void computeLikelihoodsNative(Object[] readDataArray, Object[] haplotypeDataArray,
+ *                                      double[] likelihoodArray)
+ * Replaces IntelPairHmm.cc:125-181 + JavaData::getData (JavaData.h:65-111): copies the byte[]
+ * fields into a flat batch, gklhip_compute(), writes likelihoodArray[r*numHaps + h]. */
+JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative(
+    JNIEnv* env, jobject obj, jobjectArray readDataArray, jobjectArray haplotypeDataArray,
+    jdoubleArray likelihoodArray);
+
+/* native void doneNative()  -- replaces IntelPairHmm.cc:189-192; releases the device context. */
+JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv* env, jobject obj);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKL_PAIRHMM_JNI_H */

@@ -1,0 +1,213 @@
+// Test harness: a mock JVM side for libgkl_pairhmm.so (no JDK in this image).
+//
+// Builds a JNINativeInterface_ function table (spec slot indices, gkl_amd/csrc/jni_min.h)
+// over a tiny fake object model, dlopen()s the drop-in library the way
+// NativeLibraryLoader/System.load would (reference
+// src/main/java/com/intel/gkl/NativeLibraryLoader.java:114-128), resolves the three
+// Java_com_intel_gkl_pairhmm_IntelPairHmm_* symbols by name like the JVM does, and drives
+// initNative -> computeLikelihoodsNative -> doneNative with ReadDataHolder /
+// HaplotypeDataHolder look-alikes.  Every JNI slot the shim does not declare aborts, so the
+// test also pins the exact set of JNI functions the shim may call.
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../gkl_amd/csrc/jni_min.h"
+
+namespace {
+
+struct Obj {
+  enum Kind { CLASS, BYTES, DOUBLES, OBJARRAY, HOLDER } kind;
+  std::string name;                      // CLASS
+  std::set<std::string> class_fields;    // CLASS
+  std::vector<int8_t> bytes;             // BYTES
+  std::vector<double> doubles;           // DOUBLES
+  std::vector<Obj*> elems;               // OBJARRAY
+  std::map<std::string, Obj*> fields;    // HOLDER (value may be nullptr)
+};
+
+struct Mock {
+  JNIEnv_ env;                 // must be first: JNIEnv* == Mock*
+  JNINativeInterface_ table;
+  std::vector<std::unique_ptr<Obj>> heap;
+  std::set<std::string> field_names;     // interned jfieldIDs
+  bool pending = false;
+  std::string exc_class, exc_msg;
+  long refs_created = 0, refs_deleted = 0, unimplemented_calls = 0;
+  Obj* make(Obj::Kind k) { heap.emplace_back(new Obj()); heap.back()->kind = k; return heap.back().get(); }
+  void raise(const char* cls, const std::string& msg) { pending = true; exc_class = cls; exc_msg = msg; }
+};
+
+Mock* M(JNIEnv* e) { return reinterpret_cast<Mock*>(e); }
+Obj* O(jobject o) { return reinterpret_cast<Obj*>(o); }
+
+void unimplemented() {
+  fprintf(stderr, "mock_jni: the shim called a JNI function it does not declare\n");
+  abort();
+}
+
+jclass m_FindClass(JNIEnv* e, const char* name) {
+  Obj* c = M(e)->make(Obj::CLASS);
+  c->name = name;
+  M(e)->refs_created++;
+  return reinterpret_cast<jclass>(c);
+}
+jint m_ThrowNew(JNIEnv* e, jclass c, const char* msg) {
+  M(e)->raise(O(c)->name.c_str(), msg ? msg : "");
+  return 0;
+}
+void m_ExceptionClear(JNIEnv* e) { M(e)->pending = false; }
+jboolean m_ExceptionCheck(JNIEnv* e) { return M(e)->pending ? JNI_TRUE : JNI_FALSE; }
+void m_DeleteLocalRef(JNIEnv* e, jobject) { M(e)->refs_deleted++; }
+jfieldID m_GetFieldID(JNIEnv* e, jclass c, const char* name, const char* sig) {
+  if (strcmp(sig, "[B") != 0 || !O(c)->class_fields.count(name)) {
+    M(e)->raise("java/lang/NoSuchFieldError", name);
+    return nullptr;
+  }
+  auto it = M(e)->field_names.insert(name).first;
+  return reinterpret_cast<jfieldID>(const_cast<std::string*>(&*it));
+}
+jobject m_GetObjectField(JNIEnv* e, jobject o, jfieldID f) {
+  const std::string& name = *reinterpret_cast<std::string*>(f);
+  auto it = O(o)->fields.find(name);
+  if (it == O(o)->fields.end() || !it->second) return nullptr;
+  M(e)->refs_created++;
+  return reinterpret_cast<jobject>(it->second);
+}
+jsize m_GetArrayLength(JNIEnv*, jarray a) {
+  Obj* o = O(a);
+  return (jsize)(o->kind == Obj::BYTES ? o->bytes.size() : o->kind == Obj::DOUBLES ? o->doubles.size() : o->elems.size());
+}
+jobject m_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) {
+  Obj* o = O(a);
+  if (i < 0 || (size_t)i >= o->elems.size()) { M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "element"); return nullptr; }
+  if (o->elems[i]) M(e)->refs_created++;
+  return reinterpret_cast<jobject>(o->elems[i]);
+}
+void m_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, jbyte* buf) {
+  Obj* o = O(a);
+  if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->bytes.size()) {
+    M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "byte region");
+    return;
+  }
+  memcpy(buf, o->bytes.data() + start, (size_t)len);
+}
+void m_SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
+  Obj* o = O(a);
+  if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->doubles.size()) {
+    M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "double region");
+    return;
+  }
+  memcpy(o->doubles.data() + start, buf, sizeof(double) * (size_t)len);
+}
+
+Obj* bytes_obj(Mock& m, const uint8_t* p, int64_t n) {
+  Obj* o = m.make(Obj::BYTES);
+  o->bytes.assign(reinterpret_cast<const int8_t*>(p), reinterpret_cast<const int8_t*>(p) + n);
+  return o;
+}
+
+typedef void (*init_fn)(JNIEnv*, jclass, jclass, jclass, jboolean, jint);
+typedef void (*compute_fn)(JNIEnv*, jobject, jobjectArray, jobjectArray, jdoubleArray);
+typedef void (*done_fn)(JNIEnv*, jobject);
+
+}  // namespace
+
+extern "C" {
+
+enum {
+  MOCK_DROP_GCP_FIELD = 1,    // ReadDataHolder class lacks overallGCP -> initNative must throw IAE
+  MOCK_NULL_READQUALS = 2,    // read 0 has readQuals == null
+  MOCK_SKIP_INIT = 4,         // call compute without initNative
+  MOCK_SHORT_QUALS = 8,       // read 0's insertionGOP is one byte short
+  MOCK_NULL_READ_ELEMENT = 16 // readDataArray[0] == null
+};
+
+// Returns 0 = ran without a Java exception, 1 = exception pending after initNative,
+// 2 = after computeLikelihoodsNative, -1 = could not load / resolve the library.
+// counters: [0] local refs handed out, [1] DeleteLocalRef calls.
+int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_reads, int n_haps,
+                const int64_t* read_off, const int64_t* hap_off, const uint8_t* rb, const uint8_t* rq,
+                const uint8_t* ri, const uint8_t* rd, const uint8_t* rc, const uint8_t* hb, double* out,
+                int out_len, int flags, char* exc_class, char* exc_msg, long* counters) {
+  exc_class[0] = exc_msg[0] = 0;
+  void* h = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { snprintf(exc_msg, 512, "dlopen: %s", dlerror()); return -1; }
+  init_fn f_init = (init_fn)dlsym(h, "Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative");
+  compute_fn f_compute = (compute_fn)dlsym(h, "Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative");
+  done_fn f_done = (done_fn)dlsym(h, "Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative");
+  if (!f_init || !f_compute || !f_done) { snprintf(exc_msg, 512, "missing JNI symbol"); return -1; }
+
+  Mock m;
+  for (auto& s : m.table.slot) s = reinterpret_cast<void*>(&unimplemented);
+  m.table.slot[kJniSlotFindClass] = (void*)&m_FindClass;
+  m.table.slot[kJniSlotThrowNew] = (void*)&m_ThrowNew;
+  m.table.slot[kJniSlotExceptionClear] = (void*)&m_ExceptionClear;
+  m.table.slot[kJniSlotExceptionCheck] = (void*)&m_ExceptionCheck;
+  m.table.slot[kJniSlotDeleteLocalRef] = (void*)&m_DeleteLocalRef;
+  m.table.slot[kJniSlotGetFieldID] = (void*)&m_GetFieldID;
+  m.table.slot[kJniSlotGetObjectField] = (void*)&m_GetObjectField;
+  m.table.slot[kJniSlotGetArrayLength] = (void*)&m_GetArrayLength;
+  m.table.slot[kJniSlotGetObjectArrayElement] = (void*)&m_GetObjectArrayElement;
+  m.table.slot[kJniSlotGetByteArrayRegion] = (void*)&m_GetByteArrayRegion;
+  m.table.slot[kJniSlotSetDoubleArrayRegion] = (void*)&m_SetDoubleArrayRegion;
+  m.env.functions = &m.table;
+  JNIEnv* env = &m.env;
+
+  Obj* read_cls = m.make(Obj::CLASS);
+  read_cls->name = "org/broadinstitute/gatk/nativebindings/pairhmm/ReadDataHolder";
+  read_cls->class_fields = {"readBases", "readQuals", "insertionGOP", "deletionGOP", "overallGCP"};
+  if (flags & MOCK_DROP_GCP_FIELD) read_cls->class_fields.erase("overallGCP");
+  Obj* hap_cls = m.make(Obj::CLASS);
+  hap_cls->name = "org/broadinstitute/gatk/nativebindings/pairhmm/HaplotypeDataHolder";
+  hap_cls->class_fields = {"haplotypeBases"};
+
+  Obj* reads = m.make(Obj::OBJARRAY);
+  for (int r = 0; r < n_reads; r++) {
+    const int64_t a = read_off[r], n = read_off[r + 1] - a;
+    Obj* holder = m.make(Obj::HOLDER);
+    holder->fields["readBases"] = bytes_obj(m, rb + a, n);
+    holder->fields["readQuals"] = (r == 0 && (flags & MOCK_NULL_READQUALS)) ? nullptr : bytes_obj(m, rq + a, n);
+    holder->fields["insertionGOP"] = bytes_obj(m, ri + a, (r == 0 && (flags & MOCK_SHORT_QUALS)) ? n - 1 : n);
+    holder->fields["deletionGOP"] = bytes_obj(m, rd + a, n);
+    holder->fields["overallGCP"] = bytes_obj(m, rc + a, n);
+    reads->elems.push_back((r == 0 && (flags & MOCK_NULL_READ_ELEMENT)) ? nullptr : holder);
+  }
+  Obj* haps = m.make(Obj::OBJARRAY);
+  for (int k = 0; k < n_haps; k++) {
+    Obj* holder = m.make(Obj::HOLDER);
+    holder->fields["haplotypeBases"] = bytes_obj(m, hb + hap_off[k], hap_off[k + 1] - hap_off[k]);
+    haps->elems.push_back(holder);
+  }
+  Obj* likelihoods = m.make(Obj::DOUBLES);
+  likelihoods->doubles.assign((size_t)out_len, -12345.0);
+
+  int rc_ = 0;
+  if (!(flags & MOCK_SKIP_INIT)) {
+    f_init(env, nullptr, reinterpret_cast<jclass>(read_cls), reinterpret_cast<jclass>(hap_cls),
+           use_double ? JNI_TRUE : JNI_FALSE, max_threads);
+    if (m.pending) rc_ = 1;
+  }
+  if (rc_ == 0) {
+    f_compute(env, nullptr, reinterpret_cast<jobjectArray>(reads), reinterpret_cast<jobjectArray>(haps),
+              reinterpret_cast<jdoubleArray>(likelihoods));
+    if (m.pending) rc_ = 2;
+  }
+  f_done(env, nullptr);
+  memcpy(out, likelihoods->doubles.data(), sizeof(double) * (size_t)out_len);
+  if (m.pending) {
+    snprintf(exc_class, 256, "%s", m.exc_class.c_str());
+    snprintf(exc_msg, 512, "%s", m.exc_msg.c_str());
+  }
+  if (counters) { counters[0] = m.refs_created; counters[1] = m.refs_deleted; }
+  return rc_;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""The JNI drop-in (libgkl_pairhmm.so) driven through a mock JNIEnv -- BASELINE config 1
+("JNI plumbing").  CPU tests pin the symbol surface and the exception mapping; the GPU tests
+run the reference's own test vectors through the full JNI path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gkl_amd.batch import FlatBatch, HaplotypeDataHolder, ReadDataHolder
+from gkl_amd.synth import make_batch
+from tests import mockjni
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def small_batch():
+    return make_batch("hc", 6, 3, seed=21)
+
+
+def test_jni_library_exports_the_three_natives():
+    hdr = open(os.path.join(ROOT, "include", "gkl_pairhmm_jni.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(Java_com_intel_gkl_pairhmm_IntelPairHmm_\w+)\s*\(", hdr)))
+    assert declared == ["Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative",
+                        "Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative",
+                        "Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative"]
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(mockjni.JNI_LIB)
+    for s in declared:
+        assert hasattr(lib, s)
+
+
+def test_jni_slot_indices_follow_the_spec():
+    """The clean-room table must use the JNI specification's indices."""
+    txt = open(os.path.join(ROOT, "gkl_amd", "csrc", "jni_min.h")).read()
+    got = dict(re.findall(r"kJniSlot(\w+) = (\d+)", txt))
+    spec = dict(FindClass=6, ThrowNew=14, ExceptionClear=17, DeleteLocalRef=23, GetFieldID=94,
+                GetObjectField=95, GetArrayLength=171, GetObjectArrayElement=173,
+                GetByteArrayRegion=200, SetDoubleArrayRegion=214, ExceptionCheck=228)
+    for k, v in spec.items():
+        assert int(got[k]) == v, k
+
+
+def test_missing_field_is_illegal_argument():
+    # JavaData.h:127-133: GetFieldID failure -> IllegalArgumentException("Unable to get field ID")
+    rc, _, cls, msg, _ = mockjni.run(small_batch(), flags=mockjni.DROP_GCP_FIELD)
+    assert rc == 1 and cls == "java/lang/IllegalArgumentException" and msg == "Unable to get field ID"
+
+
+def test_compute_before_init_raises():
+    rc, _, cls, msg, _ = mockjni.run(small_batch(), flags=mockjni.SKIP_INIT)
+    assert rc == 2 and cls == "java/lang/RuntimeException" and "initNative" in msg
+
+
+def test_no_gpu_means_runtime_exception_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc, out, cls, msg, _ = mockjni.run(small_batch())
+    assert rc == 1 and cls == "java/lang/RuntimeException" and "device" in msg.lower()
+    assert np.all(out == -12345.0)  # nothing was computed behind our back
+
+
+@pytest.mark.gpu
+def test_jni_full_path_matches_oracle_bit_for_bit(oracle):
+    b = make_batch("hc", 40, 8, seed=33)
+    for use_double in (False, True):
+        rc, out, cls, msg, refs = mockjni.run(b, use_double=use_double)
+        assert rc == 0, (cls, msg)
+        exp = oracle.batch(b, use_double=use_double, n_threads=8)
+        assert out.tobytes() == exp.tobytes()
+        assert refs[0] == refs[1] > 0  # every local ref handed out was deleted
+
+
+@pytest.mark.gpu
+def test_jni_golden_file(golden_cases):
+    # dataFileTest (PairHmmUnitTest.java:171-234): 1 read x 1 hap per call, abs tol 1e-5
+    for c in golden_cases[::13]:
+        b = FlatBatch.from_holders([ReadDataHolder(c["read"], c["q"], c["i"], c["d"], c["c"])],
+                                   [HaplotypeDataHolder(c["hap"])])
+        for use_double in (False, True):
+            rc, out, cls, msg, _ = mockjni.run(b, use_double=use_double)
+            assert rc == 0, (cls, msg)
+            assert abs(out[0] - c["expected"]) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_jni_argument_errors():
+    b = small_batch()
+    rc, _, cls, msg, _ = mockjni.run(b, flags=mockjni.NULL_READQUALS)
+    assert rc == 2 and cls == "java/lang/IllegalArgumentException"
+    rc, _, cls, msg, _ = mockjni.run(b, flags=mockjni.SHORT_QUALS)
+    assert rc == 2 and cls == "java/lang/IllegalArgumentException"
+    rc, _, cls, msg, _ = mockjni.run(b, flags=mockjni.NULL_READ_ELEMENT)
+    assert rc == 2 and cls == "java/lang/IllegalArgumentException"
+    rc, out, cls, msg, _ = mockjni.run(b, out_len=b.n_pairs - 1)
+    assert rc == 2 and cls == "java/lang/IllegalArgumentException" and np.all(out == -12345.0)

@@ -1,0 +1,67 @@
+"""The N>1 path on CPU: partitioning + a world_size-2 gloo run of the shard/gather logic,
+with the oracle standing in for the per-rank compute (the GPU kernels are covered by
+test_gpu_parity; this covers what is distributed: slicing, ordering, padding, gather)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gkl_amd.shard import compute_sharded, partition_reads, shard_batch
+from gkl_amd.synth import make_batch
+
+
+def test_partition_balances_work_and_covers_all_reads():
+    rng = np.random.RandomState(0)
+    lens = rng.randint(50, 251, size=1000)
+    for parts in (1, 2, 3, 4, 8):
+        b = partition_reads(lens, parts)
+        assert b[0] == 0 and b[-1] == 1000 and all(b[i] <= b[i + 1] for i in range(parts))
+        work = [lens[b[i]:b[i + 1]].sum() for i in range(parts)]
+        assert max(work) - min(work) <= 2 * 250
+    assert partition_reads([5], 4) == [0, 0, 0, 1, 1] or partition_reads([5], 4)[-1] == 1
+
+
+def test_shards_reassemble_the_batch():
+    b = make_batch("hc", 37, 5, seed=2)
+    rows = 0
+    for r in range(3):
+        s, bounds = shard_batch(b, r, 3)
+        lo, hi = bounds[r], bounds[r + 1]
+        assert s.n_reads == hi - lo and s.n_haps == b.n_haps
+        assert s.read_bases.tobytes() == b.read_bases[b.read_off[lo]:b.read_off[hi]].tobytes()
+        assert np.array_equal(s.read_off, b.read_off[lo:hi + 1] - b.read_off[lo])
+        rows += s.n_reads
+    assert rows == b.n_reads
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.oracle import Oracle
+        oracle = Oracle()
+        batch = make_batch("hc", 23, 4, seed=9)  # odd count: shards have different sizes
+        full = compute_sharded(batch, lambda s: oracle.batch(s, n_threads=1), device="cpu")
+        if rank == 0:
+            expect = oracle.batch(batch, n_threads=1)
+            ret["ok"] = bool(full is not None and full.tobytes() == expect.tobytes())
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo_gather_matches_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get("ok") is True
