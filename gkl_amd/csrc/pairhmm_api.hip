@@ -245,6 +245,11 @@ void launch_stream(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
   if (fma) hipLaunchKernelGGL((pairhmm_fwd_stream_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
   else     hipLaunchKernelGGL((pairhmm_fwd_stream_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
 }
+template <int RPL>
+void launch_stream2(const FwdArgs<float>& a, int fma, int n_blocks, hipStream_t s) {
+  if (fma) hipLaunchKernelGGL((pairhmm_fwd_stream2_kernel<RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
+  else     hipLaunchKernelGGL((pairhmm_fwd_stream2_kernel<RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
+}
 template <typename T, int RPL>
 void launch_pairs(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
   if (fma) hipLaunchKernelGGL((pairhmm_fwd_pairs_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
@@ -252,8 +257,10 @@ void launch_pairs(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
 }
 
 // rows-per-lane choices: a read of length R needs (R+1) rows <= 64*RPL
+// (4 selects the dual-chunk packed-math kernel: 2 chunks x 4 rows per lane)
 int pick_rpl_f32(int max_read, int forced) {
-  if (forced == 8 || forced == 16) return (max_read + 1 <= 64 * forced) ? forced : 0;
+  if (forced == 4 || forced == 8 || forced == 16) return (max_read + 1 <= 64 * forced) ? forced : 0;
+  if (max_read + 1 <= 64 * 4) return 4;
   if (max_read + 1 <= 64 * 8) return 8;
   if (max_read + 1 <= 64 * 16) return 16;
   return 0;
@@ -392,8 +399,9 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.tab = c->dt32;
     a.y0 = reinterpret_cast<const float*>(dp + L.y0_32);
     a.raw = c->raw32.as<float>();
-    if (rpl_main == 8) launch_stream<float, 8>(a, fma, n_main_blocks, s);
-    else               launch_stream<float, 16>(a, fma, n_main_blocks, s);
+    if (rpl_main == 4)      launch_stream2<4>(a, fma, ((plan.n_chunks + 1) / 2) * (int)plan.groups.size(), s);
+    else if (rpl_main == 8) launch_stream<float, 8>(a, fma, n_main_blocks, s);
+    else                    launch_stream<float, 16>(a, fma, n_main_blocks, s);
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa);
     // fp64 recomputation of the queued pairs (persistent wavefronts; count stays on the device)

@@ -329,6 +329,218 @@ struct WaveJob {
   }
 };
 
+// ---- the dual-chunk fp32 job: packed math ------------------------------------
+// Two independent 64-lane chunks share one wavefront: lane L holds RPL rows of chunk A
+// and RPL rows of chunk B as float2 register pairs (A in .x, B in .y).  Both chunks see
+// the same haplotype stream, so every operation of the recurrence is the same
+// instruction on naturally aligned pairs -> v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32
+// with no shuffles (a single chunk cannot be packed: row s needs row s-1, which is
+// never pair-aligned with it).  Same arithmetic per element, hence the same bits.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f fma_v(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+template <bool FMA>
+__device__ __forceinline__ v2f mul_add2_v(v2f a, v2f b, v2f c, v2f d) {
+  if (FMA) return fma_v(a, b, c * d);
+  return c * d + a * b;
+}
+template <bool FMA>
+__device__ __forceinline__ v2f m_inner_v(v2f md, v2f xd, v2f yd, v2f pmm, v2f pgapm) {
+  if (FMA) return fma_v(yd, pgapm, fma_v(xd, pgapm, md * pmm));
+  return (md * pmm + xd * pgapm) + yd * pgapm;
+}
+
+template <int RPL, bool FMA>
+struct WaveJob2 {
+  static_assert(RPL % 2 == 0, "two rows x two chunks fill one 16-byte LDS vector");
+  static constexpr int kPlanes = RPL / 2;                 // float4 = (A[2p], B[2p], A[2p+1], B[2p+1])
+  static constexpr int kRowBytes = kPlanes * kLanes * 16;  // one base code
+  static constexpr int kLdsBytes = 6 * kRowBytes;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+
+  v2f M[RPL], X[RPL], Y[RPL];
+  v2f pMM[RPL], pGAPM[RPL], pMX[RPL], pXX[RPL], pMY[RPL];
+  v2f dM, dX, dY, sM, sX;
+  uint32_t ent;
+  uint32_t lmask[2];
+  int32_t out_read[2];
+  int32_t padb_slot[2];
+  unsigned char* lds;
+
+  // rows of ONE chunk's lane (same layout rules as WaveJob::setup)
+  __device__ __forceinline__ void load_rows(const FwdArgs<float>& a, LaneSlot slot, int which, float* match,
+                                            float* mism, int* code) {
+    int R = 0, first = 0;
+    int64_t roff = 0;
+    out_read[which] = -1;
+    padb_slot[which] = -1;
+    lmask[which] = 0u;
+    if (slot.read >= 0) {
+      roff = a.b.read_off[slot.read];
+      R = (int)(a.b.read_off[slot.read + 1] - roff);
+      const int n_blocks = (R + RPL) / RPL;
+      const int pads = n_blocks * RPL - R;
+      first = slot.block * RPL - pads;
+      if (slot.block == n_blocks - 1) out_read[which] = slot.read;
+      if (slot.block != 0) lmask[which] = ~0u;
+    }
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+      const int v = first + s;
+      float mm = 0.f, gapm = 0.f, mx = 0.f, xx = 0.f, my = 0.f;
+      match[s] = mism[s] = 0.f;
+      code[s] = -1;
+      if (slot.read >= 0 && v >= 0) {
+        const int64_t at = roff + v;
+        const int qi = a.b.ins[at] & 127, qd = a.b.del[at] & 127, qc = a.b.gcp[at] & 127;
+        const int qq = a.b.read_quals[at] & 127;
+        const int hi = qi > qd ? qi : qd, lo = qi > qd ? qd : qi;
+        mm = a.tab.mm[((hi * (hi + 1)) >> 1) + lo];
+        const float pc = a.tab.ph2pr[qc];
+        gapm = 1.0f - pc;
+        mx = a.tab.ph2pr[qi];
+        xx = pc;
+        my = a.tab.ph2pr[qd];
+        match[s] = 1.0f - a.tab.ph2pr[qq];
+        mism[s] = a.tab.div3[qq];
+        const uint8_t bb = a.b.read_bases[at];
+        code[s] = bb == 'C' ? 1 : bb == 'T' ? 2 : bb == 'G' ? 3 : bb == 'N' ? 4 : 0;
+      } else if (slot.read >= 0 && v == -1) {
+        xx = 1.0f;
+        padb_slot[which] = s;
+      }
+      pMM[s][which] = mm; pGAPM[s][which] = gapm; pMX[s][which] = mx; pXX[s][which] = xx; pMY[s][which] = my;
+    }
+  }
+
+  __device__ __forceinline__ void setup(const FwdArgs<float>& a, int lane, LaneSlot sa, LaneSlot sb) {
+    float matchA[RPL], mismA[RPL], matchB[RPL], mismB[RPL];
+    int codeA[RPL], codeB[RPL];
+    load_rows(a, sa, 0, matchA, mismA, codeA);
+    load_rows(a, sb, 1, matchB, mismB, codeB);
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+#pragma unroll
+      for (int pl = 0; pl < kPlanes; pl++) {
+        v4f v;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const int s = pl * 2 + k;
+          const bool hitA = (c == codeA[s]) || (c == 4) || (codeA[s] == 4);
+          const bool hitB = (c == codeB[s]) || (c == 4) || (codeB[s] == 4);
+          v[2 * k + 0] = (c == 5 || codeA[s] < 0) ? 0.f : (hitA ? matchA[s] : mismA[s]);
+          v[2 * k + 1] = (c == 5 || codeB[s] < 0) ? 0.f : (hitB ? matchB[s] : mismB[s]);
+        }
+        *reinterpret_cast<v4f*>(lds + c * kRowBytes + pl * (kLanes * 16) + lane * 16) = v;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void reset_state(float y0) {
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+      M[s] = X[s] = v2f{0.f, 0.f};
+      Y[s] = v2f{s == padb_slot[0] ? y0 : 0.f, s == padb_slot[1] ? y0 : 0.f};
+    }
+    dM = dX = dY = sM = sX = v2f{0.f, 0.f};
+    ent = kEntIdle;
+  }
+
+  __device__ __forceinline__ void load_priors(uint32_t code, int lane, v2f* pr) const {
+    const unsigned char* p = lds + code * (uint32_t)kRowBytes + (uint32_t)lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < kPlanes; pl++) {
+      const v4f v = *reinterpret_cast<const v4f*>(p + pl * (kLanes * 16));
+      pr[2 * pl] = v2f{v[0], v[1]};
+      pr[2 * pl + 1] = v2f{v[2], v[3]};
+    }
+  }
+
+  __device__ __forceinline__ v2f recv2(v2f v) const {
+    return v2f{recv_above(v.x, lmask[0]), recv_above(v.y, lmask[1])};
+  }
+
+  __device__ __forceinline__ void advance(const v2f* pr, v2f rM, v2f rX, v2f* nM, v2f* nX, v2f* nY) const {
+    nM[0] = m_inner_v<FMA>(dM, dX, dY, pMM[0], pGAPM[0]) * pr[0];
+#pragma unroll
+    for (int s = 1; s < RPL; s++)
+      nM[s] = m_inner_v<FMA>(M[s - 1], X[s - 1], Y[s - 1], pMM[s], pGAPM[s]) * pr[s];
+#pragma unroll
+    for (int s = 0; s < RPL; s++) nY[s] = mul_add2_v<FMA>(Y[s], pXX[s], M[s], pMY[s]);
+    nX[0] = mul_add2_v<FMA>(rX, pXX[0], rM, pMX[0]);
+#pragma unroll
+    for (int s = 1; s < RPL; s++) nX[s] = mul_add2_v<FMA>(nX[s - 1], pXX[s], nM[s - 1], pMX[s]);
+  }
+
+  __device__ __forceinline__ void step_fast(uint32_t entry, int lane) {
+    ent = dpp_shr1_keep(entry, ent);
+    const v2f rM = recv2(M[RPL - 1]), rX = recv2(X[RPL - 1]), rY = recv2(Y[RPL - 1]);
+    v2f pr[RPL], nM[RPL], nX[RPL], nY[RPL];
+    load_priors(ent, lane, pr);
+    advance(pr, rM, rX, nM, nX, nY);
+#pragma unroll
+    for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
+    dM = rM; dX = rX; dY = rY;
+    sM = sM + nM[RPL - 1];
+    sX = sX + nX[RPL - 1];
+  }
+
+  __device__ __forceinline__ void step_any(const FwdArgs<float>& a, uint32_t entry, int lane, int hap_begin,
+                                           int hap_end) {
+    ent = dpp_shr1_keep(entry, ent);
+    const v2f rM = recv2(M[RPL - 1]), rX = recv2(X[RPL - 1]), rY = recv2(Y[RPL - 1]);
+    const bool sep = (int32_t)ent < 0;
+    const uint32_t code = sep ? kEntIdle : ent;
+    v2f pr[RPL], nM[RPL], nX[RPL], nY[RPL];
+    load_priors(code, lane, pr);
+    advance(pr, rM, rX, nM, nX, nY);
+    if (sep) {
+      const int k = (int)(ent & 0x7fffffffu);
+      const bool mine = (k >= hap_begin) && (k < hap_end);
+      const v2f tot = sM + sX;
+      if (mine && out_read[0] >= 0) a.raw[(int64_t)out_read[0] * a.b.n_haps + a.hap_orig[k]] = tot.x;
+      if (mine && out_read[1] >= 0) a.raw[(int64_t)out_read[1] * a.b.n_haps + a.hap_orig[k]] = tot.y;
+      const float y0n = (mine && k + 1 < hap_end) ? a.y0[k + 1] : 0.f;
+#pragma unroll
+      for (int s = 0; s < RPL; s++) {
+        M[s] = X[s] = v2f{0.f, 0.f};
+        Y[s] = v2f{s == padb_slot[0] ? y0n : 0.f, s == padb_slot[1] ? y0n : 0.f};
+      }
+      sM = sX = v2f{0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
+      sM = sM + nM[RPL - 1];
+      sX = sX + nX[RPL - 1];
+    }
+    dM = rM; dX = rX; dY = rY;
+  }
+
+  __device__ __forceinline__ void run(const FwdArgs<float>& a, int lane, int hap_begin, int hap_end) {
+    constexpr int U = 8;
+    const int sb = a.hap_pos[hap_begin];
+    const uint32_t* __restrict__ sp = a.stream + sb;
+    reset_state(a.y0[hap_begin]);
+    int t = 0;
+    int fast_from = kLanes - 1;
+    for (int k = hap_begin; k < hap_end; k++) {
+      const int sep_at = a.hap_pos[k] - sb + a.hap_len[k];
+      const int slow_end = fast_from < sep_at ? fast_from : sep_at;
+      for (; t < slow_end; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
+      for (; t + U <= sep_at; t += U) {
+        uint32_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = sp[t + u];
+#pragma unroll
+        for (int u = 0; u < U; u++) step_fast(e[u], lane);
+      }
+      for (; t < sep_at; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
+      fast_from = sep_at + kLanes;
+    }
+    for (; t < fast_from; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
+  }
+};
+
 // ---- kernels -------------------------------------------------------------------
 // Main pass: block (one wavefront) = (chunk of packed reads) x (haplotype group).
 template <typename T, int RPL, bool FMA>
@@ -342,6 +554,27 @@ __global__ __launch_bounds__(64) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
   Job job;
   job.lds = lds;
   job.setup(a, lane, a.chunk_lanes[(int64_t)chunk * kLanes + lane]);
+  __syncthreads();
+  job.run(a, lane, grp.hap_begin, grp.hap_end);
+}
+
+// Main fp32 pass, packed: block = (two chunks of packed reads) x (haplotype group).
+template <int RPL, bool FMA>
+__global__ __launch_bounds__(64) void pairhmm_fwd_stream2_kernel(FwdArgs<float> a) {
+  using Job = WaveJob2<RPL, FMA>;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
+  const int lane = threadIdx.x;
+  const int pair = blockIdx.x / a.n_groups;
+  const int g = blockIdx.x - pair * a.n_groups;
+  const HapGroup grp = a.groups[g];
+  const int ca = 2 * pair, cb = 2 * pair + 1;
+  LaneSlot sa = a.chunk_lanes[(int64_t)ca * kLanes + lane];
+  LaneSlot sb;
+  sb.read = -1; sb.block = 0;
+  if (cb < a.n_chunks) sb = a.chunk_lanes[(int64_t)cb * kLanes + lane];
+  Job job;
+  job.lds = lds;
+  job.setup(a, lane, sa, sb);
   __syncthreads();
   job.run(a, lane, grp.hap_begin, grp.hap_end);
 }

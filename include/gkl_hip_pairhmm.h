@@ -72,7 +72,7 @@ typedef struct {
                            0 = arithmetic of GKL's AVX objects (separate mul/add) */
   int32_t finalize;     /* gklhip_finalize for gklhip_compute_device; -1 = default */
   int32_t record_events;/* 1 = bracket kernels with HIP events (gklhip_get_stats) */
-  int32_t rows_per_lane;/* 0 = auto; otherwise force the fp32 kernel variant (8 or 16) */
+  int32_t rows_per_lane;/* 0 = auto; otherwise force the fp32 kernel variant: 4 (two packed chunks), 8, 16 */
 } gklhip_config;
 
 /* Flat structure-of-arrays batch. Offsets always live on the host; the byte

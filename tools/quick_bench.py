@@ -19,11 +19,12 @@ ap.add_argument("--haps", type=int, default=128)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--double", action="store_true")
 ap.add_argument("--rpl", type=int, default=0)
+ap.add_argument("--lib", default=None)
 a = ap.parse_args()
 
 b = make_batch(a.kind, a.reads, a.haps)
 db = native.DeviceBatch.upload(b)
-ctx = native.PairHmmContext(use_double=a.double, record_events=True, rows_per_lane=a.rpl)
+ctx = native.PairHmmContext(use_double=a.double, record_events=True, rows_per_lane=a.rpl, lib_path=a.lib)
 out = ctx.compute_device(db)
 torch.cuda.synchronize()
 for i in range(a.steps):
@@ -33,7 +34,9 @@ for i in range(a.steps):
     dt = time.time() - t
     st = ctx.stats()
     fb = st["n_fallback"]
-    print(f"{a.kind} {a.reads}x{a.haps} cells {b.cells:.3e} wall {dt*1e3:.2f} ms -> {b.cells/dt/1e9:.1f} GCUPS | "
+    if i < a.steps - 1:
+        continue
+    print(f"{a.lib or 'default'}: {a.kind} {a.reads}x{a.haps} cells {b.cells:.3e} wall {dt*1e3:.2f} ms -> {b.cells/dt/1e9:.1f} GCUPS | "
           f"main {st['ms_fwd_main']:.2f} ms ({b.cells/st['ms_fwd_main']/1e6:.1f} GCUPS) fallback {st['ms_fwd_fallback']:.2f} ms "
           f"(n={fb}, {fb/b.n_pairs:.3f}) total_dev {st['ms_total_device']:.2f} ms chunks {st['n_chunks']} groups {st['n_hap_groups']} "
           f"rpl {st['rows_per_lane']} fill {st['lane_fill']:.3f}")
