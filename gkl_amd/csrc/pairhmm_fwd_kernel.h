@@ -26,7 +26,7 @@
 //     transition probabilities, so a read boundary inside the array costs no
 //     instructions; lanes that start a read zero their incoming values with a
 //     per-lane AND mask (isolates pairs from each other, NaN/Inf included).
-//   * The match/mismatch prior is a 6 x rows table in LDS indexed by the
+//   * The match/mismatch prior is a 5 x rows table in LDS indexed by the
 //     haplotype base code of the lane's current column: one ds_read_b128 per
 //     four rows replaces a compare+select per cell.
 //   * No MFMA: this is a recurrence, not a contraction.  The roofline is the fp32
@@ -37,7 +37,7 @@
 
 namespace gklhip {
 
-constexpr uint32_t kEntIdle = 5u;           // stream entry: idle column (prior row of zeros)
+constexpr uint32_t kEntIdle = 5u;           // stream entry: idle column (prior 0, no LDS row)
 constexpr uint32_t kEntSep = 0x80000000u;   // stream entry: separator | stream-order hap index
 constexpr int kLanes = 64;
 
@@ -93,21 +93,58 @@ struct FwdArgs {
 // ---- cross-lane helpers -----------------------------------------------------
 // wave_shr:1 (DPP ctrl 0x138): lane L reads lane L-1 across the whole wavefront;
 // lane 0 keeps `old` (bound_ctrl off) or reads 0 (bound_ctrl on).
+//
+// GKL_DPP_NOP=1 writes the DPP ops as inline asm that always carries an `s_nop 1` (in
+// tools/ubench_mix.hip a DPP op straight behind VALU work costs ~11 extra cycles, behind an
+// s_nop none).  In the real kernels it measured neutral (single chunk) to -4 % (dual chunk),
+// so the compiler-scheduled builtin stays the default.
+#ifndef GKL_DPP_NOP
+#define GKL_DPP_NOP 0
+#endif
 __device__ __forceinline__ uint32_t dpp_shr1_keep(uint32_t old, uint32_t src) {
+  if (GKL_DPP_NOP) {
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+    return old;
+  }
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138, 0xf, 0xf, false);
 }
 __device__ __forceinline__ uint32_t dpp_shr1_zero(uint32_t src) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x138, 0xf, 0xf, true);
 }
+// (lane above) & mask in one instruction
+__device__ __forceinline__ uint32_t dpp_shr1_and(uint32_t src, uint32_t mask) {
+  if (GKL_DPP_NOP) {
+    uint32_t d;
+    asm volatile("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "=v"(d) : "v"(src), "v"(mask));
+    return d;
+  }
+  return dpp_shr1_zero(src) & mask;
+}
 // value of the lane above, ANDed with this lane's mask (0 for lanes that start a
 // read or are idle, ~0 otherwise).
+#ifndef GKL_ABL
+#define GKL_ABL 0  // timing ablations for tools/ablate.sh (results are WRONG when != 0)
+#endif
+#ifndef GKL_XLANE
+#define GKL_XLANE 0  // 0: DPP wave_shr:1 (VALU)   1: ds_bpermute_b32 (LDS crossbar, no LDS memory)
+#endif
+__device__ __forceinline__ uint32_t lane_above_u32(uint32_t v) {
+  if (GKL_XLANE == 1) {
+    const int src = (int)((__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) - 1u) & 63u) << 2;
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v);
+  }
+  return dpp_shr1_zero(v);
+}
 __device__ __forceinline__ float recv_above(float v, uint32_t lmask) {
-  return __uint_as_float(dpp_shr1_zero(__float_as_uint(v)) & lmask);
+  if (GKL_ABL == 1) return __uint_as_float(__float_as_uint(v) & lmask);
+  if (GKL_XLANE == 0) return __uint_as_float(dpp_shr1_and(__float_as_uint(v), lmask));
+  return __uint_as_float(lane_above_u32(__float_as_uint(v)) & lmask);
 }
 __device__ __forceinline__ double recv_above(double v, uint32_t lmask) {
   const uint64_t u = (uint64_t)__double_as_longlong(v);
-  const uint32_t lo = dpp_shr1_zero((uint32_t)u) & lmask;
-  const uint32_t hi = dpp_shr1_zero((uint32_t)(u >> 32)) & lmask;
+  const uint32_t lo = GKL_XLANE == 0 ? dpp_shr1_and((uint32_t)u, lmask) : (lane_above_u32((uint32_t)u) & lmask);
+  const uint32_t hi = GKL_XLANE == 0 ? dpp_shr1_and((uint32_t)(u >> 32), lmask) : (lane_above_u32((uint32_t)(u >> 32)) & lmask);
   return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
@@ -134,7 +171,7 @@ struct WaveJob {
   static constexpr int kPerVec = kVecBytes / (int)sizeof(T);        // rows per 16-byte LDS vector
   static constexpr int kPlanes = RPL / kPerVec;                      // 16-byte vectors per lane per code
   static constexpr int kRowBytes = kPlanes * kLanes * kVecBytes;     // one base code, all rows
-  static constexpr int kLdsBytes = 6 * kRowBytes;
+  static constexpr int kLdsBytes = 5 * kRowBytes;  // codes A C T G N; idle columns are handled in step_any
   static_assert(RPL % kPerVec == 0, "RPL must fill whole 16-byte vectors");
   using Vec = T __attribute__((ext_vector_type(kPerVec)));
 
@@ -142,6 +179,7 @@ struct WaveJob {
   T M[RPL], X[RPL], Y[RPL];
   T pMM[RPL], pGAPM[RPL], pMX[RPL], pXX[RPL], pMY[RPL];
   T dM, dX, dY;       // row above at the previous column (diagonal inputs)
+  T rM, rX, rY;       // row above at this lane's NEXT column, fetched at the end of the previous step
   T sM, sX;           // running sums of the lane's bottom row
   uint32_t ent;       // this lane's current stream entry
   uint32_t lmask;     // 0 if this lane starts a read / is idle
@@ -201,7 +239,7 @@ struct WaveJob {
     }
     // prior table: [base code 0..5][plane][lane][kPerVec rows]
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
+    for (int c = 0; c < 5; c++) {
 #pragma unroll
       for (int pl = 0; pl < kPlanes; pl++) {
         Vec v;
@@ -210,7 +248,7 @@ struct WaveJob {
           const int s = pl * kPerVec + k;
           const bool real = code[s] >= 0;
           const bool hit = (c == code[s]) || (c == 4) || (code[s] == 4);
-          v[k] = (c == 5 || !real) ? T(0) : (hit ? match[s] : mism[s]);
+          v[k] = !real ? T(0) : (hit ? match[s] : mism[s]);
         }
         *reinterpret_cast<Vec*>(lds + c * kRowBytes + pl * (kLanes * kVecBytes) + lane * kVecBytes) = v;
       }
@@ -226,6 +264,15 @@ struct WaveJob {
     dM = dX = dY = T(0);
     sM = sX = T(0);
     ent = kEntIdle;
+    fetch_above();
+  }
+
+  // Cross-lane hand-off, issued at the END of a step so its DPP latency hides behind the
+  // next step's M/Y updates: the lane above has just finished the column this lane does next.
+  __device__ __forceinline__ void fetch_above() {
+    rM = recv_above(M[RPL - 1], lmask);
+    rX = recv_above(X[RPL - 1], lmask);
+    rY = recv_above(Y[RPL - 1], lmask);
   }
 
   __device__ __forceinline__ void load_priors(uint32_t code, int lane, T* pr) const {
@@ -239,7 +286,7 @@ struct WaveJob {
   }
 
   // One anti-diagonal step of the recurrence for this lane's RPL rows.
-  __device__ __forceinline__ void advance(const T* pr, T rM, T rX, T* nM, T* nX, T* nY) const {
+  __device__ __forceinline__ void advance(const T* pr, T* nM, T* nX, T* nY) const {
     nM[0] = m_inner<FMA>(dM, dX, dY, pMM[0], pGAPM[0]) * pr[0];
 #pragma unroll
     for (int s = 1; s < RPL; s++)
@@ -253,16 +300,17 @@ struct WaveJob {
 
   // Fast step: every lane is inside a haplotype (entry = base code 0..4).
   __device__ __forceinline__ void step_fast(uint32_t entry, int lane) {
+    if (GKL_ABL == 4) ent = entry; else
     ent = dpp_shr1_keep(entry, ent);
-    const T rM = recv_above(M[RPL - 1], lmask);
-    const T rX = recv_above(X[RPL - 1], lmask);
-    const T rY = recv_above(Y[RPL - 1], lmask);
     T pr[RPL], nM[RPL], nX[RPL], nY[RPL];
+    if (GKL_ABL == 2) { for (int s = 0; s < RPL; s++) pr[s] = pMM[s]; } else
     load_priors(ent, lane, pr);
-    advance(pr, rM, rX, nM, nX, nY);
+    advance(pr, nM, nX, nY);
 #pragma unroll
     for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
     dM = rM; dX = rX; dY = rY;
+    fetch_above();
+    if (GKL_ABL == 3) return;
     sM = sM + nM[RPL - 1];  // ascending-column sums (:354-369)
     sX = sX + nX[RPL - 1];
   }
@@ -272,14 +320,13 @@ struct WaveJob {
   __device__ __forceinline__ void step_any(const FwdArgs<T>& a, uint32_t entry, int lane,
                                            int hap_begin, int hap_end) {
     ent = dpp_shr1_keep(entry, ent);
-    const T rM = recv_above(M[RPL - 1], lmask);
-    const T rX = recv_above(X[RPL - 1], lmask);
-    const T rY = recv_above(Y[RPL - 1], lmask);
     const bool sep = (int32_t)ent < 0;
-    const uint32_t code = sep ? kEntIdle : ent;
+    const bool off = sep || ent == kEntIdle;  // no haplotype base in this column: prior 0
     T pr[RPL], nM[RPL], nX[RPL], nY[RPL];
-    load_priors(code, lane, pr);
-    advance(pr, rM, rX, nM, nX, nY);
+    load_priors(off ? 0u : ent, lane, pr);
+#pragma unroll
+    for (int s = 0; s < RPL; s++) pr[s] = off ? T(0) : pr[s];
+    advance(pr, nM, nX, nY);
     if (sep) {
       const int k = (int)(ent & 0x7fffffffu);
       const bool mine = (k >= hap_begin) && (k < hap_end);
@@ -301,6 +348,7 @@ struct WaveJob {
       sX = sX + nX[RPL - 1];
     }
     dM = rM; dX = rX; dY = rY;
+    fetch_above();
   }
 
   // Stream haplotypes [hap_begin, hap_end) (stream order) through the loaded rows.
@@ -355,12 +403,12 @@ struct WaveJob2 {
   static_assert(RPL % 2 == 0, "two rows x two chunks fill one 16-byte LDS vector");
   static constexpr int kPlanes = RPL / 2;                 // float4 = (A[2p], B[2p], A[2p+1], B[2p+1])
   static constexpr int kRowBytes = kPlanes * kLanes * 16;  // one base code
-  static constexpr int kLdsBytes = 6 * kRowBytes;
+  static constexpr int kLdsBytes = 5 * kRowBytes;  // codes A C T G N; idle columns are handled in step_any
   typedef float v4f __attribute__((ext_vector_type(4)));
 
   v2f M[RPL], X[RPL], Y[RPL];
   v2f pMM[RPL], pGAPM[RPL], pMX[RPL], pXX[RPL], pMY[RPL];
-  v2f dM, dX, dY, sM, sX;
+  v2f dM, dX, dY, rM, rX, rY, sM, sX;
   uint32_t ent;
   uint32_t lmask[2];
   int32_t out_read[2];
@@ -419,7 +467,7 @@ struct WaveJob2 {
     load_rows(a, sa, 0, matchA, mismA, codeA);
     load_rows(a, sb, 1, matchB, mismB, codeB);
 #pragma unroll
-    for (int c = 0; c < 6; c++) {
+    for (int c = 0; c < 5; c++) {
 #pragma unroll
       for (int pl = 0; pl < kPlanes; pl++) {
         v4f v;
@@ -428,8 +476,8 @@ struct WaveJob2 {
           const int s = pl * 2 + k;
           const bool hitA = (c == codeA[s]) || (c == 4) || (codeA[s] == 4);
           const bool hitB = (c == codeB[s]) || (c == 4) || (codeB[s] == 4);
-          v[2 * k + 0] = (c == 5 || codeA[s] < 0) ? 0.f : (hitA ? matchA[s] : mismA[s]);
-          v[2 * k + 1] = (c == 5 || codeB[s] < 0) ? 0.f : (hitB ? matchB[s] : mismB[s]);
+          v[2 * k + 0] = codeA[s] < 0 ? 0.f : (hitA ? matchA[s] : mismA[s]);
+          v[2 * k + 1] = codeB[s] < 0 ? 0.f : (hitB ? matchB[s] : mismB[s]);
         }
         *reinterpret_cast<v4f*>(lds + c * kRowBytes + pl * (kLanes * 16) + lane * 16) = v;
       }
@@ -444,6 +492,13 @@ struct WaveJob2 {
     }
     dM = dX = dY = sM = sX = v2f{0.f, 0.f};
     ent = kEntIdle;
+    fetch_above();
+  }
+
+  __device__ __forceinline__ void fetch_above() {
+    rM = recv2(M[RPL - 1]);
+    rX = recv2(X[RPL - 1]);
+    rY = recv2(Y[RPL - 1]);
   }
 
   __device__ __forceinline__ void load_priors(uint32_t code, int lane, v2f* pr) const {
@@ -460,7 +515,7 @@ struct WaveJob2 {
     return v2f{recv_above(v.x, lmask[0]), recv_above(v.y, lmask[1])};
   }
 
-  __device__ __forceinline__ void advance(const v2f* pr, v2f rM, v2f rX, v2f* nM, v2f* nX, v2f* nY) const {
+  __device__ __forceinline__ void advance(const v2f* pr, v2f* nM, v2f* nX, v2f* nY) const {
     nM[0] = m_inner_v<FMA>(dM, dX, dY, pMM[0], pGAPM[0]) * pr[0];
 #pragma unroll
     for (int s = 1; s < RPL; s++)
@@ -473,14 +528,17 @@ struct WaveJob2 {
   }
 
   __device__ __forceinline__ void step_fast(uint32_t entry, int lane) {
+    if (GKL_ABL == 4) ent = entry; else
     ent = dpp_shr1_keep(entry, ent);
-    const v2f rM = recv2(M[RPL - 1]), rX = recv2(X[RPL - 1]), rY = recv2(Y[RPL - 1]);
     v2f pr[RPL], nM[RPL], nX[RPL], nY[RPL];
+    if (GKL_ABL == 2) { for (int s = 0; s < RPL; s++) pr[s] = pMM[s]; } else
     load_priors(ent, lane, pr);
-    advance(pr, rM, rX, nM, nX, nY);
+    advance(pr, nM, nX, nY);
 #pragma unroll
     for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
     dM = rM; dX = rX; dY = rY;
+    fetch_above();
+    if (GKL_ABL == 3) return;
     sM = sM + nM[RPL - 1];
     sX = sX + nX[RPL - 1];
   }
@@ -488,12 +546,13 @@ struct WaveJob2 {
   __device__ __forceinline__ void step_any(const FwdArgs<float>& a, uint32_t entry, int lane, int hap_begin,
                                            int hap_end) {
     ent = dpp_shr1_keep(entry, ent);
-    const v2f rM = recv2(M[RPL - 1]), rX = recv2(X[RPL - 1]), rY = recv2(Y[RPL - 1]);
     const bool sep = (int32_t)ent < 0;
-    const uint32_t code = sep ? kEntIdle : ent;
+    const bool off = sep || ent == kEntIdle;
     v2f pr[RPL], nM[RPL], nX[RPL], nY[RPL];
-    load_priors(code, lane, pr);
-    advance(pr, rM, rX, nM, nX, nY);
+    load_priors(off ? 0u : ent, lane, pr);
+#pragma unroll
+    for (int s = 0; s < RPL; s++) pr[s] = off ? v2f{0.f, 0.f} : pr[s];
+    advance(pr, nM, nX, nY);
     if (sep) {
       const int k = (int)(ent & 0x7fffffffu);
       const bool mine = (k >= hap_begin) && (k < hap_end);
@@ -514,6 +573,7 @@ struct WaveJob2 {
       sX = sX + nX[RPL - 1];
     }
     dM = rM; dX = rX; dY = rY;
+    fetch_above();
   }
 
   __device__ __forceinline__ void run(const FwdArgs<float>& a, int lane, int hap_begin, int hap_end) {
