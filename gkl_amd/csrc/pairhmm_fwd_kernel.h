@@ -157,6 +157,17 @@ __device__ __forceinline__ T mul_add2(T a, T b, T c, T d) {
   if (FMA) return fma_t(a, b, c * d);  // fma(a, b, c*d)
   return c * d + a * b;
 }
+// "* prior" of the M update.  fp32 uses v_mul_legacy_f32: identical to the IEEE multiply for the
+// finite non-negative values of this recurrence, but 0 * (Inf|NaN) = 0, so a column whose prior
+// is 0 by construction (separator / idle / pad rows) clears M -- and through M the X chain --
+// even if an earlier pair overflowed.  fp64 has no such opcode: its general step selects.
+__device__ __forceinline__ float mul_prior(float a, float b) {
+  float r;  // (hipcc 7.2 exposes no builtin for it; plain, non-volatile asm keeps it schedulable)
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double mul_prior(double a, double b) { return a * b; }
+
 // M-state inner sum: ((Md*pMM + Xd*pGAPM) + Yd*pGAPM)   (template.h:213)
 template <bool FMA, typename T>
 __device__ __forceinline__ T m_inner(T md, T xd, T yd, T pmm, T pgapm) {
@@ -287,10 +298,10 @@ struct WaveJob {
 
   // One anti-diagonal step of the recurrence for this lane's RPL rows.
   __device__ __forceinline__ void advance(const T* pr, T* nM, T* nX, T* nY) const {
-    nM[0] = m_inner<FMA>(dM, dX, dY, pMM[0], pGAPM[0]) * pr[0];
+    nM[0] = mul_prior(m_inner<FMA>(dM, dX, dY, pMM[0], pGAPM[0]), pr[0]);
 #pragma unroll
     for (int s = 1; s < RPL; s++)
-      nM[s] = m_inner<FMA>(M[s - 1], X[s - 1], Y[s - 1], pMM[s], pGAPM[s]) * pr[s];
+      nM[s] = mul_prior(m_inner<FMA>(M[s - 1], X[s - 1], Y[s - 1], pMM[s], pGAPM[s]), pr[s]);
 #pragma unroll
     for (int s = 0; s < RPL; s++) nY[s] = mul_add2<FMA>(Y[s], pXX[s], M[s], pMY[s]);  // (:222)
     nX[0] = mul_add2<FMA>(rX, pXX[0], rM, pMX[0]);                                      // (:219)
@@ -315,10 +326,13 @@ struct WaveJob {
     sX = sX + nX[RPL - 1];
   }
 
-  // General step: lanes may be idle, inside a haplotype, or on a separator (end of
-  // haplotype: emit the result, go back to the column-0 state of the next one).
+  // General step: lanes may be idle, inside a haplotype, or on a separator (end of haplotype:
+  // emit the result, return to the column-0 state of the next one).  Branch-free except for
+  // the result store: M and X clear themselves on a prior-0 column (see mul_prior; fp64
+  // selects explicitly), Y and the running sums are selected.
   __device__ __forceinline__ void step_any(const FwdArgs<T>& a, uint32_t entry, int lane,
                                            int hap_begin, int hap_end) {
+    constexpr bool kSelfClearing = sizeof(T) == 4;
     ent = dpp_shr1_keep(entry, ent);
     const bool sep = (int32_t)ent < 0;
     const bool off = sep || ent == kEntIdle;  // no haplotype base in this column: prior 0
@@ -327,26 +341,22 @@ struct WaveJob {
 #pragma unroll
     for (int s = 0; s < RPL; s++) pr[s] = off ? T(0) : pr[s];
     advance(pr, nM, nX, nY);
+    const T tM = sM + nM[RPL - 1], tX = sX + nX[RPL - 1];  // on a separator both addends are 0
+    T y0n = T(0);
     if (sep) {
       const int k = (int)(ent & 0x7fffffffu);
       const bool mine = (k >= hap_begin) && (k < hap_end);
-      if (mine && out_read >= 0)
-        a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
-      const T y0n = (mine && k + 1 < hap_end) ? a.y0[k + 1] : T(0);
-#pragma unroll
-      for (int s = 0; s < RPL; s++) {
-        M[s] = T(0);
-        X[s] = T(0);
-        Y[s] = (s == padb_slot) ? y0n : T(0);
-      }
-      sM = T(0);
-      sX = T(0);
-    } else {
-#pragma unroll
-      for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
-      sM = sM + nM[RPL - 1];
-      sX = sX + nX[RPL - 1];
+      if (mine && out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
+      if (mine && k + 1 < hap_end) y0n = a.y0[k + 1];
     }
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+      M[s] = (!kSelfClearing && sep) ? T(0) : nM[s];
+      X[s] = (!kSelfClearing && sep) ? T(0) : nX[s];
+      Y[s] = sep ? ((s == padb_slot) ? y0n : T(0)) : nY[s];
+    }
+    sM = sep ? T(0) : tM;
+    sX = sep ? T(0) : tX;
     dM = rM; dX = rX; dY = rY;
     fetch_above();
   }
@@ -370,6 +380,8 @@ struct WaveJob {
 #pragma unroll
         for (int u = 0; u < U; u++) step_fast(e[u], lane);
       }
+      if (t >= fast_from)
+        for (; t < sep_at; t++) step_fast(sp[t], lane);  // < U leftover columns, still all in-haplotype
       for (; t < sep_at; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
       fast_from = sep_at + kLanes;
     }

@@ -142,6 +142,19 @@ def test_hc_batch_policy_and_tolerance(native, ctx32, ctx64, oracle):
     assert np.mean(ref32 == out) > 0.9
 
 
+@pytest.mark.parametrize("rpl", [4, 8, 16])
+def test_every_fp32_kernel_variant_bit_exact(native, oracle, rpl):
+    """rows_per_lane 4 = dual-chunk packed kernel, 8 = default, 16 = long-read variant."""
+    b = make_batch("hc", 150, 12, seed=77)
+    rng = np.random.RandomState(rpl)
+    b2 = random_batch(rng, 30, 7, read_len=(1, 250), hap_len=(1, 90), alphabet=b"ACGTN")
+    with native.PairHmmContext(rows_per_lane=rpl) as c:
+        assert c.stats()["rows_per_lane"] == 0
+        check_against_oracle(c, oracle, b)
+        assert c.stats()["rows_per_lane"] == rpl
+        check_against_oracle(c, oracle, b2)
+
+
 def test_region_batch_no_fallback(ctx32, oracle):
     b = make_batch("region", 200, 16, seed=5)
     out, u = check_against_oracle(ctx32, oracle, b)

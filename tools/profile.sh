@@ -8,12 +8,12 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace.err
 CMDS="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $PMC --kernel-trace -d $OUT/pmc$i -o pmc -- $CMDS > $OUT/pmc$i.json 2> $OUT/pmc$i.err
+  rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/pmc$i -o pmc -- $CMDS > $OUT/pmc$i.json 2> $OUT/pmc$i.err
 done
 find $OUT -name "*.csv" | head -30
