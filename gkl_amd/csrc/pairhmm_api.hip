@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -108,6 +110,8 @@ struct FinalizeArgs {
   uint8_t* used64;
   int32_t* list;
   int32_t* count;
+  int32_t* read_fail;  // [n_reads] number of haplotypes each read must be recomputed against
+  int32_t n_haps;
   int64_t n;
   int mode;            // gklhip_finalize (device modes only) or -1: leave `out` to the host
   float log10_init_f;  // log10f(2^120), host libm
@@ -125,6 +129,7 @@ __global__ void policy_kernel(FinalizeArgs a) {
     a.used64[i] = 1;
     const int k = atomicAdd(a.count, 1);
     a.list[k] = (int32_t)i;
+    atomicAdd(a.read_fail + (int32_t)(i / a.n_haps), 1);
   } else {
     a.used64[i] = 0;
     if (a.mode == GKLHIP_FINALIZE_DEVICE_F64) {
@@ -145,6 +150,123 @@ __global__ void finalize64_kernel(FinalizeArgs a, int use_list) {
   if (a.mode >= 0) a.out[p] = log10(a.raw64[p]) - a.log10_init_d;
 }
 
+// Packed fp64 fallback, step 2 (device): for every chunk of the second read packing, find the
+// runs of consecutive haplotypes (stream order, never across a stream group) that at least one
+// of its reads must be recomputed against, and queue one wave job per run.
+__global__ void build_jobs_kernel(const LaneSlot* __restrict__ lanes, const int32_t* __restrict__ n_chunks,
+                                  const uint8_t* __restrict__ used64, int n_haps,
+                                  const int32_t* __restrict__ hap_orig, const int32_t* __restrict__ hap_group,
+                                  FwdJob* __restrict__ jobs, int32_t* __restrict__ job_count) {
+  extern __shared__ int32_t smem[];
+  int32_t* s_reads = smem;                                   // [64] distinct reads of the chunk
+  uint8_t* need = reinterpret_cast<uint8_t*>(smem + kLanes + 1);  // [n_haps]
+  const int c = blockIdx.x;
+  if (c >= *n_chunks) return;
+  if (threadIdx.x == 0) smem[kLanes] = 0;
+  __syncthreads();
+  if (threadIdx.x < kLanes) {
+    const LaneSlot sl = lanes[(int64_t)c * kLanes + threadIdx.x];
+    if (sl.read >= 0 && sl.block == 0) s_reads[atomicAdd(&smem[kLanes], 1)] = sl.read;
+  }
+  __syncthreads();
+  const int nr = smem[kLanes];
+  for (int k = threadIdx.x; k < n_haps; k += blockDim.x) {
+    const int h = hap_orig[k];
+    uint8_t nd = 0;
+    for (int i = 0; i < nr; i++) nd |= used64[(int64_t)s_reads[i] * n_haps + h];
+    need[k] = nd;
+  }
+  __syncthreads();
+  // a needed haplotype starts a run if its predecessor is not needed or lies in another stream group
+  for (int k = threadIdx.x; k < n_haps; k += blockDim.x) {
+    if (!need[k]) continue;
+    if (k > 0 && need[k - 1] && hap_group[k - 1] == hap_group[k]) continue;
+    int e = k + 1;
+    while (e < n_haps && need[e] && hap_group[e] == hap_group[k]) e++;
+    FwdJob j;
+    j.chunk = c; j.hap_begin = k; j.hap_end = e; j.pad_ = 0;
+    jobs[atomicAdd(job_count, 1)] = j;
+  }
+}
+
+// ---- packed fp64 fallback, step 1 (device): order the affected reads by how many haplotypes
+// they failed against (counting sort, most first) and pack them, window by window, into 64-lane
+// chunks with best-fit-decreasing -- the device twin of pack_reads_windowed(), so the pass needs
+// no host round trip.  Reads with similar fallback counts share chunks; in nested patterns (a
+// read underflows against every haplotype shorter than some length) a chunk then needs one
+// contiguous run of the length-sorted haplotype stream.
+constexpr int kPackWindow = 96;
+
+__global__ void fail_hist_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ hist) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads && read_fail[r] > 0) atomicAdd(hist + read_fail[r], 1);
+}
+
+// one block: bucket start positions for DESCENDING fail count; pos[c] = #reads with count > c
+__global__ void fail_scan_kernel(const int32_t* __restrict__ hist, int n_haps, int32_t* __restrict__ pos,
+                                 int32_t* __restrict__ n_fail_reads) {
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = n_haps; c >= 1; c--) { pos[c] = acc; acc += hist[c]; }
+    *n_fail_reads = acc;
+  }
+}
+
+__global__ void fail_scatter_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ pos,
+                                    int32_t* __restrict__ order) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_reads && read_fail[r] > 0) order[atomicAdd(pos + read_fail[r], 1)] = r;
+}
+
+__global__ __launch_bounds__(64) void pack_windows_kernel(const int32_t* __restrict__ order,
+                                                          const int32_t* __restrict__ n_fail_reads,
+                                                          const int64_t* __restrict__ read_off, int rpl,
+                                                          LaneSlot* __restrict__ lanes, int32_t* __restrict__ n_chunks) {
+  __shared__ int32_t s_read[kPackWindow], s_need[kPackWindow], s_bin[kPackWindow], s_off[kPackWindow];
+  __shared__ int32_t s_free[kPackWindow];
+  __shared__ int32_t s_nbins, s_base;
+  const int n = *n_fail_reads;
+  const int w0 = blockIdx.x * kPackWindow;
+  if (w0 >= n) return;
+  const int cnt = min(kPackWindow, n - w0);
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const int r = order[w0 + i];
+    s_read[i] = r;
+    s_need[i] = (int)((read_off[r + 1] - read_off[r] + rpl) / rpl);  // blocks_for()
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < cnt; i++) {  // insertion sort, lanes needed descending
+      const int nr = s_read[i], nn = s_need[i];
+      int j = i - 1;
+      while (j >= 0 && s_need[j] < nn) { s_read[j + 1] = s_read[j]; s_need[j + 1] = s_need[j]; j--; }
+      s_read[j + 1] = nr; s_need[j + 1] = nn;
+    }
+    int nb = 0;
+    for (int i = 0; i < cnt; i++) {  // best fit
+      const int nn = s_need[i];
+      int best = -1, best_free = kLanes + 1;
+      for (int b = 0; b < nb; b++)
+        if (s_free[b] >= nn && s_free[b] < best_free) { best = b; best_free = s_free[b]; }
+      if (best < 0) { best = nb++; s_free[best] = kLanes; }
+      s_bin[i] = best;
+      s_off[i] = kLanes - s_free[best];
+      s_free[best] -= nn;
+    }
+    s_nbins = nb;
+    s_base = atomicAdd(n_chunks, nb);
+  }
+  __syncthreads();
+  LaneSlot idle; idle.read = -1; idle.block = 0;
+  for (int i = threadIdx.x; i < s_nbins * kLanes; i += blockDim.x) lanes[(int64_t)s_base * kLanes + i] = idle;
+  __syncthreads();
+  for (int i = 0; i < cnt; i++)
+    for (int b = threadIdx.x; b < s_need[i]; b += blockDim.x) {
+      LaneSlot sl; sl.read = s_read[i]; sl.block = b;
+      lanes[(int64_t)(s_base + s_bin[i]) * kLanes + s_off[i] + b] = sl;
+    }
+}
+
 }  // namespace gklhip
 
 // ------------------------------------------------------------------ context
@@ -163,6 +285,7 @@ struct gklhip_ctx {
   hipEvent_t stage_free = nullptr;  // previous call's uploads have left the staging buffer
   // per-call device scratch
   DevBuf raw32, raw64, used64, list, counters, stream_buf, read_off_dev, out_dev;
+  DevBuf read_fail, lanes2, jobs, fail_order, fail_hist;
   // host-API device copies of the batch
   DevBuf batch_dev;
   // events
@@ -197,7 +320,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // Layout of the per-call plan block (identical in pinned staging and on the device).
 struct PlanLayout {
-  size_t lanes, groups, hap_len, hap_pos, hap_orig, hap_sidx, stream_src, y0_32, y0_64, read_off, total;
+  size_t lanes, groups, hap_len, hap_pos, hap_orig, hap_sidx, hap_group, stream_src, y0_32, y0_64, read_off, total;
 };
 PlanLayout layout_for(const Plan& p, int n_reads, int n_haps) {
   PlanLayout l;
@@ -208,6 +331,7 @@ PlanLayout layout_for(const Plan& p, int n_reads, int n_haps) {
   l.hap_pos = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_orig = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_sidx = o; o = align_up(o + (size_t)n_haps * 4);
+  l.hap_group = o; o = align_up(o + (size_t)n_haps * 4);
   l.stream_src = o; o = align_up(o + p.stream_src.size() * 4);
   l.y0_32 = o; o = align_up(o + (size_t)n_haps * 4);
   l.y0_64 = o; o = align_up(o + (size_t)n_haps * 8);
@@ -251,9 +375,9 @@ void launch_stream2(const FwdArgs<float>& a, int fma, int n_blocks, hipStream_t 
   else     hipLaunchKernelGGL((pairhmm_fwd_stream2_kernel<RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
 }
 template <typename T, int RPL>
-void launch_pairs(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
-  if (fma) hipLaunchKernelGGL((pairhmm_fwd_pairs_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
-  else     hipLaunchKernelGGL((pairhmm_fwd_pairs_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
+void launch_jobs(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
+  if (fma) hipLaunchKernelGGL((pairhmm_fwd_jobs_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
+  else     hipLaunchKernelGGL((pairhmm_fwd_jobs_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
 }
 
 // rows-per-lane choices: a read of length R needs (R+1) rows <= 64*RPL
@@ -306,6 +430,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   memcpy(hs + L.hap_pos, plan.hap_pos.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_orig, plan.hap_orig.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_sidx, plan.hap_sidx.data(), (size_t)n_haps * 4);
+  memcpy(hs + L.hap_group, plan.hap_group.data(), (size_t)n_haps * 4);
   memcpy(hs + L.stream_src, plan.stream_src.data(), plan.stream_src.size() * 4);
   {
     // Y[0][j] = INITIAL_CONSTANT / (NUMBER)haplen, divided on the host (template.h:110,176)
@@ -329,8 +454,10 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   if ((rc = c->used64.reserve((size_t)n_pairs))) return rc;
   if ((rc = c->list.reserve((size_t)n_pairs * 4))) return rc;
   if ((rc = c->counters.reserve(64))) return rc;
+  if ((rc = c->read_fail.reserve((size_t)n_reads * 4))) return rc;
   if ((rc = c->stream_buf.reserve(plan.stream_src.size() * 4))) return rc;
   HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, s));
+  if (!use_double) HIP_TRY(hipMemsetAsync(c->read_fail.p, 0, (size_t)n_reads * 4, s));
 
   const bool ev = c->cfg.record_events != 0;
   if (ev) HIP_TRY(hipEventRecord(c->ev[0], s));
@@ -358,15 +485,16 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.n_groups = (int)plan.groups.size();
     a.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.lanes);
     a.n_chunks = plan.n_chunks;
-    a.pair_list = c->list.as<int32_t>();
-    a.pair_count = c->counters.as<int32_t>();
-    a.pair_next = c->counters.as<int32_t>() + 1;
+    a.jobs = c->jobs.as<FwdJob>();
+    a.job_count = c->counters.as<int32_t>() + 2;
+    a.job_next = c->counters.as<int32_t>() + 3;
   };
 
   FinalizeArgs fa;
   fa.raw32 = c->raw32.as<float>(); fa.raw64 = c->raw64.as<double>(); fa.out = out_dev;
   fa.used64 = c->used64.as<uint8_t>(); fa.list = c->list.as<int32_t>();
   fa.count = c->counters.as<int32_t>(); fa.n = n_pairs; fa.mode = finalize_mode;
+  fa.read_fail = c->read_fail.as<int32_t>(); fa.n_haps = n_haps;
   fa.log10_init_f = host_tables_f32().log10_initial;
   fa.log10_init32_as_f64 = std::log10(std::ldexp(1.0, 120));
   fa.log10_init_d = host_tables_f64().log10_initial;
@@ -404,16 +532,45 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     else                    launch_stream<float, 16>(a, fma, n_main_blocks, s);
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa);
-    // fp64 recomputation of the queued pairs (persistent wavefronts; count stays on the device)
+    // ---- fp64 recomputation of the underflowed pairs ----
     FwdArgs<double> d{};
     fill_common(d);
     d.tab = c->dt64;
     d.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
     d.raw = c->raw64.as<double>();
-    const int n_persist = (int)std::min<int64_t>(n_pairs, 256 * 10);
     if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
-    if (rpl64 == 4) launch_pairs<double, 4>(d, fma, n_persist, s);
-    else            launch_pairs<double, 8>(d, fma, n_persist, s);
+    // Plan the pass on the device (no host round trip): order affected reads by fallback count,
+    // pack them into chunks, queue one job per (chunk, needed haplotype run), then let persistent
+    // wavefronts stream those jobs -- same WaveJob template as the main pass, T = double.
+    const size_t n_groups = plan.groups.size();
+    if ((rc = c->fail_hist.reserve((size_t)(2 * (n_haps + 2)) * 4))) return rc;
+    if ((rc = c->fail_order.reserve((size_t)n_reads * 4))) return rc;
+    if ((rc = c->lanes2.reserve((size_t)n_reads * kLanes * sizeof(LaneSlot)))) return rc;
+    if ((rc = c->jobs.reserve((size_t)n_reads * ((size_t)(n_haps + 1) / 2 + n_groups) * sizeof(FwdJob)))) return rc;
+    int32_t* hist = c->fail_hist.as<int32_t>();
+    int32_t* pos = hist + (n_haps + 2);
+    int32_t* cnts = c->counters.as<int32_t>();  // [0] pairs [2] jobs [3] next job [4] fail reads [5] chunks
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(2 * (n_haps + 2)) * 4, s));
+    const unsigned rb = (unsigned)((n_reads + 255) / 256);
+    hipLaunchKernelGGL(fail_hist_kernel, dim3(rb), dim3(256), 0, s, c->read_fail.as<int32_t>(), n_reads, hist);
+    hipLaunchKernelGGL(fail_scan_kernel, dim3(1), dim3(64), 0, s, hist, n_haps, pos, cnts + 4);
+    hipLaunchKernelGGL(fail_scatter_kernel, dim3(rb), dim3(256), 0, s, c->read_fail.as<int32_t>(), n_reads, pos,
+                       c->fail_order.as<int32_t>());
+    hipLaunchKernelGGL(pack_windows_kernel, dim3((unsigned)((n_reads + kPackWindow - 1) / kPackWindow)), dim3(64), 0, s,
+                       c->fail_order.as<int32_t>(), cnts + 4, b.read_off, rpl64, c->lanes2.as<LaneSlot>(), cnts + 5);
+    const int jb_threads = n_haps <= 64 ? 64 : n_haps <= 128 ? 128 : 256;
+    hipLaunchKernelGGL(build_jobs_kernel, dim3((unsigned)n_reads), dim3(jb_threads),
+                       (size_t)(kLanes + 1) * 4 + (size_t)n_haps, s, c->lanes2.as<LaneSlot>(), cnts + 5,
+                       c->used64.as<uint8_t>(), n_haps, reinterpret_cast<const int32_t*>(dp + L.hap_orig),
+                       reinterpret_cast<const int32_t*>(dp + L.hap_group), c->jobs.as<FwdJob>(), cnts + 2);
+    d.chunk_lanes = c->lanes2.as<LaneSlot>();
+    d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
+    d.jobs = c->jobs.as<FwdJob>();
+    {
+      const int n_persist = (int)std::min<int64_t>(n_pairs, 256 * 16);
+      if (rpl64 == 4) launch_jobs<double, 4>(d, fma, n_persist, s);
+      else            launch_jobs<double, 8>(d, fma, n_persist, s);
+    }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
   }
@@ -435,7 +592,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     HIP_TRY(hipStreamSynchronize(s));
     st.n_fallback = use_double ? n_pairs : cnt[0];
   } else {
-    st.n_fallback = -1;  // unknown without a sync; gklhip_get_raw fills it in
+    st.n_fallback = use_double ? n_pairs : -1;  // unknown without a sync; gklhip_get_raw fills it in
   }
   return GKLHIP_OK;
 }
@@ -536,7 +693,8 @@ int gklhip_done(gklhip_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev, &c->raw32, &c->raw64, &c->used64, &c->list,
-                    &c->counters, &c->stream_buf, &c->read_off_dev, &c->out_dev, &c->batch_dev})
+                    &c->counters, &c->stream_buf, &c->read_off_dev, &c->out_dev, &c->batch_dev, &c->read_fail,
+                    &c->lanes2, &c->jobs, &c->fail_order, &c->fail_hist})
     b->release();
   c->stage.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);

@@ -69,6 +69,10 @@ struct LaneSlot {  // one lane of a chunk: which read it holds, and which RPL-ro
   int32_t block;   // 0 .. n_blocks-1
 };
 
+struct FwdJob {  // one wave job of the job-list pass: stream haps [hap_begin, hap_end) through a chunk
+  int32_t chunk, hap_begin, hap_end, pad_;
+};
+
 template <typename T>
 struct FwdArgs {
   DevBatch b;
@@ -84,10 +88,10 @@ struct FwdArgs {
   const LaneSlot* chunk_lanes;  // [n_chunks * 64]
   int32_t n_chunks;
   T* raw;  // [n_reads * n_haps], r-major, scaled likelihood sums
-  // pair-list mode (fp64 fallback): entries are pair indices r*n_haps + h
-  const int32_t* pair_list;
-  const int32_t* pair_count;
-  int32_t* pair_next;
+  // job-list mode (packed fp64 fallback): jobs are (chunk, first hap, end hap) in stream order
+  const FwdJob* jobs;
+  const int32_t* job_count;
+  int32_t* job_next;
 };
 
 // ---- cross-lane helpers -----------------------------------------------------
@@ -651,35 +655,31 @@ __global__ __launch_bounds__(64) void pairhmm_fwd_stream2_kernel(FwdArgs<float> 
   job.run(a, lane, grp.hap_begin, grp.hap_end);
 }
 
-// Pair-list pass (fp64 recomputation of underflowed pairs): persistent wavefronts
-// pull (read, hap) pairs from a device-resident list; the read occupies the first
-// n_blocks lanes, one haplotype is streamed.
+// Job-list pass (packed fp64 recomputation): persistent wavefronts pull (chunk, haplotype run)
+// jobs built on the device from the fallback flags; chunks come from a second read packing
+// that groups reads with similar fallback patterns.
 template <typename T, int RPL, bool FMA>
-__global__ __launch_bounds__(64) void pairhmm_fwd_pairs_kernel(FwdArgs<T> a) {
+__global__ __launch_bounds__(64) void pairhmm_fwd_jobs_kernel(FwdArgs<T> a) {
   using Job = WaveJob<T, RPL, FMA>;
   __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
-  const int n = *a.pair_count;
+  const int n = *a.job_count;
   Job job;
   job.lds = lds;
+  int loaded_chunk = -1;
   for (;;) {
     int idx = 0;
-    if (lane == 0) idx = atomicAdd(a.pair_next, 1);
+    if (lane == 0) idx = atomicAdd(a.job_next, 1);
     idx = __builtin_amdgcn_readfirstlane(idx);
     if (idx >= n) break;
-    const int p = a.pair_list[idx];
-    const int r = p / a.b.n_haps;
-    const int h = p - r * a.b.n_haps;
-    const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
-    const int n_blocks = (R + RPL) / RPL;
-    LaneSlot slot;
-    slot.read = lane < n_blocks ? r : -1;
-    slot.block = lane;
-    __syncthreads();  // previous job's LDS reads are done
-    job.setup(a, lane, slot);
-    __syncthreads();
-    const int k = a.hap_sidx[h];
-    job.run(a, lane, k, k + 1);
+    const FwdJob j = a.jobs[idx];
+    if (j.chunk != loaded_chunk) {
+      __syncthreads();  // previous job's LDS reads are done
+      job.setup(a, lane, a.chunk_lanes[(int64_t)j.chunk * kLanes + lane]);
+      __syncthreads();
+      loaded_chunk = j.chunk;
+    }
+    job.run(a, lane, j.hap_begin, j.hap_end);
   }
 }
 

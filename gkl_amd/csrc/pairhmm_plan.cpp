@@ -20,12 +20,17 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   p.hap_pos.resize(n_haps);
   p.hap_orig.resize(n_haps);
   p.hap_sidx.resize(n_haps);
+  p.hap_group.resize(n_haps);
   int64_t total_cols = 0;
-  for (int h = 0; h < n_haps; h++) {
+  std::iota(p.hap_orig.begin(), p.hap_orig.end(), 0);
+  std::stable_sort(p.hap_orig.begin(), p.hap_orig.end(), [&](int32_t a, int32_t b) {
+    return hap_off[a + 1] - hap_off[a] < hap_off[b + 1] - hap_off[b];
+  });
+  for (int k = 0; k < n_haps; k++) {
+    const int h = p.hap_orig[k];
     const int len = (int)(hap_off[h + 1] - hap_off[h]);
-    p.hap_len[h] = len;
-    p.hap_orig[h] = h;
-    p.hap_sidx[h] = h;
+    p.hap_len[k] = len;
+    p.hap_sidx[h] = k;
     p.max_hap_len = std::max(p.max_hap_len, len);
     total_cols += len + 1;
   }
@@ -43,9 +48,10 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
       g.pad_ = 0;
       int64_t cols = 0;
       // at least one haplotype per group; stop once the group reached its share
-      do {
+      do {  // h is a stream-order index here
         p.hap_pos[h] = (int32_t)p.stream_src.size();
-        const int64_t base = hap_off[h];
+        p.hap_group[h] = (int32_t)p.groups.size();
+        const int64_t base = hap_off[p.hap_orig[h]];
         for (int c = 0; c < p.hap_len[h]; c++) p.stream_src.push_back((int32_t)(base + c));
         p.stream_src.push_back(-2 - h);  // separator of stream-order hap h
         cols += p.hap_len[h] + 1;
@@ -57,52 +63,62 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
     }
   }
 
-  // ---- read packing: best-fit decreasing into 64-lane chunks ----
+  // ---- read packing: best-fit decreasing into 64-lane chunks (one window = all reads) ----
   for (int r = 0; r < n_reads; r++)
     p.max_read_len = std::max(p.max_read_len, (int)(read_off[r + 1] - read_off[r]));
   if (rows_per_lane <= 0 || n_reads == 0) return;
-  const int rpl = rows_per_lane;
   std::vector<int32_t> order(n_reads);
   std::iota(order.begin(), order.end(), 0);
-  std::vector<int32_t> need(n_reads);
-  for (int r = 0; r < n_reads; r++) {
-    const int R = (int)(read_off[r + 1] - read_off[r]);
-    need[r] = blocks_for(R, rpl);
-    p.useful_rows += R;
-  }
-  std::stable_sort(order.begin(), order.end(),
-                   [&](int32_t a, int32_t b) { return need[a] > need[b]; });
-  // open[c] = chunks that still have exactly c free lanes
+  p.n_chunks = pack_reads_windowed(order.data(), n_reads, read_off, rows_per_lane, n_reads, &p.lanes,
+                                   &p.useful_rows);
+}
+
+int pack_reads_windowed(const int32_t* order_in, int n, const int64_t* read_off, int rows_per_lane,
+                        int window, std::vector<PlanLane>* lanes, int64_t* useful_rows) {
+  const int rpl = rows_per_lane;
+  if (window < 1) window = 1;
+  int chunks_total = 0;
+  std::vector<int32_t> order, need_of;
   std::vector<std::vector<int32_t>> open(kLanes + 1);
-  std::vector<int32_t> used_lanes;  // per chunk
+  std::vector<int32_t> used_lanes;
   std::vector<std::vector<int32_t>> members;
-  for (int32_t r : order) {
-    const int n = need[r];  // 1..64 (caller guarantees the read fits a chunk)
-    int c = n;
-    while (c <= kLanes && open[c].empty()) c++;
-    int chunk;
-    if (c > kLanes) {
-      chunk = (int)used_lanes.size();
-      used_lanes.push_back(0);
-      members.emplace_back();
-      c = kLanes;
-    } else {
-      chunk = open[c].back();
-      open[c].pop_back();
+  for (int w0 = 0; w0 < n; w0 += window) {
+    const int w1 = std::min(n, w0 + window);
+    order.assign(order_in + w0, order_in + w1);
+    auto need = [&](int32_t r) { return blocks_for((int)(read_off[r + 1] - read_off[r]), rpl); };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return need(a) > need(b); });
+    for (auto& o : open) o.clear();
+    used_lanes.clear();
+    members.clear();
+    for (int32_t r : order) {
+      const int nb = need(r);  // 1..64 (caller guarantees the read fits a chunk)
+      if (useful_rows) *useful_rows += read_off[r + 1] - read_off[r];
+      int c = nb;
+      while (c <= kLanes && open[c].empty()) c++;  // open[c] = chunks with exactly c free lanes
+      int chunk;
+      if (c > kLanes) {
+        chunk = (int)used_lanes.size();
+        used_lanes.push_back(0);
+        members.emplace_back();
+        c = kLanes;
+      } else {
+        chunk = open[c].back();
+        open[c].pop_back();
+      }
+      members[chunk].push_back(r);
+      used_lanes[chunk] += nb;
+      if (c - nb > 0) open[c - nb].push_back(chunk);
     }
-    members[chunk].push_back(r);
-    used_lanes[chunk] += n;
-    const int left = c - n;
-    if (left > 0) open[left].push_back(chunk);
-  }
-  p.n_chunks = (int)used_lanes.size();
-  p.lanes.assign((size_t)p.n_chunks * kLanes, PlanLane{-1, 0});
-  for (int ch = 0; ch < p.n_chunks; ch++) {
-    int lane = 0;
-    for (int32_t r : members[ch]) {
-      for (int b = 0; b < need[r]; b++) p.lanes[(size_t)ch * kLanes + lane++] = PlanLane{r, b};
+    const size_t base = lanes->size();
+    lanes->resize(base + members.size() * kLanes, PlanLane{-1, 0});
+    for (size_t ch = 0; ch < members.size(); ch++) {
+      int lane = 0;
+      for (int32_t r : members[ch])
+        for (int b = 0; b < need(r); b++) (*lanes)[base + ch * kLanes + lane++] = PlanLane{r, b};
     }
+    chunks_total += (int)members.size();
   }
+  return chunks_total;
 }
 
 }  // namespace gklhip

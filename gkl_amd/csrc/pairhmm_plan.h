@@ -28,6 +28,7 @@ struct Plan {
   std::vector<int32_t> hap_pos;     // stream index of column 1
   std::vector<int32_t> hap_orig;    // stream order -> caller index
   std::vector<int32_t> hap_sidx;    // caller index -> stream order
+  std::vector<int32_t> hap_group;   // stream order -> index into groups
   // stream source: >= 0 index into hap_bases; -1 idle; <= -2 separator of stream hap (-2-k)
   std::vector<int32_t> stream_src;
   int64_t useful_rows = 0;
@@ -39,8 +40,16 @@ struct Plan {
 inline int blocks_for(int R, int rpl) { return (R + rpl) / rpl; }
 
 // Build the haplotype streams (always) and, when rows_per_lane > 0, the read packing.
-// target_cols: desired columns per haplotype group (job length).
+// Haplotypes are streamed in order of increasing length (ties by index); target_cols:
+// desired columns per haplotype group (job length).
 void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off,
                 int rows_per_lane, int target_cols, Plan* out);
+
+// Pack the given reads (in the given order) into 64-lane chunks: best-fit-decreasing inside
+// consecutive windows of `window` reads, never across windows, so reads that are adjacent in
+// `order` (e.g. sorted by how many haplotypes they must be recomputed against) share chunks.
+// Appends to lanes; returns the number of chunks created.
+int pack_reads_windowed(const int32_t* order, int n, const int64_t* read_off, int rows_per_lane,
+                        int window, std::vector<PlanLane>* lanes, int64_t* useful_rows);
 
 }  // namespace gklhip

@@ -115,7 +115,8 @@ int gklhip_done(gklhip_ctx* ctx);
 int gklhip_compute(gklhip_ctx* ctx, const gklhip_batch* host_batch, double* out_host);
 
 /* Byte arrays and `out_dev` in HBM; launches on `hip_stream` (a hipStream_t; NULL = HIP's
- * default stream) and returns without a host sync when record_events==0. */
+ * default stream) and returns without a host sync when record_events == 0 (the fp64
+ * recomputation pass is planned on the device). One stream per context. */
 int gklhip_compute_device(gklhip_ctx* ctx, const gklhip_batch* dev_batch, double* out_dev,
                           void* hip_stream);
 
