@@ -197,9 +197,11 @@ __global__ void build_jobs_kernel(const LaneSlot* __restrict__ lanes, const int3
 // contiguous run of the length-sorted haplotype stream.
 constexpr int kPackWindow = 96;
 
-__global__ void fail_hist_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ hist) {
+// (reads longer than max_len bases do not fit a chunk: they take the striped long-read path)
+__global__ void fail_hist_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ hist,
+                                 const int64_t* __restrict__ read_off, int max_len) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads && read_fail[r] > 0) atomicAdd(hist + read_fail[r], 1);
+  if (r < n_reads && read_fail[r] > 0 && read_off[r + 1] - read_off[r] <= max_len) atomicAdd(hist + read_fail[r], 1);
 }
 
 // one block: bucket start positions for DESCENDING fail count; pos[c] = #reads with count > c
@@ -213,9 +215,10 @@ __global__ void fail_scan_kernel(const int32_t* __restrict__ hist, int n_haps, i
 }
 
 __global__ void fail_scatter_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ pos,
-                                    int32_t* __restrict__ order) {
+                                    int32_t* __restrict__ order, const int64_t* __restrict__ read_off, int max_len) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads && read_fail[r] > 0) order[atomicAdd(pos + read_fail[r], 1)] = r;
+  if (r < n_reads && read_fail[r] > 0 && read_off[r + 1] - read_off[r] <= max_len)
+    order[atomicAdd(pos + read_fail[r], 1)] = r;
 }
 
 __global__ __launch_bounds__(64) void pack_windows_kernel(const int32_t* __restrict__ order,
@@ -285,7 +288,7 @@ struct gklhip_ctx {
   hipEvent_t stage_free = nullptr;  // previous call's uploads have left the staging buffer
   // per-call device scratch
   DevBuf raw32, raw64, used64, list, counters, stream_buf, read_off_dev, out_dev;
-  DevBuf read_fail, lanes2, jobs, fail_order, fail_hist;
+  DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist;
   // host-API device copies of the batch
   DevBuf batch_dev;
   // events
@@ -296,6 +299,9 @@ struct gklhip_ctx {
   hipStream_t last_stream = nullptr;
   bool have_last = false;
   Plan plan;
+  std::vector<PlanLane> long_lanes;
+  std::vector<FwdJob> long_jobs;
+  DevBuf carry;
 };
 
 namespace {
@@ -320,9 +326,9 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // Layout of the per-call plan block (identical in pinned staging and on the device).
 struct PlanLayout {
-  size_t lanes, groups, hap_len, hap_pos, hap_orig, hap_sidx, hap_group, stream_src, y0_32, y0_64, read_off, total;
+  size_t lanes, groups, hap_len, hap_pos, hap_orig, hap_sidx, hap_group, stream_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count, total;
 };
-PlanLayout layout_for(const Plan& p, int n_reads, int n_haps) {
+PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lanes, size_t n_long_jobs) {
   PlanLayout l;
   size_t o = 0;
   l.lanes = o; o = align_up(o + p.lanes.size() * sizeof(PlanLane));
@@ -336,6 +342,9 @@ PlanLayout layout_for(const Plan& p, int n_reads, int n_haps) {
   l.y0_32 = o; o = align_up(o + (size_t)n_haps * 4);
   l.y0_64 = o; o = align_up(o + (size_t)n_haps * 8);
   l.read_off = o; o = align_up(o + (size_t)(n_reads + 1) * 8);
+  l.long_lanes = o; o = align_up(o + n_long_lanes * sizeof(PlanLane));
+  l.long_jobs = o; o = align_up(o + n_long_jobs * sizeof(FwdJob));
+  l.long_count = o; o = align_up(o + 16);
   l.total = o;
   return l;
 }
@@ -380,20 +389,17 @@ void launch_jobs(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
   else     hipLaunchKernelGGL((pairhmm_fwd_jobs_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
 }
 
-// rows-per-lane choices: a read of length R needs (R+1) rows <= 64*RPL
-// (4 selects the dual-chunk packed-math kernel: 2 chunks x 4 rows per lane)
-int pick_rpl_f32(int max_read, int forced) {
-  if (forced == 4 || forced == 8 || forced == 16) return (max_read + 1 <= 64 * forced) ? forced : 0;
-  // auto: the single-chunk 8-row kernel measured 2-5 % faster than the packed dual-chunk one
-  if (max_read + 1 <= 64 * 8) return 8;
-  if (max_read + 1 <= 64 * 16) return 16;
-  return 0;
+template <typename T, int RPL>
+void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry_len, hipStream_t s) {
+  if (fma) hipLaunchKernelGGL((pairhmm_fwd_long_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a, carry, carry_len);
+  else     hipLaunchKernelGGL((pairhmm_fwd_long_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a, carry, carry_len);
 }
-int pick_rpl_f64(int max_read) {
-  if (max_read + 1 <= 64 * 4) return 4;
-  if (max_read + 1 <= 64 * 8) return 8;
-  return 0;
-}
+
+// Rows per lane.  fp32 main pass: 8 (one chunk per wavefront; 4 = the dual-chunk packed-math
+// kernel, opt-in).  fp64 passes: 4.  A read of length R needs R+1 rows; reads that exceed
+// 64*RPL rows go to the striped long-read kernel of the same RPL.
+constexpr int kRplF64 = 4;
+int pick_rpl_f32(int forced) { return forced == 4 ? 4 : 8; }
 
 // The whole device-side pipeline on stream `s`; `db` holds DEVICE byte arrays, host offsets.
 int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int finalize_mode, hipStream_t s) {
@@ -409,14 +415,33 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
 
   // ---- plan (host) ----
   Plan& plan = c->plan;
-  int max_read = 0;
-  for (int r = 0; r < n_reads; r++) max_read = std::max(max_read, (int)(db->read_off[r + 1] - db->read_off[r]));
-  const int rpl64 = pick_rpl_f64(max_read);
-  const int rpl_main = use_double ? rpl64 : pick_rpl_f32(max_read, c->cfg.rows_per_lane);
-  if (rpl_main == 0 || rpl64 == 0)
-    return fail(GKLHIP_ERR_UNSUPPORTED, "read of length %d exceeds the in-register row capacity", max_read);
+  const int rpl64 = kRplF64;
+  const int rpl_main = use_double ? rpl64 : pick_rpl_f32(c->cfg.rows_per_lane);
   build_plan(n_reads, n_haps, db->read_off, db->hap_off, rpl_main, 4096, &plan);
-  const PlanLayout L = layout_for(plan, n_reads, n_haps);
+  // Long reads: pseudo-chunks (lane 0 names the read) + one striped job per (read, stream group)
+  // for the main pass; for the fp64 fallback the same pseudo-chunks feed build_jobs_kernel.
+  std::vector<PlanLane>& long_lanes = c->long_lanes;
+  std::vector<FwdJob>& long_jobs = c->long_jobs;
+  std::vector<int32_t> long64;  // reads too long for the packed fp64 pass
+  long_lanes.clear(); long_jobs.clear();
+  for (int r = 0; r < n_reads; r++)
+    if (blocks_for((int)(db->read_off[r + 1] - db->read_off[r]), rpl64) > kLanes) long64.push_back(r);
+  const std::vector<int32_t>& long_main = plan.long_reads;
+  const int n_long_main = (int)long_main.size();
+  const int n_long64 = use_double ? 0 : (int)long64.size();
+  // pseudo-chunk index space: [0, n_long_main) main-pass reads, then [n_long_main, +n_long64) fp64-pass reads
+  for (int32_t r : long_main) { long_lanes.resize(long_lanes.size() + kLanes, PlanLane{-1, 0}); long_lanes[long_lanes.size() - kLanes] = PlanLane{r, 0}; }
+  if (!use_double)
+    for (int32_t r : long64) { long_lanes.resize(long_lanes.size() + kLanes, PlanLane{-1, 0}); long_lanes[long_lanes.size() - kLanes] = PlanLane{r, 0}; }
+  for (int i = 0; i < n_long_main; i++)
+    for (const PlanGroup& g : plan.groups) long_jobs.push_back(FwdJob{i, g.hap_begin, g.hap_end, 0});
+  int carry_len = 0;
+  for (const PlanGroup& g : plan.groups) {
+    const int last = g.hap_end - 1;
+    carry_len = std::max(carry_len, plan.hap_pos[last] + plan.hap_len[last] - plan.hap_pos[g.hap_begin] + 3 * kLanes);
+  }
+  carry_len = (carry_len + 63) / 64 * 64;
+  const PlanLayout L = layout_for(plan, n_reads, n_haps, long_lanes.size(), long_jobs.size());
 
   // ---- stage + upload plan ----
   int rc;
@@ -444,6 +469,12 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     }
   }
   memcpy(hs + L.read_off, db->read_off, (size_t)(n_reads + 1) * 8);
+  if (!long_lanes.empty()) memcpy(hs + L.long_lanes, long_lanes.data(), long_lanes.size() * sizeof(PlanLane));
+  if (!long_jobs.empty()) memcpy(hs + L.long_jobs, long_jobs.data(), long_jobs.size() * sizeof(FwdJob));
+  {
+    int32_t lc[4] = {(int32_t)long_jobs.size(), n_long_main, n_long64, 0};
+    memcpy(hs + L.long_count, lc, sizeof lc);
+  }
   unsigned char* dp = c->plan_dev.as<unsigned char>();
   HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, s));
   HIP_TRY(hipEventRecord(c->stage_free, s));
@@ -500,6 +531,11 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   fa.log10_init_d = host_tables_f64().log10_initial;
 
   const int n_main_blocks = plan.n_chunks * (int)plan.groups.size();
+  const int n_long_waves = 512;  // persistent wavefronts of the striped long-read kernel
+  if (n_long_main > 0 || n_long64 > 0) {
+    if ((rc = c->carry.reserve((size_t)n_long_waves * 2 * (3 * (size_t)carry_len + 64) * sizeof(double)))) return rc;
+  }
+  st.n_long_pairs = (int32_t)std::min<int64_t>((int64_t)n_long_main * n_haps, 0x7fffffff);
   st.n_chunks = plan.n_chunks;
   st.n_hap_groups = (int)plan.groups.size();
   st.rows_per_lane = rpl_main;
@@ -516,8 +552,15 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.tab = c->dt64;
     a.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
     a.raw = c->raw64.as<double>();
-    if (rpl_main == 4) launch_stream<double, 4>(a, fma, n_main_blocks, s);
-    else               launch_stream<double, 8>(a, fma, n_main_blocks, s);
+    if (n_main_blocks > 0) launch_stream<double, 4>(a, fma, n_main_blocks, s);
+    if (n_long_main > 0) {
+      FwdArgs<double> la = a;
+      la.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.long_lanes);
+      la.jobs = reinterpret_cast<const FwdJob*>(dp + L.long_jobs);
+      la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
+      la.job_next = c->counters.as<int32_t>() + 7;
+      launch_long<double, 4>(la, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
+    }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
     if (ev) { HIP_TRY(hipEventRecord(c->ev[3], s)); HIP_TRY(hipEventRecord(c->ev[4], s)); }
@@ -527,9 +570,19 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.tab = c->dt32;
     a.y0 = reinterpret_cast<const float*>(dp + L.y0_32);
     a.raw = c->raw32.as<float>();
-    if (rpl_main == 4)      launch_stream2<4>(a, fma, ((plan.n_chunks + 1) / 2) * (int)plan.groups.size(), s);
-    else if (rpl_main == 8) launch_stream<float, 8>(a, fma, n_main_blocks, s);
-    else                    launch_stream<float, 16>(a, fma, n_main_blocks, s);
+    if (n_main_blocks > 0) {
+      if (rpl_main == 4) launch_stream2<4>(a, fma, ((plan.n_chunks + 1) / 2) * (int)plan.groups.size(), s);
+      else               launch_stream<float, 8>(a, fma, n_main_blocks, s);
+    }
+    if (n_long_main > 0) {
+      FwdArgs<float> la = a;
+      la.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.long_lanes);
+      la.jobs = reinterpret_cast<const FwdJob*>(dp + L.long_jobs);
+      la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
+      la.job_next = c->counters.as<int32_t>() + 7;
+      if (rpl_main == 4) launch_long<float, 4>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
+      else               launch_long<float, 8>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
+    }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa);
     // ---- fp64 recomputation of the underflowed pairs ----
@@ -552,10 +605,11 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     int32_t* cnts = c->counters.as<int32_t>();  // [0] pairs [2] jobs [3] next job [4] fail reads [5] chunks
     HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(2 * (n_haps + 2)) * 4, s));
     const unsigned rb = (unsigned)((n_reads + 255) / 256);
-    hipLaunchKernelGGL(fail_hist_kernel, dim3(rb), dim3(256), 0, s, c->read_fail.as<int32_t>(), n_reads, hist);
+    hipLaunchKernelGGL(fail_hist_kernel, dim3(rb), dim3(256), 0, s, c->read_fail.as<int32_t>(), n_reads, hist,
+                       b.read_off, kLanes * rpl64 - 1);
     hipLaunchKernelGGL(fail_scan_kernel, dim3(1), dim3(64), 0, s, hist, n_haps, pos, cnts + 4);
     hipLaunchKernelGGL(fail_scatter_kernel, dim3(rb), dim3(256), 0, s, c->read_fail.as<int32_t>(), n_reads, pos,
-                       c->fail_order.as<int32_t>());
+                       c->fail_order.as<int32_t>(), b.read_off, kLanes * rpl64 - 1);
     hipLaunchKernelGGL(pack_windows_kernel, dim3((unsigned)((n_reads + kPackWindow - 1) / kPackWindow)), dim3(64), 0, s,
                        c->fail_order.as<int32_t>(), cnts + 4, b.read_off, rpl64, c->lanes2.as<LaneSlot>(), cnts + 5);
     const int jb_threads = n_haps <= 64 ? 64 : n_haps <= 128 ? 128 : 256;
@@ -566,10 +620,22 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     d.chunk_lanes = c->lanes2.as<LaneSlot>();
     d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
     d.jobs = c->jobs.as<FwdJob>();
-    {
-      const int n_persist = (int)std::min<int64_t>(n_pairs, 256 * 16);
-      if (rpl64 == 4) launch_jobs<double, 4>(d, fma, n_persist, s);
-      else            launch_jobs<double, 8>(d, fma, n_persist, s);
+    launch_jobs<double, 4>(d, fma, (int)std::min<int64_t>(n_pairs, 256 * 16), s);
+    if (n_long64 > 0) {
+      // reads too long for a chunk: one pseudo-chunk each, same run detection, striped kernel
+      if ((rc = c->jobs_long.reserve((size_t)n_long64 * ((size_t)(n_haps + 1) / 2 + n_groups) * sizeof(FwdJob)))) return rc;
+      const LaneSlot* pl = reinterpret_cast<const LaneSlot*>(dp + L.long_lanes);
+      hipLaunchKernelGGL(build_jobs_kernel, dim3((unsigned)n_long64), dim3(jb_threads),
+                         (size_t)(kLanes + 1) * 4 + (size_t)n_haps, s, pl + (size_t)n_long_main * kLanes,
+                         reinterpret_cast<const int32_t*>(dp + L.long_count) + 2, c->used64.as<uint8_t>(), n_haps,
+                         reinterpret_cast<const int32_t*>(dp + L.hap_orig),
+                         reinterpret_cast<const int32_t*>(dp + L.hap_group), c->jobs_long.as<FwdJob>(), cnts + 8);
+      FwdArgs<double> ld = d;
+      ld.chunk_lanes = pl + (size_t)n_long_main * kLanes;
+      ld.jobs = c->jobs_long.as<FwdJob>();
+      ld.job_count = cnts + 8;
+      ld.job_next = cnts + 9;
+      launch_long<double, 4>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
@@ -694,7 +760,7 @@ int gklhip_done(gklhip_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev, &c->raw32, &c->raw64, &c->used64, &c->list,
                     &c->counters, &c->stream_buf, &c->read_off_dev, &c->out_dev, &c->batch_dev, &c->read_fail,
-                    &c->lanes2, &c->jobs, &c->fail_order, &c->fail_hist})
+                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry})
     b->release();
   c->stage.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);

@@ -152,6 +152,17 @@ __device__ __forceinline__ double recv_above(double v, uint32_t lmask) {
   return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// broadcast lane `src` (wave-uniform index) of v
+__device__ __forceinline__ float read_lane(float v, int src) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), src));
+}
+__device__ __forceinline__ double read_lane(double v, int src) {
+  const uint64_t u = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
@@ -390,6 +401,47 @@ struct WaveJob {
       fast_from = sep_at + kLanes;
     }
     for (; t < fast_from; t++) step_any(a, sp[t], lane, hap_begin, hap_end);  // drain
+  }
+
+  // One 64-lane STRIPE of a read that is longer than a chunk (the reference's stripe loop with
+  // its shiftOutM/X/Y carry arrays, PH/avx-pairhmm-template.h:249,291-323, at 64*RPL rows per
+  // stripe).  The row above lane 0 is the bottom row of the previous stripe: it arrives through
+  // `cin` (one (M,X,Y) triple per stream position, read 64 positions at a time, coalesced, and
+  // handed to lane 0 with v_readlane); this stripe's own bottom row leaves through `cout` the
+  // same way.  Every step runs the general body -- this path is for rare inputs.
+  __device__ __forceinline__ void run_stripe(const FwdArgs<T>& a, int lane, int hap_begin, int hap_end,
+                                             const T* __restrict__ cin, T* __restrict__ cout, int clen) {
+    const int sb = a.hap_pos[hap_begin];
+    const uint32_t* __restrict__ sp = a.stream + sb;
+    reset_state(a.y0[hap_begin]);
+    const int t_end = a.hap_pos[hap_end - 1] - sb + a.hap_len[hap_end - 1] + kLanes;  // last separator + 64
+    T ciM = T(0), ciX = T(0), ciY = T(0), coM = T(0), coX = T(0), coY = T(0);
+    // column-0 state of the boundary row (its Y is Y0 when that row is the read's pad row):
+    // the diagonal input of lane 0's first column.  Slot [3*clen ..] of the carry buffer.
+    if (cout && lane == kLanes - 1) { cout[3 * clen] = M[RPL - 1]; cout[3 * clen + 1] = X[RPL - 1]; cout[3 * clen + 2] = Y[RPL - 1]; }
+    if (cin && lane == 0) { dM = cin[3 * clen]; dX = cin[3 * clen + 1]; dY = cin[3 * clen + 2]; }
+    for (int t = 0; t < t_end; t++) {
+      if (cin) {
+        if ((t & 63) == 0) {
+          ciM = cin[t + lane]; ciX = cin[clen + t + lane]; ciY = cin[2 * clen + t + lane];
+        }
+        const T vM = read_lane(ciM, t & 63), vX = read_lane(ciX, t & 63), vY = read_lane(ciY, t & 63);
+        if (lane == 0) { rM = vM; rX = vX; rY = vY; }
+      }
+      step_any(a, sp[t], lane, hap_begin, hap_end);
+      if (cout) {
+        const int p = t - (kLanes - 1);  // stream position lane 63 has just finished
+        if (p >= 0) {
+          const T bM = read_lane(M[RPL - 1], kLanes - 1), bX = read_lane(X[RPL - 1], kLanes - 1),
+                  bY = read_lane(Y[RPL - 1], kLanes - 1);
+          if (lane == (p & 63)) { coM = bM; coX = bX; coY = bY; }
+          if ((p & 63) == 63 || t == t_end - 1) {
+            const int base = p & ~63;
+            cout[base + lane] = coM; cout[clen + base + lane] = coX; cout[2 * clen + base + lane] = coY;
+          }
+        }
+      }
+    }
   }
 };
 
@@ -680,6 +732,50 @@ __global__ __launch_bounds__(64) void pairhmm_fwd_jobs_kernel(FwdArgs<T> a) {
       loaded_chunk = j.chunk;
     }
     job.run(a, lane, j.hap_begin, j.hap_end);
+  }
+}
+
+// Long-read pass: a read with more rows than one chunk holds is processed stripe by stripe by
+// one persistent wavefront per (read, haplotype run) job; `carry` is per-wavefront scratch for
+// the two ping-pong carry rows (2 x 3 x carry_len values).
+template <typename T, int RPL, bool FMA>
+__global__ __launch_bounds__(64) void pairhmm_fwd_long_kernel(FwdArgs<T> a, T* carry, int carry_len) {
+  using Job = WaveJob<T, RPL, FMA>;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
+  const int lane = threadIdx.x;
+  const int n = *a.job_count;
+  const int64_t cstride = 3 * (int64_t)carry_len + 64;  // (M,X,Y) rows + the column-0 triple
+  T* my = carry + (int64_t)blockIdx.x * 2 * cstride;
+  Job job;
+  job.lds = lds;
+  for (;;) {
+    int idx = 0;
+    if (lane == 0) idx = atomicAdd(a.job_next, 1);
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    if (idx >= n) break;
+    const FwdJob j = a.jobs[idx];
+    const int r = a.chunk_lanes[(int64_t)j.chunk * kLanes].read;  // pseudo-chunk: lane 0 names the read
+    const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+    const int n_blocks = (R + RPL) / RPL;
+    const int n_stripes = (n_blocks + kLanes - 1) / kLanes;
+    const int first_cnt = n_blocks - kLanes * (n_stripes - 1);  // lanes of the first (partial) stripe
+    for (int st = 0; st < n_stripes; st++) {
+      LaneSlot slot;
+      if (st == 0) {
+        slot.read = lane >= kLanes - first_cnt ? r : -1;
+        slot.block = lane - (kLanes - first_cnt);
+      } else {
+        slot.read = r;
+        slot.block = first_cnt + (st - 1) * kLanes + lane;
+      }
+      __syncthreads();
+      job.setup(a, lane, slot);
+      __syncthreads();
+      const T* cin = st > 0 ? my + (int64_t)((st + 1) & 1) * cstride : nullptr;
+      T* cout = st + 1 < n_stripes ? my + (int64_t)(st & 1) * cstride : nullptr;
+      job.run_stripe(a, lane, j.hap_begin, j.hap_end, cin, cout, carry_len);
+      __threadfence_block();  // this stripe's carry stores before the next stripe's carry loads
+    }
   }
 }
 

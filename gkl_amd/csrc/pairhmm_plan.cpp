@@ -67,10 +67,14 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   for (int r = 0; r < n_reads; r++)
     p.max_read_len = std::max(p.max_read_len, (int)(read_off[r + 1] - read_off[r]));
   if (rows_per_lane <= 0 || n_reads == 0) return;
-  std::vector<int32_t> order(n_reads);
-  std::iota(order.begin(), order.end(), 0);
-  p.n_chunks = pack_reads_windowed(order.data(), n_reads, read_off, rows_per_lane, n_reads, &p.lanes,
-                                   &p.useful_rows);
+  std::vector<int32_t> order;
+  order.reserve(n_reads);
+  for (int r = 0; r < n_reads; r++) {
+    if (blocks_for((int)(read_off[r + 1] - read_off[r]), rows_per_lane) <= kLanes) order.push_back(r);
+    else p.long_reads.push_back(r);
+  }
+  p.n_chunks = pack_reads_windowed(order.data(), (int)order.size(), read_off, rows_per_lane,
+                                   (int)std::max<size_t>(order.size(), 1), &p.lanes, &p.useful_rows);
 }
 
 int pack_reads_windowed(const int32_t* order_in, int n, const int64_t* read_off, int rows_per_lane,

@@ -31,6 +31,7 @@ struct Plan {
   std::vector<int32_t> hap_group;   // stream order -> index into groups
   // stream source: >= 0 index into hap_bases; -1 idle; <= -2 separator of stream hap (-2-k)
   std::vector<int32_t> stream_src;
+  std::vector<int32_t> long_reads;  // reads with more than 64*rows_per_lane-1 bases: striped kernel
   int64_t useful_rows = 0;
   int max_read_len = 0;
   int max_hap_len = 0;

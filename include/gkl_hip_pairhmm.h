@@ -72,7 +72,7 @@ typedef struct {
                            0 = arithmetic of GKL's AVX objects (separate mul/add) */
   int32_t finalize;     /* gklhip_finalize for gklhip_compute_device; -1 = default */
   int32_t record_events;/* 1 = bracket kernels with HIP events (gklhip_get_stats) */
-  int32_t rows_per_lane;/* 0 = auto; otherwise force the fp32 kernel variant: 4 (two packed chunks), 8, 16 */
+  int32_t rows_per_lane;/* 0 = auto (8); 4 = the dual-chunk packed-math fp32 kernel */
 } gklhip_config;
 
 /* Flat structure-of-arrays batch. Offsets always live on the host; the byte
@@ -100,7 +100,7 @@ typedef struct {
   int32_t n_chunks;        /* 64-lane read packs of the fp32 (or all-fp64) pass */
   int32_t n_hap_groups;
   int32_t rows_per_lane;
-  int32_t n_long_pairs;    /* pairs routed to the striped long-read kernel */
+  int32_t n_long_pairs;    /* pairs of the main pass routed to the striped long-read kernel */
   float ms_fwd_main;       /* HIP-event time of the main forward kernel (record_events) */
   float ms_fwd_fallback;   /* HIP-event time of the fp64 fallback kernel */
   float ms_total_device;   /* first launch .. last kernel of the call */

@@ -94,8 +94,6 @@ def test_reference_vectors_bit_exact(native, engine):
             native.PairHmmContext(use_double=True, fma_mode=fma_mode) as c64:
         for v in vs:
             b = batch_from_vector(v)
-            if b.read_lens.max() > 511:
-                continue  # long-read kernel: covered by test_long_reads
             e = v["engines"][engine]
             out = c32.compute(b)
             r32, r64, u = c32.raw(b.n_pairs)
@@ -142,9 +140,9 @@ def test_hc_batch_policy_and_tolerance(native, ctx32, ctx64, oracle):
     assert np.mean(ref32 == out) > 0.9
 
 
-@pytest.mark.parametrize("rpl", [4, 8, 16])
+@pytest.mark.parametrize("rpl", [4, 8])
 def test_every_fp32_kernel_variant_bit_exact(native, oracle, rpl):
-    """rows_per_lane 4 = dual-chunk packed kernel, 8 = default, 16 = long-read variant."""
+    """rows_per_lane 4 = dual-chunk packed kernel, 8 = default."""
     b = make_batch("hc", 150, 12, seed=77)
     rng = np.random.RandomState(rpl)
     b2 = random_batch(rng, 30, 7, read_len=(1, 250), hap_len=(1, 90), alphabet=b"ACGTN")
@@ -153,6 +151,37 @@ def test_every_fp32_kernel_variant_bit_exact(native, oracle, rpl):
         check_against_oracle(c, oracle, b)
         assert c.stats()["rows_per_lane"] == rpl
         check_against_oracle(c, oracle, b2)
+
+
+@pytest.mark.parametrize("rpl", [0, 4])
+def test_long_reads_striped_kernel(native, oracle, rpl):
+    """Reads longer than a chunk (fp32: > 511 bases at 8 rows/lane, > 255 at 4; fp64: > 255) take the
+    striped kernel with the carry row in memory; mixed with short reads in one batch, with and
+    without the fp64 fallback, they must stay bit-exact."""
+    rng = np.random.RandomState(2024)
+    short = random_batch(rng, 20, 5, read_len=(30, 250), hap_len=(40, 700), qual_range=(10, 45))
+    longb = random_batch(rng, 7, 5, read_len=(256, 1400), hap_len=(300, 1500), qual_range=(10, 45))
+    edge = random_batch(rng, 4, 5, read_len=(511, 513), hap_len=(60, 70), qual_range=(10, 45))
+    # one batch: short + long reads against the long batch's haplotypes
+    def cat(*bs):
+        lens = np.concatenate([b.read_lens for b in bs])
+        off = np.zeros(lens.size + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        j = lambda name: np.concatenate([getattr(b, name) for b in bs])  # noqa: E731
+        return FlatBatch(lens.size, longb.n_haps, off, longb.hap_off, j("read_bases"), j("read_quals"),
+                         j("ins_gop"), j("del_gop"), j("gcp"), longb.hap_bases)
+    b = cat(short, longb, edge)
+    with native.PairHmmContext(rows_per_lane=rpl, record_events=True) as c:
+        out, u = check_against_oracle(c, oracle, b)
+        assert c.stats()["n_long_pairs"] > 0
+        assert u[20 * 5:].any() and not u[20 * 5:].all()  # long reads on both sides of the policy
+    with native.PairHmmContext(use_double=True) as c:
+        check_against_oracle(c, oracle, b, use_double=True)
+    # unrelated long reads: every long pair underflows and is recomputed by the striped fp64 kernel
+    unrelated = random_batch(rng, 3, 4, read_len=(600, 900), hap_len=(500, 800), related=False, qual_range=(25, 45))
+    with native.PairHmmContext(rows_per_lane=rpl) as c:
+        out, u = check_against_oracle(c, oracle, unrelated)
+        assert u.all()
 
 
 def test_region_batch_no_fallback(ctx32, oracle):
