@@ -160,8 +160,9 @@ __global__ void build_jobs_kernel(const LaneSlot* __restrict__ lanes, const int3
   extern __shared__ int32_t smem[];
   int32_t* s_reads = smem;                                   // [64] distinct reads of the chunk
   uint8_t* need = reinterpret_cast<uint8_t*>(smem + kLanes + 1);  // [n_haps]
-  const int c = blockIdx.x;
-  if (c >= *n_chunks) return;
+  const int total = *n_chunks;
+  for (int c = blockIdx.x; c < total; c += gridDim.x) {
+  __syncthreads();
   if (threadIdx.x == 0) smem[kLanes] = 0;
   __syncthreads();
   if (threadIdx.x < kLanes) {
@@ -187,6 +188,7 @@ __global__ void build_jobs_kernel(const LaneSlot* __restrict__ lanes, const int3
     j.chunk = c; j.hap_begin = k; j.hap_end = e; j.pad_ = 0;
     jobs[atomicAdd(job_count, 1)] = j;
   }
+  }  // chunk loop
 }
 
 // ---- packed fp64 fallback, step 1 (device): order the affected reads by how many haplotypes
@@ -225,48 +227,61 @@ __global__ __launch_bounds__(64) void pack_windows_kernel(const int32_t* __restr
                                                           const int32_t* __restrict__ n_fail_reads,
                                                           const int64_t* __restrict__ read_off, int rpl,
                                                           LaneSlot* __restrict__ lanes, int32_t* __restrict__ n_chunks) {
-  __shared__ int32_t s_read[kPackWindow], s_need[kPackWindow], s_bin[kPackWindow], s_off[kPackWindow];
-  __shared__ int32_t s_free[kPackWindow];
-  __shared__ int32_t s_nbins, s_base;
+  // One wavefront per window of <= 96 reads; everything is wave-parallel: rank sort by lanes
+  // needed (descending, stable), then best fit where the 64 lanes each watch up to two bins and
+  // a shuffle reduction picks the fullest bin that still fits.
+  __shared__ int32_t s_read[kPackWindow], s_need[kPackWindow], s_sread[kPackWindow], s_sneed[kPackWindow];
+  __shared__ int32_t s_bin[kPackWindow], s_off[kPackWindow];
+  const int lane = threadIdx.x;
   const int n = *n_fail_reads;
   const int w0 = blockIdx.x * kPackWindow;
   if (w0 >= n) return;
   const int cnt = min(kPackWindow, n - w0);
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+  for (int i = lane; i < cnt; i += kLanes) {
     const int r = order[w0 + i];
     s_read[i] = r;
     s_need[i] = (int)((read_off[r + 1] - read_off[r] + rpl) / rpl);  // blocks_for()
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < cnt; i++) {  // insertion sort, lanes needed descending
-      const int nr = s_read[i], nn = s_need[i];
-      int j = i - 1;
-      while (j >= 0 && s_need[j] < nn) { s_read[j + 1] = s_read[j]; s_need[j + 1] = s_need[j]; j--; }
-      s_read[j + 1] = nr; s_need[j + 1] = nn;
+  for (int i = lane; i < cnt; i += kLanes) {
+    const int ni = s_need[i];
+    int rank = 0;
+    for (int j = 0; j < cnt; j++) {
+      const int nj = s_need[j];
+      rank += (nj > ni) || (nj == ni && j < i);
     }
-    int nb = 0;
-    for (int i = 0; i < cnt; i++) {  // best fit
-      const int nn = s_need[i];
-      int best = -1, best_free = kLanes + 1;
-      for (int b = 0; b < nb; b++)
-        if (s_free[b] >= nn && s_free[b] < best_free) { best = b; best_free = s_free[b]; }
-      if (best < 0) { best = nb++; s_free[best] = kLanes; }
-      s_bin[i] = best;
-      s_off[i] = kLanes - s_free[best];
-      s_free[best] -= nn;
-    }
-    s_nbins = nb;
-    s_base = atomicAdd(n_chunks, nb);
+    s_sread[rank] = s_read[i];
+    s_sneed[rank] = ni;
   }
   __syncthreads();
+  int free0 = 0, free1 = 0;  // free lanes of bins `lane` and `lane + 64` (0 = bin not open)
+  int nb = 0;                // bins opened so far (wave-uniform)
+  for (int i = 0; i < cnt; i++) {
+    const int nn = s_sneed[i];
+    // key = free*256 + bin for bins that fit, smallest free wins (best fit); none -> large
+    int key = 0x7fffffff;
+    if (free0 >= nn) key = free0 * 256 + lane;
+    if (free1 >= nn && free1 * 256 + lane + kLanes < key) key = free1 * 256 + lane + kLanes;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) key = min(key, __shfl_xor(key, d, kLanes));
+    int bin, off;
+    if (key == 0x7fffffff) { bin = nb++; off = 0; }
+    else { bin = key & 255; off = kLanes - (key >> 8); }
+    if (bin == lane) free0 = (key == 0x7fffffff ? kLanes : free0) - nn;
+    if (bin == lane + kLanes) free1 = (key == 0x7fffffff ? kLanes : free1) - nn;
+    if (lane == 0) { s_bin[i] = bin; s_off[i] = off; }
+  }
+  int base = 0;
+  if (lane == 0) base = atomicAdd(n_chunks, nb);
+  base = __shfl(base, 0, kLanes);
+  __syncthreads();
   LaneSlot idle; idle.read = -1; idle.block = 0;
-  for (int i = threadIdx.x; i < s_nbins * kLanes; i += blockDim.x) lanes[(int64_t)s_base * kLanes + i] = idle;
+  for (int i = lane; i < nb * kLanes; i += kLanes) lanes[(int64_t)base * kLanes + i] = idle;
   __syncthreads();
   for (int i = 0; i < cnt; i++)
-    for (int b = threadIdx.x; b < s_need[i]; b += blockDim.x) {
-      LaneSlot sl; sl.read = s_read[i]; sl.block = b;
-      lanes[(int64_t)(s_base + s_bin[i]) * kLanes + s_off[i] + b] = sl;
+    for (int b = lane; b < s_sneed[i]; b += kLanes) {
+      LaneSlot sl; sl.read = s_sread[i]; sl.block = b;
+      lanes[(int64_t)(base + s_bin[i]) * kLanes + s_off[i] + b] = sl;
     }
 }
 
@@ -414,6 +429,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   const int fma = c->cfg.fma_mode != 0;
 
   // ---- plan (host) ----
+  const auto t_plan0 = std::chrono::steady_clock::now();
   Plan& plan = c->plan;
   const int rpl64 = kRplF64;
   const int rpl_main = use_double ? rpl64 : pick_rpl_f32(c->cfg.rows_per_lane);
@@ -478,6 +494,10 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   unsigned char* dp = c->plan_dev.as<unsigned char>();
   HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, s));
   HIP_TRY(hipEventRecord(c->stage_free, s));
+  if (getenv("GKLHIP_TIMING"))
+    fprintf(stderr, "[gklhip] host plan + staging: %.3f ms (%d chunks, %zu stream entries, %zu plan bytes)\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count(),
+            plan.n_chunks, plan.stream_src.size(), L.total);
 
   // ---- scratch ----
   if ((rc = c->raw32.reserve((size_t)n_pairs * 4))) return rc;
@@ -613,7 +633,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     hipLaunchKernelGGL(pack_windows_kernel, dim3((unsigned)((n_reads + kPackWindow - 1) / kPackWindow)), dim3(64), 0, s,
                        c->fail_order.as<int32_t>(), cnts + 4, b.read_off, rpl64, c->lanes2.as<LaneSlot>(), cnts + 5);
     const int jb_threads = n_haps <= 64 ? 64 : n_haps <= 128 ? 128 : 256;
-    hipLaunchKernelGGL(build_jobs_kernel, dim3((unsigned)n_reads), dim3(jb_threads),
+    hipLaunchKernelGGL(build_jobs_kernel, dim3((unsigned)std::min(n_reads, 2048)), dim3(jb_threads),
                        (size_t)(kLanes + 1) * 4 + (size_t)n_haps, s, c->lanes2.as<LaneSlot>(), cnts + 5,
                        c->used64.as<uint8_t>(), n_haps, reinterpret_cast<const int32_t*>(dp + L.hap_orig),
                        reinterpret_cast<const int32_t*>(dp + L.hap_group), c->jobs.as<FwdJob>(), cnts + 2);

@@ -387,7 +387,7 @@ struct WaveJob {
     for (int k = hap_begin; k < hap_end; k++) {
       const int sep_at = a.hap_pos[k] - sb + a.hap_len[k];  // stream-relative separator position
       const int slow_end = fast_from < sep_at ? fast_from : sep_at;
-      for (; t < slow_end; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
+      run_any(a, sp, t, slow_end, lane, hap_begin, hap_end);
       for (; t + U <= sep_at; t += U) {
         uint32_t e[U];
 #pragma unroll
@@ -397,10 +397,25 @@ struct WaveJob {
       }
       if (t >= fast_from)
         for (; t < sep_at; t++) step_fast(sp[t], lane);  // < U leftover columns, still all in-haplotype
-      for (; t < sep_at; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
+      run_any(a, sp, t, sep_at, lane, hap_begin, hap_end);
       fast_from = sep_at + kLanes;
     }
-    for (; t < fast_from; t++) step_any(a, sp[t], lane, hap_begin, hap_end);  // drain
+    run_any(a, sp, t, fast_from, lane, hap_begin, hap_end);  // drain
+  }
+
+  // General steps for stream positions [t, end): four at a time so the stream entries come from
+  // one scalar load issued ahead of use and the state needs no loop-carried register copies.
+  __device__ __forceinline__ void run_any(const FwdArgs<T>& a, const uint32_t* __restrict__ sp, int& t, int end,
+                                          int lane, int hap_begin, int hap_end) {
+    constexpr int V = 4;
+    for (; t + V <= end; t += V) {
+      uint32_t e[V];
+#pragma unroll
+      for (int u = 0; u < V; u++) e[u] = sp[t + u];
+#pragma unroll
+      for (int u = 0; u < V; u++) step_any(a, e[u], lane, hap_begin, hap_end);
+    }
+    for (; t < end; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
   }
 
   // One 64-lane STRIPE of a read that is longer than a chunk (the reference's stripe loop with

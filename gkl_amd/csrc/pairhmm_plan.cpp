@@ -79,48 +79,68 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
 
 int pack_reads_windowed(const int32_t* order_in, int n, const int64_t* read_off, int rows_per_lane,
                         int window, std::vector<PlanLane>* lanes, int64_t* useful_rows) {
+  // Allocation-free inner loops (this runs on the caller's thread for every batch): counting
+  // sort by lanes needed, then best fit through per-free-size stacks threaded through `next`.
   const int rpl = rows_per_lane;
   if (window < 1) window = 1;
   int chunks_total = 0;
-  std::vector<int32_t> order, need_of;
-  std::vector<std::vector<int32_t>> open(kLanes + 1);
-  std::vector<int32_t> used_lanes;
-  std::vector<std::vector<int32_t>> members;
+  // lanes needed per read, computed once (a shift when rpl is a power of two, as it always is)
+  int shift = -1;
+  for (int b = 0; b < 8; b++) if ((1 << b) == rpl) shift = b;
+  std::vector<uint8_t> need_of((size_t)n);
+  int64_t need_sum = 0;
+  for (int i = 0; i < n; i++) {
+    const int32_t r = order_in[i];
+    const int R = (int)(read_off[r + 1] - read_off[r]);
+    need_of[i] = (uint8_t)(shift >= 0 ? (R + rpl) >> shift : blocks_for(R, rpl));
+    need_sum += need_of[i];
+    if (useful_rows) *useful_rows += R;
+  }
+  lanes->reserve(lanes->size() + (size_t)(need_sum + need_sum / 8 + 2 * kLanes));
+  std::vector<int32_t> sorted((size_t)std::min(n, window));
+  std::vector<uint8_t> sorted_need((size_t)std::min(n, window));
+  std::vector<int32_t> next;  // per chunk of the current window: next chunk with the same free size
+  std::vector<int32_t> used;  // per chunk: lanes taken
   for (int w0 = 0; w0 < n; w0 += window) {
-    const int w1 = std::min(n, w0 + window);
-    order.assign(order_in + w0, order_in + w1);
-    auto need = [&](int32_t r) { return blocks_for((int)(read_off[r + 1] - read_off[r]), rpl); };
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return need(a) > need(b); });
-    for (auto& o : open) o.clear();
-    used_lanes.clear();
-    members.clear();
-    for (int32_t r : order) {
-      const int nb = need(r);  // 1..64 (caller guarantees the read fits a chunk)
-      if (useful_rows) *useful_rows += read_off[r + 1] - read_off[r];
+    const int cnt = std::min(window, n - w0);
+    int32_t bucket[kLanes + 2] = {0};
+    for (int i = 0; i < cnt; i++) bucket[need_of[w0 + i]]++;
+    int32_t start[kLanes + 2];
+    int acc = 0;
+    for (int c = kLanes; c >= 1; c--) { start[c] = acc; acc += bucket[c]; }  // descending, stable
+    for (int i = 0; i < cnt; i++) {
+      const int at = start[need_of[w0 + i]]++;
+      sorted[at] = order_in[w0 + i];
+      sorted_need[at] = need_of[w0 + i];
+    }
+    int32_t head[kLanes + 1];
+    for (int c = 0; c <= kLanes; c++) head[c] = -1;
+    next.clear();
+    used.clear();
+    const size_t base = lanes->size();
+    for (int i = 0; i < cnt; i++) {
+      const int32_t r = sorted[i];
+      const int nb = sorted_need[i];  // 1..64 (caller guarantees the read fits a chunk)
       int c = nb;
-      while (c <= kLanes && open[c].empty()) c++;  // open[c] = chunks with exactly c free lanes
+      while (c <= kLanes && head[c] < 0) c++;  // smallest free size that fits
       int chunk;
       if (c > kLanes) {
-        chunk = (int)used_lanes.size();
-        used_lanes.push_back(0);
-        members.emplace_back();
+        chunk = (int)used.size();
+        used.push_back(0);
+        next.push_back(-1);
+        lanes->resize(base + (size_t)(chunk + 1) * kLanes, PlanLane{-1, 0});
         c = kLanes;
       } else {
-        chunk = open[c].back();
-        open[c].pop_back();
+        chunk = head[c];
+        head[c] = next[chunk];
       }
-      members[chunk].push_back(r);
-      used_lanes[chunk] += nb;
-      if (c - nb > 0) open[c - nb].push_back(chunk);
+      PlanLane* dst = lanes->data() + base + (size_t)chunk * kLanes + used[chunk];
+      for (int b = 0; b < nb; b++) dst[b] = PlanLane{r, b};
+      used[chunk] += nb;
+      const int left = c - nb;
+      if (left > 0) { next[chunk] = head[left]; head[left] = chunk; }
     }
-    const size_t base = lanes->size();
-    lanes->resize(base + members.size() * kLanes, PlanLane{-1, 0});
-    for (size_t ch = 0; ch < members.size(); ch++) {
-      int lane = 0;
-      for (int32_t r : members[ch])
-        for (int b = 0; b < need(r); b++) (*lanes)[base + ch * kLanes + lane++] = PlanLane{r, b};
-    }
-    chunks_total += (int)members.size();
+    chunks_total += (int)used.size();
   }
   return chunks_total;
 }
