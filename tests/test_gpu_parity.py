@@ -184,6 +184,43 @@ def test_long_reads_striped_kernel(native, oracle, rpl):
         assert u.all()
 
 
+def test_full_size_batch_properties(native, oracle):
+    """BASELINE config 2/3 at full size (10 000 reads x 128 haps, 1.28 M pairs): too big for the
+    oracle as a whole, so check size-independent properties bit-for-bit: (1) every pair's result
+    is independent of what else is in the batch (a sub-batch reproduces the full batch's entries),
+    (2) permuting reads and haplotypes permutes the outputs, (3) a random sub-batch agrees with
+    the oracle, (4) the fp32 policy stays within 1e-5 relative of the fp64 path."""
+    b = make_batch("hc")
+    rng = np.random.RandomState(42)
+    with native.PairHmmContext(record_events=True) as c:
+        full = c.compute(b).reshape(b.n_reads, b.n_haps)
+        st = c.stats()
+        assert st["n_fallback"] > 100000 and st["n_chunks"] > 2000  # packed fp64 fallback path in use
+        r32, r64, u = c.raw(b.n_pairs)
+        u = u.reshape(b.n_reads, b.n_haps)
+        # (1)+(3): 48 random reads against all haplotypes
+        pick = np.sort(rng.choice(b.n_reads, 48, replace=False))
+        subs = [b.read_slice(int(r), int(r) + 1) for r in pick]
+        lens = np.array([s.read_lens[0] for s in subs])
+        off = np.zeros(len(subs) + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        j = lambda name: np.concatenate([getattr(s, name) for s in subs])  # noqa: E731
+        sb = FlatBatch(len(subs), b.n_haps, off, b.hap_off, j("read_bases"), j("read_quals"), j("ins_gop"),
+                       j("del_gop"), j("gcp"), b.hap_bases)
+        sub = c.compute(sb).reshape(len(subs), b.n_haps)
+        assert np.array_equal(bits(sub), bits(full[pick]))
+        exp = oracle.batch(sb, n_threads=8).reshape(len(subs), b.n_haps)
+        assert np.array_equal(bits(sub), bits(exp))
+        # (2): reversed reads and haplotypes
+        rb = FlatBatch.from_holders(*[list(reversed(x)) for x in b.read_slice(0, 2000).to_holders()])
+        rev = c.compute(rb).reshape(2000, b.n_haps)
+        assert np.array_equal(bits(rev[::-1, ::-1]), bits(full[:2000]))
+    with native.PairHmmContext(use_double=True) as c64:
+        fulld = c64.compute(b).reshape(b.n_reads, b.n_haps)
+    assert np.max(np.abs(full - fulld) / np.abs(fulld)) < REL_TOL
+    assert np.array_equal(bits(full[u == 1]), bits(fulld[u == 1]))  # fallback pairs ARE the fp64 path
+
+
 def test_region_batch_no_fallback(ctx32, oracle):
     b = make_batch("region", 200, 16, seed=5)
     out, u = check_against_oracle(ctx32, oracle, b)
