@@ -12,7 +12,7 @@
 // Slots used (spec index): FindClass 6, ThrowNew 14, ExceptionClear 17,
 // DeleteLocalRef 23, GetFieldID 94, GetObjectField 95, GetArrayLength 171,
 // GetObjectArrayElement 173, GetByteArrayRegion 200, SetDoubleArrayRegion 214,
-// ExceptionCheck 228.
+// ExceptionCheck 228; the PDHMM shim adds NewDoubleArray 182 and GetLongArrayRegion 204.
 #pragma once
 #include <stdint.h>
 
@@ -37,6 +37,7 @@ typedef jobject jarray;
 typedef jarray jobjectArray;
 typedef jarray jbyteArray;
 typedef jarray jdoubleArray;
+typedef jarray jlongArray;
 struct _jfieldID;
 typedef struct _jfieldID* jfieldID;
 
@@ -57,7 +58,9 @@ enum {
   kJniSlotGetObjectField = 95,
   kJniSlotGetArrayLength = 171,
   kJniSlotGetObjectArrayElement = 173,
+  kJniSlotNewDoubleArray = 182,
   kJniSlotGetByteArrayRegion = 200,
+  kJniSlotGetLongArrayRegion = 204,
   kJniSlotSetDoubleArrayRegion = 214,
   kJniSlotExceptionCheck = 228,
   kJniSlotCount = 235  // JNI 9+: GetModule is 233, IsVirtualThread (21) is 234
@@ -102,6 +105,12 @@ inline jobject GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) {
 }
 inline void GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, jbyte* buf) {
   fn<void (*)(JNIEnv*, jbyteArray, jsize, jsize, jbyte*)>(e, kJniSlotGetByteArrayRegion)(e, a, start, len, buf);
+}
+inline jdoubleArray NewDoubleArray(JNIEnv* e, jsize len) {
+  return fn<jdoubleArray (*)(JNIEnv*, jsize)>(e, kJniSlotNewDoubleArray)(e, len);
+}
+inline void GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize start, jsize len, jlong* buf) {
+  fn<void (*)(JNIEnv*, jlongArray, jsize, jsize, jlong*)>(e, kJniSlotGetLongArrayRegion)(e, a, start, len, buf);
 }
 inline void SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
   fn<void (*)(JNIEnv*, jdoubleArray, jsize, jsize, const jdouble*)>(e, kJniSlotSetDoubleArrayRegion)(e, a, start, len, buf);

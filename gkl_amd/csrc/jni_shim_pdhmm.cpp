@@ -1,0 +1,226 @@
+// JNI drop-in layer of libgkl_pdhmm.so: the four natives of com.intel.gkl.pdhmm.IntelPDHMM
+// (include/gkl_pdhmm_jni.h) over the C ABI of include/gkl_hip_pdhmm.h.  Replaces the reference's
+// IntelPDHMM.cc + JavaData.h; arrays are copied with Get<T>ArrayRegion (no critical sections held
+// across GPU work), every pair goes through the same (vector-arithmetic) kernel.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/gkl_hip_pairhmm.h"
+#include "../../include/gkl_hip_pdhmm.h"
+#include "../../include/gkl_pdhmm_jni.h"
+
+#ifdef GKL_USE_SYSTEM_JNI
+namespace gkljni {
+inline jclass FindClass(JNIEnv* e, const char* n) { return e->FindClass(n); }
+inline jint ThrowNew(JNIEnv* e, jclass c, const char* m) { return e->ThrowNew(c, m); }
+inline void ExceptionClear(JNIEnv* e) { e->ExceptionClear(); }
+inline jboolean ExceptionCheck(JNIEnv* e) { return e->ExceptionCheck(); }
+inline void DeleteLocalRef(JNIEnv* e, jobject o) { e->DeleteLocalRef(o); }
+inline jfieldID GetFieldID(JNIEnv* e, jclass c, const char* n, const char* s) { return e->GetFieldID(c, n, s); }
+inline jobject GetObjectField(JNIEnv* e, jobject o, jfieldID f) { return e->GetObjectField(o, f); }
+inline jsize GetArrayLength(JNIEnv* e, jarray a) { return e->GetArrayLength(a); }
+inline jobject GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { return e->GetObjectArrayElement(a, i); }
+inline void GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, jbyte* b) { e->GetByteArrayRegion(a, s, l, b); }
+inline void GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, jlong* b) { e->GetLongArrayRegion(a, s, l, b); }
+inline jdoubleArray NewDoubleArray(JNIEnv* e, jsize l) { return e->NewDoubleArray(l); }
+inline void SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize s, jsize l, const jdouble* b) { e->SetDoubleArrayRegion(a, s, l, b); }
+}  // namespace gkljni
+#endif
+
+namespace {
+constexpr const char* kIAE = "java/lang/IllegalArgumentException";
+constexpr const char* kOOM = "java/lang/OutOfMemoryError";
+constexpr const char* kRTE = "java/lang/RuntimeException";
+
+struct State {
+  std::mutex mu;
+  gklhip_pdhmm_ctx* ctx = nullptr;
+  int max_memory_mb = 512;
+  jfieldID readBases = nullptr, readQuals = nullptr, insertionGOP = nullptr, deletionGOP = nullptr,
+           overallGCP = nullptr, haplotypeBases = nullptr, haplotypePDBases = nullptr;
+} g;
+
+void throw_java(JNIEnv* env, const char* cls, const char* msg) {
+  gkljni::ExceptionClear(env);
+  jclass c = gkljni::FindClass(env, cls);
+  if (c) gkljni::ThrowNew(env, c, msg);
+}
+
+void throw_status(JNIEnv* env, int st) {
+  const char* d = gklhip_pdhmm_last_error();
+  char msg[600];
+  snprintf(msg, sizeof msg, "%s", (d && *d) ? d : "GKL-HIP PDHMM failure");
+  throw_java(env, st == GKLHIP_ERR_INVALID_ARG ? kIAE : st == GKLHIP_ERR_OOM ? kOOM : kRTE, msg);
+}
+
+gklhip_pdhmm_ctx* context() {
+  std::lock_guard<std::mutex> lock(g.mu);
+  return g.ctx;
+}
+
+// holder[i].<field> -> bytes; false after throwing
+bool read_field(JNIEnv* env, jobjectArray arr, jsize i, jfieldID fid, std::vector<int8_t>& dst) {
+  jobject holder = gkljni::GetObjectArrayElement(env, arr, i);
+  if (gkljni::ExceptionCheck(env)) return false;
+  if (!holder) { throw_java(env, kIAE, "null element in data holder array"); return false; }
+  jbyteArray bytes = (jbyteArray)gkljni::GetObjectField(env, holder, fid);
+  if (!bytes) { gkljni::DeleteLocalRef(env, holder); throw_java(env, kIAE, "null byte[] field in data holder"); return false; }
+  const jsize len = gkljni::GetArrayLength(env, bytes);
+  dst.resize((size_t)len);
+  if (len > 0) gkljni::GetByteArrayRegion(env, bytes, 0, len, reinterpret_cast<jbyte*>(dst.data()));
+  gkljni::DeleteLocalRef(env, bytes);
+  gkljni::DeleteLocalRef(env, holder);
+  return !gkljni::ExceptionCheck(env);
+}
+}  // namespace
+
+extern "C" {
+
+JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_initNative(JNIEnv* env, jclass, jclass readDataHolder,
+                                                                     jclass haplotypeDataHolder, jint, jint, jint,
+                                                                     jint maxMemoryInMB) {
+  std::lock_guard<std::mutex> lock(g.mu);
+  struct { jfieldID* dst; jclass cls; const char* name; } fields[] = {
+      {&g.readBases, readDataHolder, "readBases"},       {&g.readQuals, readDataHolder, "readQuals"},
+      {&g.insertionGOP, readDataHolder, "insertionGOP"}, {&g.deletionGOP, readDataHolder, "deletionGOP"},
+      {&g.overallGCP, readDataHolder, "overallGCP"},     {&g.haplotypeBases, haplotypeDataHolder, "haplotypeBases"},
+      {&g.haplotypePDBases, haplotypeDataHolder, "haplotypePDBases"}};
+  for (auto& f : fields) {
+    jfieldID id = f.cls ? gkljni::GetFieldID(env, f.cls, f.name, "[B") : nullptr;
+    if (!id) { throw_java(env, kIAE, "Unable to get field ID"); return; }  // JavaData.h:282-290
+    *f.dst = id;
+  }
+  g.max_memory_mb = maxMemoryInMB > 0 ? maxMemoryInMB : 512;
+  if (g.ctx) { gklhip_pdhmm_done(g.ctx); g.ctx = nullptr; }
+  const char* dev = getenv("GKL_HIP_DEVICE");
+  const int st = gklhip_pdhmm_init((dev && *dev) ? atoi(dev) : -1, &g.ctx);
+  if (st != GKLHIP_OK) { g.ctx = nullptr; throw_status(env, st); }
+}
+
+JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNative(
+    JNIEnv* env, jobject, jobjectArray readDataArray, jobjectArray haplotypeDataArray, jdoubleArray likelihoodArray) {
+  if (!readDataArray || !haplotypeDataArray || !likelihoodArray) { throw_java(env, kIAE, "null argument"); return; }
+  gklhip_pdhmm_ctx* ctx = context();
+  if (!ctx) { throw_java(env, kRTE, "GKL-HIP PDHMM: computeLikelihoodsNative before initNative"); return; }
+  try {
+    const jsize n_reads = gkljni::GetArrayLength(env, readDataArray);
+    const jsize n_haps = gkljni::GetArrayLength(env, haplotypeDataArray);
+    const int64_t total = (int64_t)n_reads * n_haps;
+    if (total == 0) {  // JavaData.h:93-96
+      throw_java(env, kIAE, "Batch size is too small because there are no pairs to process. Ensure that the input arrays are not empty.");
+      return;
+    }
+    if (total > 0x7fffffffLL || (int64_t)gkljni::GetArrayLength(env, likelihoodArray) < total) {
+      throw_java(env, kIAE, "likelihoodArray length must be equal to readDataArray length * haplotypeDataArray length");
+      return;
+    }
+    std::vector<std::vector<int8_t>> rb(n_reads), rq(n_reads), ri(n_reads), rd(n_reads), rc(n_reads), hb(n_haps), hp(n_haps);
+    int max_r = 0, max_h = 0;
+    for (jsize r = 0; r < n_reads; r++) {
+      if (!read_field(env, readDataArray, r, g.readBases, rb[r]) || !read_field(env, readDataArray, r, g.readQuals, rq[r]) ||
+          !read_field(env, readDataArray, r, g.insertionGOP, ri[r]) || !read_field(env, readDataArray, r, g.deletionGOP, rd[r]) ||
+          !read_field(env, readDataArray, r, g.overallGCP, rc[r]))
+        return;
+      const size_t len = rb[r].size();
+      if (len == 0 || rq[r].size() < len || ri[r].size() < len || rd[r].size() < len || rc[r].size() < len) {
+        throw_java(env, kIAE, "empty read or read quality array shorter than readBases");
+        return;
+      }
+      max_r = (int)std::max<size_t>(max_r, len);
+    }
+    for (jsize h = 0; h < n_haps; h++) {
+      if (!read_field(env, haplotypeDataArray, h, g.haplotypeBases, hb[h]) ||
+          !read_field(env, haplotypeDataArray, h, g.haplotypePDBases, hp[h]))
+        return;
+      if (hb[h].empty() || hp[h].size() < hb[h].size()) { throw_java(env, kIAE, "empty haplotype or haplotypePDBases shorter than haplotypeBases"); return; }
+      max_h = (int)std::max<size_t>(max_h, hb[h].size());
+    }
+    // batches bounded by maxMemoryInMB like JavaData.h:86-101
+    const int64_t per_pair = (int64_t)max_r * 5 + (int64_t)max_h * 2 + 8 + 16;
+    int64_t batch = std::min<int64_t>(total, ((int64_t)g.max_memory_mb * 1024 * 1024) / per_pair);
+    if (batch <= 0) { throw_java(env, kIAE, "Batch size is too small. Please increase the memory limit for PDHMM by using the maxMemoryInMB argument."); return; }
+    std::vector<int8_t> b_hb((size_t)batch * max_h), b_hp((size_t)batch * max_h), b_rb((size_t)batch * max_r),
+        b_rq((size_t)batch * max_r), b_ri((size_t)batch * max_r), b_rd((size_t)batch * max_r), b_rc((size_t)batch * max_r);
+    std::vector<int64_t> hl((size_t)batch), rl((size_t)batch);
+    std::vector<double> out((size_t)batch);
+    for (int64_t start = 0; start < total; start += batch) {
+      const int64_t cnt = std::min(batch, total - start);
+      std::fill(b_hb.begin(), b_hb.end(), 0); std::fill(b_hp.begin(), b_hp.end(), 0);
+      for (auto* v : {&b_rb, &b_rq, &b_ri, &b_rd, &b_rc}) std::fill(v->begin(), v->end(), 0);
+      for (int64_t k = 0; k < cnt; k++) {
+        const int64_t pair = start + k;  // read-major: JavaData.h:190-191
+        const int r = (int)(pair / n_haps), h = (int)(pair % n_haps);
+        const size_t R = rb[r].size(), H = hb[h].size();
+        memcpy(&b_rb[(size_t)k * max_r], rb[r].data(), R); memcpy(&b_rq[(size_t)k * max_r], rq[r].data(), R);
+        memcpy(&b_ri[(size_t)k * max_r], ri[r].data(), R); memcpy(&b_rd[(size_t)k * max_r], rd[r].data(), R);
+        memcpy(&b_rc[(size_t)k * max_r], rc[r].data(), R);
+        memcpy(&b_hb[(size_t)k * max_h], hb[h].data(), H); memcpy(&b_hp[(size_t)k * max_h], hp[h].data(), H);
+        hl[(size_t)k] = (int64_t)H; rl[(size_t)k] = (int64_t)R;
+      }
+      gklhip_pdhmm_batch b = {(int32_t)cnt, max_h, max_r, b_hb.data(), b_hp.data(), b_rb.data(), b_rq.data(),
+                              b_ri.data(), b_rd.data(), b_rc.data(), hl.data(), rl.data()};
+      const int st = gklhip_pdhmm_compute(ctx, &b, out.data());
+      if (st != GKLHIP_OK) { throw_status(env, st); return; }
+      gkljni::SetDoubleArrayRegion(env, likelihoodArray, (jsize)start, (jsize)cnt, out.data());
+    }
+  } catch (const std::bad_alloc&) {
+    throw_java(env, kOOM, "Memory allocation issue.");
+  }
+}
+
+JNIEXPORT jdoubleArray JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computePDHMMNative(
+    JNIEnv* env, jobject, jbyteArray jhap_bases, jbyteArray jhap_pdbases, jbyteArray jread_bases, jbyteArray jread_qual,
+    jbyteArray jread_ins_qual, jbyteArray jread_del_qual, jbyteArray jgcp, jlongArray jhap_lengths,
+    jlongArray jread_lengths, jint testcase, jint maxHapLength, jint maxReadLength) {
+  gklhip_pdhmm_ctx* ctx = context();
+  if (!ctx) { throw_java(env, kRTE, "GKL-HIP PDHMM: computePDHMMNative before initNative"); return nullptr; }
+  if (!jhap_bases || !jhap_pdbases || !jread_bases || !jread_qual || !jread_ins_qual || !jread_del_qual || !jgcp ||
+      !jhap_lengths || !jread_lengths || testcase <= 0 || maxHapLength <= 0 || maxReadLength <= 0) {
+    throw_java(env, kIAE, "Input arrays aren't valid.");  // IntelPDHMM.cc:165-189
+    return nullptr;
+  }
+  try {
+    const size_t hb = (size_t)testcase * (size_t)maxHapLength, rb = (size_t)testcase * (size_t)maxReadLength;
+    jbyteArray arrs[7] = {jhap_bases, jhap_pdbases, jread_bases, jread_qual, jread_ins_qual, jread_del_qual, jgcp};
+    const size_t want[7] = {hb, hb, rb, rb, rb, rb, rb};
+    std::vector<int8_t> bufs[7];
+    for (int i = 0; i < 7; i++) {
+      if ((size_t)gkljni::GetArrayLength(env, arrs[i]) < want[i]) { throw_java(env, kIAE, "Input arrays aren't valid."); return nullptr; }
+      bufs[i].resize(want[i]);
+      gkljni::GetByteArrayRegion(env, arrs[i], 0, (jsize)want[i], reinterpret_cast<jbyte*>(bufs[i].data()));
+    }
+    if (gkljni::GetArrayLength(env, jhap_lengths) < testcase || gkljni::GetArrayLength(env, jread_lengths) < testcase) {
+      throw_java(env, kIAE, "Input arrays aren't valid.");
+      return nullptr;
+    }
+    std::vector<int64_t> hl((size_t)testcase), rl((size_t)testcase);
+    gkljni::GetLongArrayRegion(env, jhap_lengths, 0, testcase, reinterpret_cast<jlong*>(hl.data()));
+    gkljni::GetLongArrayRegion(env, jread_lengths, 0, testcase, reinterpret_cast<jlong*>(rl.data()));
+    if (gkljni::ExceptionCheck(env)) return nullptr;
+    jdoubleArray jresult = gkljni::NewDoubleArray(env, testcase);
+    if (!jresult) { throw_java(env, kOOM, "Memory allocation issue."); return nullptr; }
+    std::vector<double> out((size_t)testcase);
+    gklhip_pdhmm_batch b = {testcase, maxHapLength, maxReadLength, bufs[0].data(), bufs[1].data(), bufs[2].data(),
+                            bufs[3].data(), bufs[4].data(), bufs[5].data(), bufs[6].data(), hl.data(), rl.data()};
+    const int st = gklhip_pdhmm_compute(ctx, &b, out.data());
+    if (st != GKLHIP_OK) { throw_status(env, st); return jresult; }  // the reference also returns the array (IntelPDHMM.cc:241)
+    gkljni::SetDoubleArrayRegion(env, jresult, 0, testcase, out.data());
+    return jresult;
+  } catch (const std::bad_alloc&) {
+    throw_java(env, kOOM, "Memory allocation issue.");
+    return nullptr;
+  }
+}
+
+JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_doneNative(JNIEnv*, jclass) {
+  std::lock_guard<std::mutex> lock(g.mu);
+  if (g.ctx) { gklhip_pdhmm_done(g.ctx); g.ctx = nullptr; }
+}
+
+}  // extern "C"

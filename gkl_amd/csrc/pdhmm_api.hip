@@ -1,0 +1,250 @@
+// C-ABI implementation (include/gkl_hip_pdhmm.h) of the MI355X PDHMM path.  Compiled WITHOUT the
+// fp64 flush-to-zero flag of the PairHMM translation unit: the reference's PDHMM never touches
+// MXCSR (no _MM_SET_FLUSH_ZERO_MODE anywhere under src/main/native/pdhmm).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gkl_hip_pairhmm.h"  // status codes
+#include "../../include/gkl_hip_pdhmm.h"
+#include "pdhmm_kernel.h"
+
+using namespace gklhip;
+
+namespace {
+thread_local std::string g_pd_err;
+
+int pd_fail(int status, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_pd_err = buf;
+  return status;
+}
+
+#define PD_HIP_TRY(expr)                                                                          \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess) {                                                                      \
+      (void)hipGetLastError();                                                                    \
+      return pd_fail(e__ == hipErrorOutOfMemory ? GKLHIP_ERR_OOM : GKLHIP_ERR_HIP, "%s: %s", #expr, \
+                     hipGetErrorString(e__));                                                     \
+    }                                                                                             \
+  } while (0)
+
+// ---- host tables: ProbabilityCache of pdhmm-common.h:139-192 (exact 1/ln10 here, unlike PairHMM) ----
+constexpr int kPdMaxQual = 254;
+constexpr int kPdMmSize = ((kPdMaxQual + 1) * (kPdMaxQual + 2)) >> 1;
+
+struct PdTables {
+  std::vector<double> q2err, mm;
+  double initial_condition, initial_condition_log10;
+};
+
+const PdTables& pd_tables() {
+  static const PdTables t = [] {
+    PdTables r;
+    std::vector<double> jac(80001);
+    for (int k = 0; k < 80001; k++) jac[k] = std::log10(1.0 + std::pow(10.0, -k * 0.0001));  // MathUtils.cc:84-87
+    auto round_half_away = [](double d) { return d > 0.0 ? (int)(d + 0.5) : (int)(d - 0.5); };
+    auto log10_sum = [&](double a, double b) {  // MathUtils.cc:91-109 (a <= b after the swap)
+      if (a > b) std::swap(a, b);
+      if (a == -1e10) return b;
+      const double diff = b - a;
+      return b + (diff < 8.0 ? jac[round_half_away(diff * (1.0 / 0.0001))] : 0.0);
+    };
+    const double inv_ln10 = 1.0 / std::log(10);
+    r.mm.resize(kPdMmSize);
+    for (int i = 0, offset = 0; i <= kPdMaxQual; offset += ++i)
+      for (int j = 0; j <= i; j++) {
+        const double l10 = std::log1p(-std::min(1.0, std::pow(10, log10_sum(-0.1 * i, -0.1 * j)))) * inv_ln10;
+        r.mm[offset + j] = std::pow(10, l10);
+      }
+    r.q2err.resize(kPdMaxQual + 1);
+    for (int q = 0; q <= kPdMaxQual; q++) r.q2err[q] = std::pow(10.0, (double)q / -10.0);
+    r.initial_condition = std::pow(2, 1020);                       // MathUtils.cc:31
+    r.initial_condition_log10 = std::log10(r.initial_condition);  // :32
+    return r;
+  }();
+  return t;
+}
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return GKLHIP_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    const size_t want = n + n / 4 + 256;
+    PD_HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+    return GKLHIP_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+}  // namespace
+
+struct gklhip_pdhmm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::mutex mu;
+  Buf tables, inputs, entries, sums, misc, carry;
+  float last_ms = 0.f;
+};
+
+extern "C" {
+
+const char* gklhip_pdhmm_last_error(void) { return g_pd_err.c_str(); }
+
+int64_t gklhip_pdhmm_get_table(int which, double* dst, int64_t cap) {
+  const PdTables& t = pd_tables();
+  const std::vector<double>* v = which == 0 ? &t.q2err : which == 1 ? &t.mm : nullptr;
+  if (!v) return -1;
+  if (dst) memcpy(dst, v->data(), sizeof(double) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
+  return (int64_t)v->size();
+}
+
+int gklhip_pdhmm_init(int device, gklhip_pdhmm_ctx** out_ctx) {
+  if (!out_ctx) return pd_fail(GKLHIP_ERR_INVALID_ARG, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return pd_fail(GKLHIP_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU compute path)");
+  }
+  if (device < 0) PD_HIP_TRY(hipGetDevice(&device));
+  if (device >= ndev) return pd_fail(GKLHIP_ERR_INVALID_ARG, "device %d of %d", device, ndev);
+  PD_HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PD_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return pd_fail(GKLHIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  gklhip_pdhmm_ctx* c = new (std::nothrow) gklhip_pdhmm_ctx();
+  if (!c) return pd_fail(GKLHIP_ERR_OOM, "context allocation failed");
+  c->device = device;
+  auto bail = [&](int st) { gklhip_pdhmm_done(c); return st; };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(pd_fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(pd_fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  const PdTables& t = pd_tables();
+  int rc = c->tables.reserve((t.q2err.size() + t.mm.size()) * sizeof(double));
+  if (rc) return bail(rc);
+  if (hipMemcpy(c->tables.p, t.q2err.data(), t.q2err.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->tables.as<double>() + t.q2err.size(), t.mm.data(), t.mm.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+    return bail(pd_fail(GKLHIP_ERR_HIP, "table upload failed"));
+  *out_ctx = c;
+  return GKLHIP_OK;
+}
+
+int gklhip_pdhmm_done(gklhip_pdhmm_ctx* c) {
+  if (!c) return GKLHIP_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->sums, &c->misc, &c->carry}) b->release();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return GKLHIP_OK;
+}
+
+float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* c) { return c ? c->last_ms : 0.f; }
+
+int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, double* out_host) {
+  if (!c) return pd_fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
+  if (!b) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batch is NULL");
+  // IntelPDHMM.java:163-173
+  if (b->batch <= 0) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batchSize must be greater than 0");
+  if (b->max_hap_len <= 0 || b->max_read_len <= 0)
+    return pd_fail(GKLHIP_ERR_INVALID_ARG, "maxHapLength / maxReadLength must be greater than 0");
+  if (!b->hap_bases || !b->hap_pdbases || !b->read_bases || !b->read_qual || !b->read_ins_qual || !b->read_del_qual ||
+      !b->gcp || !b->hap_lengths || !b->read_lengths || !out_host)
+    return pd_fail(GKLHIP_ERR_INVALID_ARG, "Input arrays aren't valid.");
+  for (int i = 0; i < b->batch; i++) {
+    if (b->hap_lengths[i] < 1 || b->hap_lengths[i] > b->max_hap_len)
+      return pd_fail(GKLHIP_ERR_INVALID_ARG, "hap_lengths[%d] = %lld outside 1..%d", i, (long long)b->hap_lengths[i], b->max_hap_len);
+    if (b->read_lengths[i] < 1 || b->read_lengths[i] > b->max_read_len)
+      return pd_fail(GKLHIP_ERR_INVALID_ARG, "read_lengths[%d] = %lld outside 1..%d", i, (long long)b->read_lengths[i], b->max_read_len);
+  }
+  std::lock_guard<std::mutex> lock(c->mu);
+  PD_HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t n = (size_t)b->batch;
+  const size_t hap_bytes = n * (size_t)b->max_hap_len, read_bytes = n * (size_t)b->max_read_len;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t o_hb = 0, o_hp = up(hap_bytes), o_rb = o_hp + up(hap_bytes), o_rq = o_rb + up(read_bytes),
+               o_ri = o_rq + up(read_bytes), o_rd = o_ri + up(read_bytes), o_gc = o_rd + up(read_bytes),
+               o_hl = o_gc + up(read_bytes), o_rl = o_hl + up(n * 8), total = o_rl + up(n * 8);
+  int rc;
+  if ((rc = c->inputs.reserve(total))) return rc;
+  unsigned char* d = c->inputs.as<unsigned char>();
+  PD_HIP_TRY(hipMemcpyAsync(d + o_hb, b->hap_bases, hap_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_hp, b->hap_pdbases, hap_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_rb, b->read_bases, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_rq, b->read_qual, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_ri, b->read_ins_qual, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_rd, b->read_del_qual, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_gc, b->gcp, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_hl, b->hap_lengths, n * 8, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_rl, b->read_lengths, n * 8, hipMemcpyHostToDevice, s));
+
+  const int entry_stride = (b->max_hap_len + 2 * kLanes + 63) / 64 * 64;
+  const int carry_len = entry_stride;
+  const int n_blocks = (int)std::min<size_t>(n, 256 * 8);
+  if ((rc = c->entries.reserve(n * (size_t)entry_stride * 4))) return rc;
+  if ((rc = c->sums.reserve(n * 8))) return rc;
+  if ((rc = c->misc.reserve(64))) return rc;
+  if ((rc = c->carry.reserve((size_t)n_blocks * 2 * (6 * (size_t)carry_len + 64) * 8))) return rc;
+  PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
+
+  const PdTables& t = pd_tables();
+  PdArgs a;
+  a.hap_bases = reinterpret_cast<const int8_t*>(d + o_hb);
+  a.hap_pdbases = reinterpret_cast<const int8_t*>(d + o_hp);
+  a.read_bases = reinterpret_cast<const int8_t*>(d + o_rb);
+  a.read_qual = reinterpret_cast<const int8_t*>(d + o_rq);
+  a.read_ins = reinterpret_cast<const int8_t*>(d + o_ri);
+  a.read_del = reinterpret_cast<const int8_t*>(d + o_rd);
+  a.gcp = reinterpret_cast<const int8_t*>(d + o_gc);
+  a.hap_len = reinterpret_cast<const int64_t*>(d + o_hl);
+  a.read_len = reinterpret_cast<const int64_t*>(d + o_rl);
+  a.batch = b->batch; a.max_hap = b->max_hap_len; a.max_read = b->max_read_len;
+  a.q2err = c->tables.as<double>();
+  a.mm_prob = c->tables.as<double>() + t.q2err.size();
+  a.entries = c->entries.as<uint32_t>();
+  a.entry_stride = entry_stride;
+  a.sums = c->sums.as<double>();
+  a.status = c->misc.as<int32_t>();
+  a.next = c->misc.as<int32_t>() + 1;
+  a.carry = c->carry.as<double>();
+  a.carry_len = carry_len;
+
+  hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, a);
+  PD_HIP_TRY(hipEventRecord(c->ev0, s));
+  hipLaunchKernelGGL(pdhmm_fwd_kernel, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
+  PD_HIP_TRY(hipEventRecord(c->ev1, s));
+  PD_HIP_TRY(hipGetLastError());
+  std::vector<double> sums(n);
+  int32_t status[2] = {0, 0};
+  PD_HIP_TRY(hipMemcpyAsync(sums.data(), c->sums.p, n * 8, hipMemcpyDeviceToHost, s));
+  PD_HIP_TRY(hipMemcpyAsync(status, c->misc.p, 8, hipMemcpyDeviceToHost, s));
+  PD_HIP_TRY(hipStreamSynchronize(s));
+  PD_HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  if (status[0] != 0)  // PDHMM_INPUT_DATA_ERROR (pdhmm-serial.cc:183-199): negative ins / del / gcp quality
+    return pd_fail(GKLHIP_ERR_INVALID_ARG, "Error while calculating pdhmm. Input arrays aren't valid.");
+  for (size_t i = 0; i < n; i++) out_host[i] = std::log10(sums[i]) - t.initial_condition_log10;  // pdhmm.h:846
+  return GKLHIP_OK;
+}
+
+}  // extern "C"

@@ -224,3 +224,106 @@ class PairHmmContext:
         if st != OK:
             _raise(self.lib, st)
         return r32, r64, u
+
+
+# ---------------------------------------------------------------- PDHMM (include/gkl_hip_pdhmm.h)
+PDHMM_LIB_PATH = os.path.join(LIB_DIR, "libgklhip_pdhmm.so")
+
+
+class CPdhmmBatch(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("max_hap_len", C.c_int32), ("max_read_len", C.c_int32),
+                ("hap_bases", C.c_void_p), ("hap_pdbases", C.c_void_p), ("read_bases", C.c_void_p),
+                ("read_qual", C.c_void_p), ("read_ins_qual", C.c_void_p), ("read_del_qual", C.c_void_p),
+                ("gcp", C.c_void_p), ("hap_lengths", C.c_void_p), ("read_lengths", C.c_void_p)]
+
+
+_pd_lib = None
+
+
+def load_pdhmm_library(path: Optional[str] = None):
+    global _pd_lib
+    if _pd_lib is not None and path is None:
+        return _pd_lib
+    p = path or PDHMM_LIB_PATH
+    try:
+        import torch  # noqa: F401  (HIP runtime load order, see load_library)
+    except ImportError:
+        pass
+    if not os.path.exists(p):
+        raise RuntimeException(f"{p} is not built (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    lib.gklhip_pdhmm_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.gklhip_pdhmm_init.restype = C.c_int
+    lib.gklhip_pdhmm_compute.argtypes = [C.c_void_p, C.POINTER(CPdhmmBatch), C.c_void_p]
+    lib.gklhip_pdhmm_compute.restype = C.c_int
+    lib.gklhip_pdhmm_done.argtypes = [C.c_void_p]
+    lib.gklhip_pdhmm_done.restype = C.c_int
+    lib.gklhip_pdhmm_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.gklhip_pdhmm_last_kernel_ms.restype = C.c_float
+    lib.gklhip_pdhmm_get_table.argtypes = [C.c_int, C.c_void_p, C.c_int64]
+    lib.gklhip_pdhmm_get_table.restype = C.c_int64
+    lib.gklhip_pdhmm_last_error.restype = C.c_char_p
+    if path is None:
+        _pd_lib = lib
+    return lib
+
+
+def pdhmm_host_table(which: int) -> np.ndarray:
+    lib = load_pdhmm_library()
+    n = lib.gklhip_pdhmm_get_table(which, None, 0)
+    a = np.empty(n, np.float64)
+    lib.gklhip_pdhmm_get_table(which, a.ctypes.data, n)
+    return a
+
+
+class PdhmmContext:
+    """One gklhip_pdhmm context (= IntelPDHMM.initNative)."""
+
+    def __init__(self, device: int = -1):
+        self.lib = load_pdhmm_library()
+        h = C.c_void_p()
+        st = self.lib.gklhip_pdhmm_init(device, C.byref(h))
+        if st != OK:
+            self._raise(st)
+        self.handle = h
+
+    def _raise(self, status):
+        msg = (self.lib.gklhip_pdhmm_last_error() or b"").decode()
+        if status == ERR_INVALID_ARG:
+            raise IllegalArgumentException(msg)
+        if status == ERR_OOM:
+            raise OutOfMemoryError(msg)
+        raise RuntimeException(msg)
+
+    def compute(self, b) -> np.ndarray:
+        keep = [np.ascontiguousarray(a, np.int8) for a in (b.hap_bases, b.hap_pdbases, b.read_bases, b.read_qual,
+                                                           b.read_ins_qual, b.read_del_qual, b.gcp)]
+        hl = np.ascontiguousarray(b.hap_lengths, np.int64)
+        rl = np.ascontiguousarray(b.read_lengths, np.int64)
+        cb = CPdhmmBatch(b.batch, b.max_hap_len, b.max_read_len, *[a.ctypes.data for a in keep],
+                         hl.ctypes.data, rl.ctypes.data)
+        out = np.empty(max(b.batch, 0), np.float64)
+        st = self.lib.gklhip_pdhmm_compute(self.handle, C.byref(cb), out.ctypes.data)
+        if st != OK:
+            self._raise(st)
+        return out
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.gklhip_pdhmm_last_kernel_ms(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gklhip_pdhmm_done(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

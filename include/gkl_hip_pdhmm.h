@@ -1,0 +1,57 @@
+/*
+ * gkl_hip_pdhmm.h -- C ABI of the MI355X-native PDHMM (partially determined haplotype PairHMM),
+ * the "next" row f1 of SURVEY.md section 8 / BASELINE.json config 5.
+ *
+ * Replaces, in the reference (paths under /root/reference/src/main/native/pdhmm):
+ *   gklhip_pdhmm_init     initializeNative: pdhmm-implementation.h:303-322 (ProbabilityCache tables
+ *                         of pdhmm-common.h:139-192, engine choice) -- here: tables + device context
+ *   gklhip_pdhmm_compute  computePDHMM: pdhmm-implementation.h:361-396 -> computePDHMM_<engine>
+ *                         (pdhmm.h:1133-1290), on the padded 1:1 batch IntelPDHMM.computePDHMM passes
+ *                         (src/main/java/com/intel/gkl/pdhmm/IntelPDHMM.java:147-186)
+ *   gklhip_pdhmm_done     doneNative
+ * Arithmetic: the reference's vector (AVX2) kernels for every pair; see gkl_amd/csrc/pdhmm_kernel.h.
+ */
+#ifndef GKL_HIP_PDHMM_H
+#define GKL_HIP_PDHMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gklhip_pdhmm_ctx gklhip_pdhmm_ctx;
+
+/* status codes are gklhip_status of gkl_hip_pairhmm.h (0 ok, 1 invalid argument, 2 no device,
+ * 3 out of memory, 4 HIP error, 5 unsupported) */
+
+typedef struct {
+  int32_t batch;             /* number of (read, haplotype) pairs */
+  int32_t max_hap_len;       /* row stride of the two haplotype arrays */
+  int32_t max_read_len;      /* row stride of the five read arrays */
+  const int8_t* hap_bases;   /* [batch][max_hap_len] */
+  const int8_t* hap_pdbases; /* [batch][max_hap_len] PD flag bytes: SNP 1, DEL_START 2, DEL_END 4, A 8, C 16, G 32, T 64 */
+  const int8_t* read_bases;  /* [batch][max_read_len] */
+  const int8_t* read_qual;
+  const int8_t* read_ins_qual;
+  const int8_t* read_del_qual;
+  const int8_t* gcp;
+  const int64_t* hap_lengths;  /* [batch], 1..max_hap_len */
+  const int64_t* read_lengths; /* [batch], 1..max_read_len */
+} gklhip_pdhmm_batch;
+
+int gklhip_pdhmm_init(int device /* -1 = current */, gklhip_pdhmm_ctx** out_ctx);
+/* Host buffers in, out_host[batch] = log10 likelihoods. Negative ins/del/gcp quals ->
+ * GKLHIP_ERR_INVALID_ARG (PDHMM_INPUT_DATA_ERROR in the reference). */
+int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_batch* batch, double* out_host);
+/* HIP-event time of the forward kernel of the last call, milliseconds. */
+float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* ctx);
+int gklhip_pdhmm_done(gklhip_pdhmm_ctx* ctx);
+/* host-built tables as uploaded: 0 qualToErrorProb[255], 1 matchToMatchProb[32640] */
+int64_t gklhip_pdhmm_get_table(int which, double* dst, int64_t cap);
+const char* gklhip_pdhmm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKL_HIP_PDHMM_H */

@@ -40,3 +40,20 @@ def batch_from_vector(v):
     return FlatBatch(v["n_reads"], v["n_haps"], np.array(v["read_off"], np.int64),
                      np.array(v["hap_off"], np.int64), h(v["read_bases"]), h(v["read_quals"]),
                      h(v["ins_gop"]), h(v["del_gop"]), h(v["gcp"]), h(v["hap_bases"]))
+
+
+def load_pdhmm_file(name):
+    """A reference PDHMM fixture (tab separated: hap, [pd bytes], read, 4 x fastq quals, expected;
+    parsed like IntelPDHMMUnitTest.java:161-257: quals are fastq-33)."""
+    from gkl_amd.pdhmm_batch import PdhmmBatch
+    pairs, exp = [], []
+    with open(os.path.join(GOLDEN, name), encoding="utf-8") as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            c = line.rstrip("\n").split("\t")
+            pd = np.array([int(x) for x in c[1][1:-1].split(",")], dtype=np.int8)
+            q = lambda s: (np.frombuffer(s.encode("utf-8"), dtype=np.uint8).astype(np.int16) - 33).astype(np.int8)  # noqa: E731
+            pairs.append((c[0].encode(), pd, c[2].encode(), q(c[3]), q(c[4]), q(c[5]), q(c[6])))
+            exp.append(float(c[7]))
+    return PdhmmBatch.from_pairs(pairs), np.array(exp)

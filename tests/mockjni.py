@@ -42,3 +42,42 @@ def run(batch, use_double=False, max_threads=1, flags=0, out_len=None, lib_path=
                          *[a.ctypes.data_as(C.c_void_p) for a in arrs], out.ctypes.data_as(C.c_void_p),
                          int(n), int(flags), ec, em, counters)
     return rc, out[:n], ec.value.decode(), em.value.decode(), (counters[0], counters[1])
+
+
+# ---------------------------------------------------------------- PDHMM
+PD_JNI_LIB = os.path.join(ROOT, "gkl_amd", "lib", "libgkl_pdhmm.so")
+PD_DROP_PDBASES_FIELD, PD_SKIP_INIT, PD_HOLDERS = 1, 2, 4
+
+
+def run_pdhmm(b, flags=0, max_memory_mb=512, holders=None):
+    """Drive IntelPDHMM's natives through the mock JNIEnv.
+
+    b: PdhmmBatch (padded 1:1) -> computePDHMMNative.  holders=(reads_batch, haps_batch): two PdhmmBatch-like
+    objects giving distinct reads / haplotypes -> computeLikelihoodsNative over their cross product.
+    Returns (rc, out, exception_class, exception_message)."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    build()
+    lib = C.CDLL(SO)
+    ec, em = C.create_string_buffer(256), C.create_string_buffer(512)
+    if holders is None:
+        n_a, n_b, out_len = b.batch, 0, b.batch
+        hap_src, read_src = b, b
+    else:
+        read_src, hap_src = holders
+        n_a, n_b, out_len = read_src.batch, hap_src.batch, read_src.batch * hap_src.batch
+        flags |= PD_HOLDERS
+    out = np.zeros(max(out_len, 1), np.float64)
+    arrs = [np.ascontiguousarray(a, np.int8) for a in (hap_src.hap_bases, hap_src.hap_pdbases, read_src.read_bases,
+                                                       read_src.read_qual, read_src.read_ins_qual,
+                                                       read_src.read_del_qual, read_src.gcp)]
+    hl = np.ascontiguousarray(hap_src.hap_lengths, np.int64)
+    rl = np.ascontiguousarray(read_src.read_lengths, np.int64)
+    lib.mockjni_run_pdhmm.restype = C.c_int
+    rc = lib.mockjni_run_pdhmm(PD_JNI_LIB.encode(), int(n_a), int(n_b), int(hap_src.max_hap_len),
+                               int(read_src.max_read_len), *[a.ctypes.data_as(C.c_void_p) for a in arrs],
+                               hl.ctypes.data_as(C.c_void_p), rl.ctypes.data_as(C.c_void_p),
+                               out.ctypes.data_as(C.c_void_p), int(out_len), int(flags), int(max_memory_mb), ec, em)
+    return rc, out[:out_len], ec.value.decode(), em.value.decode()

@@ -10,6 +10,7 @@
 // test also pins the exact set of JNI functions the shim may call.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,11 +25,12 @@
 namespace {
 
 struct Obj {
-  enum Kind { CLASS, BYTES, DOUBLES, OBJARRAY, HOLDER } kind;
+  enum Kind { CLASS, BYTES, DOUBLES, LONGS, OBJARRAY, HOLDER } kind;
   std::string name;                      // CLASS
   std::set<std::string> class_fields;    // CLASS
   std::vector<int8_t> bytes;             // BYTES
   std::vector<double> doubles;           // DOUBLES
+  std::vector<int64_t> longs;            // LONGS
   std::vector<Obj*> elems;               // OBJARRAY
   std::map<std::string, Obj*> fields;    // HOLDER (value may be nullptr)
 };
@@ -83,7 +85,8 @@ jobject m_GetObjectField(JNIEnv* e, jobject o, jfieldID f) {
 }
 jsize m_GetArrayLength(JNIEnv*, jarray a) {
   Obj* o = O(a);
-  return (jsize)(o->kind == Obj::BYTES ? o->bytes.size() : o->kind == Obj::DOUBLES ? o->doubles.size() : o->elems.size());
+  return (jsize)(o->kind == Obj::BYTES ? o->bytes.size() : o->kind == Obj::DOUBLES ? o->doubles.size()
+                 : o->kind == Obj::LONGS ? o->longs.size() : o->elems.size());
 }
 jobject m_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) {
   Obj* o = O(a);
@@ -108,10 +111,45 @@ void m_SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, c
   memcpy(o->doubles.data() + start, buf, sizeof(double) * (size_t)len);
 }
 
+jdoubleArray m_NewDoubleArray(JNIEnv* e, jsize len) {
+  Obj* o = M(e)->make(Obj::DOUBLES);
+  o->doubles.assign((size_t)len, 0.0);
+  M(e)->refs_created++;
+  return reinterpret_cast<jdoubleArray>(o);
+}
+void m_GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize start, jsize len, jlong* buf) {
+  Obj* o = O(a);
+  if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->longs.size()) {
+    M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "long region");
+    return;
+  }
+  memcpy(buf, o->longs.data() + start, sizeof(int64_t) * (size_t)len);
+}
+
+void install_table(Mock& m);
+
 Obj* bytes_obj(Mock& m, const uint8_t* p, int64_t n) {
   Obj* o = m.make(Obj::BYTES);
   o->bytes.assign(reinterpret_cast<const int8_t*>(p), reinterpret_cast<const int8_t*>(p) + n);
   return o;
+}
+
+void install_table(Mock& m) {
+  for (auto& s : m.table.slot) s = reinterpret_cast<void*>(&unimplemented);
+  m.table.slot[kJniSlotFindClass] = (void*)&m_FindClass;
+  m.table.slot[kJniSlotThrowNew] = (void*)&m_ThrowNew;
+  m.table.slot[kJniSlotExceptionClear] = (void*)&m_ExceptionClear;
+  m.table.slot[kJniSlotExceptionCheck] = (void*)&m_ExceptionCheck;
+  m.table.slot[kJniSlotDeleteLocalRef] = (void*)&m_DeleteLocalRef;
+  m.table.slot[kJniSlotGetFieldID] = (void*)&m_GetFieldID;
+  m.table.slot[kJniSlotGetObjectField] = (void*)&m_GetObjectField;
+  m.table.slot[kJniSlotGetArrayLength] = (void*)&m_GetArrayLength;
+  m.table.slot[kJniSlotGetObjectArrayElement] = (void*)&m_GetObjectArrayElement;
+  m.table.slot[kJniSlotGetByteArrayRegion] = (void*)&m_GetByteArrayRegion;
+  m.table.slot[kJniSlotSetDoubleArrayRegion] = (void*)&m_SetDoubleArrayRegion;
+  m.table.slot[kJniSlotNewDoubleArray] = (void*)&m_NewDoubleArray;
+  m.table.slot[kJniSlotGetLongArrayRegion] = (void*)&m_GetLongArrayRegion;
+  m.env.functions = &m.table;
 }
 
 typedef void (*init_fn)(JNIEnv*, jclass, jclass, jclass, jboolean, jint);
@@ -146,19 +184,7 @@ int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_rea
   if (!f_init || !f_compute || !f_done) { snprintf(exc_msg, 512, "missing JNI symbol"); return -1; }
 
   Mock m;
-  for (auto& s : m.table.slot) s = reinterpret_cast<void*>(&unimplemented);
-  m.table.slot[kJniSlotFindClass] = (void*)&m_FindClass;
-  m.table.slot[kJniSlotThrowNew] = (void*)&m_ThrowNew;
-  m.table.slot[kJniSlotExceptionClear] = (void*)&m_ExceptionClear;
-  m.table.slot[kJniSlotExceptionCheck] = (void*)&m_ExceptionCheck;
-  m.table.slot[kJniSlotDeleteLocalRef] = (void*)&m_DeleteLocalRef;
-  m.table.slot[kJniSlotGetFieldID] = (void*)&m_GetFieldID;
-  m.table.slot[kJniSlotGetObjectField] = (void*)&m_GetObjectField;
-  m.table.slot[kJniSlotGetArrayLength] = (void*)&m_GetArrayLength;
-  m.table.slot[kJniSlotGetObjectArrayElement] = (void*)&m_GetObjectArrayElement;
-  m.table.slot[kJniSlotGetByteArrayRegion] = (void*)&m_GetByteArrayRegion;
-  m.table.slot[kJniSlotSetDoubleArrayRegion] = (void*)&m_SetDoubleArrayRegion;
-  m.env.functions = &m.table;
+  install_table(m);
   JNIEnv* env = &m.env;
 
   Obj* read_cls = m.make(Obj::CLASS);
@@ -207,6 +233,88 @@ int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_rea
     snprintf(exc_msg, 512, "%s", m.exc_msg.c_str());
   }
   if (counters) { counters[0] = m.refs_created; counters[1] = m.refs_deleted; }
+  return rc_;
+}
+
+
+// ---- PDHMM: IntelPDHMM natives (include/gkl_pdhmm_jni.h) ----
+typedef void (*pd_init_fn)(JNIEnv*, jclass, jclass, jclass, jint, jint, jint, jint);
+typedef jdoubleArray (*pd_flat_fn)(JNIEnv*, jobject, jbyteArray, jbyteArray, jbyteArray, jbyteArray, jbyteArray, jbyteArray,
+                                   jbyteArray, jlongArray, jlongArray, jint, jint, jint);
+typedef void (*pd_done_fn)(JNIEnv*, jclass);
+
+enum { MOCKPD_DROP_PDBASES_FIELD = 1, MOCKPD_SKIP_INIT = 2, MOCKPD_HOLDERS = 4 };
+
+// Padded 1:1 batch (IntelPDHMM.computePDHMM layout). With MOCKPD_HOLDERS the same data is instead
+// presented as reads x haplotypes holder arrays (n_reads = batch of distinct reads, n_haps haplotypes,
+// flat arrays then hold [n_reads][max_read] and [n_haps][max_hap]) and computeLikelihoodsNative is driven.
+int mockjni_run_pdhmm(const char* lib_path, int n_a, int n_b, int max_hap, int max_read, const uint8_t* hb,
+                      const uint8_t* hp, const uint8_t* rb, const uint8_t* rq, const uint8_t* ri, const uint8_t* rd,
+                      const uint8_t* rc, const int64_t* hap_len, const int64_t* read_len, double* out, int out_len,
+                      int flags, int max_memory_mb, char* exc_class, char* exc_msg) {
+  exc_class[0] = exc_msg[0] = 0;
+  void* h = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { snprintf(exc_msg, 512, "dlopen: %s", dlerror()); return -1; }
+  pd_init_fn f_init = (pd_init_fn)dlsym(h, "Java_com_intel_gkl_pdhmm_IntelPDHMM_initNative");
+  pd_flat_fn f_flat = (pd_flat_fn)dlsym(h, "Java_com_intel_gkl_pdhmm_IntelPDHMM_computePDHMMNative");
+  compute_fn f_cl = (compute_fn)dlsym(h, "Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNative");
+  pd_done_fn f_done = (pd_done_fn)dlsym(h, "Java_com_intel_gkl_pdhmm_IntelPDHMM_doneNative");
+  if (!f_init || !f_flat || !f_cl || !f_done) { snprintf(exc_msg, 512, "missing JNI symbol"); return -1; }
+  Mock m;
+  install_table(m);
+  JNIEnv* env = &m.env;
+  Obj* read_cls = m.make(Obj::CLASS);
+  read_cls->class_fields = {"readBases", "readQuals", "insertionGOP", "deletionGOP", "overallGCP"};
+  Obj* hap_cls = m.make(Obj::CLASS);
+  hap_cls->class_fields = {"haplotypeBases", "haplotypePDBases"};
+  if (flags & MOCKPD_DROP_PDBASES_FIELD) hap_cls->class_fields.erase("haplotypePDBases");
+  int rc_ = 0;
+  if (!(flags & MOCKPD_SKIP_INIT)) {
+    f_init(env, nullptr, reinterpret_cast<jclass>(read_cls), reinterpret_cast<jclass>(hap_cls), 0, 1, 0, max_memory_mb);
+    if (m.pending) rc_ = 1;
+  }
+  if (rc_ == 0 && (flags & MOCKPD_HOLDERS)) {
+    const int n_reads = n_a, n_haps = n_b;
+    Obj* reads = m.make(Obj::OBJARRAY);
+    for (int r = 0; r < n_reads; r++) {
+      Obj* holder = m.make(Obj::HOLDER);
+      const int64_t n = read_len[r];
+      holder->fields["readBases"] = bytes_obj(m, rb + (int64_t)r * max_read, n);
+      holder->fields["readQuals"] = bytes_obj(m, rq + (int64_t)r * max_read, n);
+      holder->fields["insertionGOP"] = bytes_obj(m, ri + (int64_t)r * max_read, n);
+      holder->fields["deletionGOP"] = bytes_obj(m, rd + (int64_t)r * max_read, n);
+      holder->fields["overallGCP"] = bytes_obj(m, rc + (int64_t)r * max_read, n);
+      reads->elems.push_back(holder);
+    }
+    Obj* haps = m.make(Obj::OBJARRAY);
+    for (int k = 0; k < n_haps; k++) {
+      Obj* holder = m.make(Obj::HOLDER);
+      holder->fields["haplotypeBases"] = bytes_obj(m, hb + (int64_t)k * max_hap, hap_len[k]);
+      holder->fields["haplotypePDBases"] = bytes_obj(m, hp + (int64_t)k * max_hap, hap_len[k]);
+      haps->elems.push_back(holder);
+    }
+    Obj* lik = m.make(Obj::DOUBLES);
+    lik->doubles.assign((size_t)out_len, -12345.0);
+    f_cl(env, nullptr, reinterpret_cast<jobjectArray>(reads), reinterpret_cast<jobjectArray>(haps),
+         reinterpret_cast<jdoubleArray>(lik));
+    if (m.pending) rc_ = 2;
+    memcpy(out, lik->doubles.data(), sizeof(double) * (size_t)out_len);
+  } else if (rc_ == 0) {
+    const int batch = n_a;
+    Obj* arrs[7];
+    const uint8_t* src[7] = {hb, hp, rb, rq, ri, rd, rc};
+    for (int i = 0; i < 7; i++) arrs[i] = bytes_obj(m, src[i], (int64_t)batch * (i < 2 ? max_hap : max_read));
+    Obj* hl = m.make(Obj::LONGS); hl->longs.assign(hap_len, hap_len + batch);
+    Obj* rl = m.make(Obj::LONGS); rl->longs.assign(read_len, read_len + batch);
+    jdoubleArray res = f_flat(env, nullptr, (jbyteArray)arrs[0], (jbyteArray)arrs[1], (jbyteArray)arrs[2], (jbyteArray)arrs[3],
+                              (jbyteArray)arrs[4], (jbyteArray)arrs[5], (jbyteArray)arrs[6], (jlongArray)hl, (jlongArray)rl,
+                              batch, max_hap, max_read);
+    if (m.pending) rc_ = 2;
+    else if (!res) rc_ = 3;
+    else memcpy(out, O(res)->doubles.data(), sizeof(double) * (size_t)std::min<size_t>(out_len, O(res)->doubles.size()));
+  }
+  f_done(env, nullptr);
+  if (m.pending) { snprintf(exc_class, 256, "%s", m.exc_class.c_str()); snprintf(exc_msg, 512, "%s", m.exc_msg.c_str()); }
   return rc_;
 }
 

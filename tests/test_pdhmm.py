@@ -1,0 +1,237 @@
+"""PDHMM (BASELINE config 5): oracle pins on CPU, HIP parity on the GPU.
+
+Tolerances: the reference's own bar is abs 1e-4 against the stored expectations
+(IntelPDHMMUnitTest.java:33); the HIP path is additionally BIT-EXACT against the oracle's "vector"
+arithmetic, which is bit-identical to GKL's AVX2 kernels."""
+import numpy as np
+import pytest
+
+from gkl_amd.pdhmm_batch import PdhmmBatch
+from tests.golden_io import load_pdhmm_file
+
+FILES = ["pdhmm_syn_990_1_2.txt", "pdhmm_syn_199_68_51.txt", "pdhmm_syn_1412_129_223.head300.txt"]
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pd_oracle():
+    from oracle.pdhmm import PdhmmOracle
+    return PdhmmOracle()
+
+
+@pytest.fixture(scope="module")
+def pd_reference():
+    from oracle.pdhmm import PdhmmReference
+    if not PdhmmReference.available():
+        pytest.skip("oracle/_ref/libgkl_ref_pdhmm.so not built")
+    return PdhmmReference()
+
+
+def random_pd_batch(rng, n, read_len=(1, 60), hap_len=(1, 80), flag_rate=0.15, lower=True, with_n=True):
+    pairs = []
+    alpha = np.frombuffer(b"ACGT" + (b"acgt" if lower else b"") + (b"N" if with_n else b""), dtype=np.int8)
+    for _ in range(n):
+        H = int(rng.randint(hap_len[0], hap_len[1] + 1))
+        R = int(rng.randint(read_len[0], read_len[1] + 1))
+        hap = np.frombuffer(b"ACGT", dtype=np.int8)[rng.randint(0, 4, H)].copy()
+        if with_n and H > 3 and rng.random_sample() < 0.3:
+            hap[rng.randint(0, H)] = ord("N")
+        pd = np.zeros(H, np.int8)
+        for j in range(H):
+            u = rng.random_sample()
+            if u < flag_rate * 0.4:
+                pd[j] = 1 | int(rng.randint(1, 16)) << 3          # SNP with a random allele set
+            elif u < flag_rate * 0.6:
+                pd[j] = 2                                          # DEL_START
+            elif u < flag_rate * 0.8:
+                pd[j] = 4                                          # DEL_END
+            elif u < flag_rate:
+                pd[j] = int(rng.randint(0, 128))                  # arbitrary combination
+        if R <= H and rng.random_sample() < 0.7:
+            off = int(rng.randint(0, H - R + 1))
+            read = hap[off:off + R].copy()
+            flip = rng.random_sample(R) < 0.05
+            read[flip] = alpha[rng.randint(0, alpha.size, int(flip.sum()))]
+        else:
+            read = alpha[rng.randint(0, alpha.size, R)]
+        q = lambda lo, hi: rng.randint(lo, hi + 1, R).astype(np.int8)  # noqa: E731
+        pairs.append((hap, pd, read, q(2, 60), q(5, 70), q(5, 70), q(3, 40)))
+    return PdhmmBatch.from_pairs(pairs)
+
+
+# ------------------------------------------------------------------ oracle pins (CPU)
+def test_pdhmm_oracle_matches_expected_files(pd_oracle):
+    for f in FILES:
+        b, exp = load_pdhmm_file(f)
+        for sem in (0, 1):
+            st, out = pd_oracle.compute(b, semantics=sem)
+            assert st == 0 and np.max(np.abs(out - exp)) <= TOL, (f, sem)
+
+
+def test_pdhmm_oracle_bit_identical_to_reference_kernels(pd_oracle, pd_reference):
+    assert all(np.array_equal(pd_oracle.table(w), pd_reference.table(w)) for w in (0, 1))
+    rng = np.random.RandomState(3)
+    batches = [load_pdhmm_file(f)[0] for f in FILES[:2]] + [random_pd_batch(rng, 64, read_len=(1, 90), hap_len=(1, 120))]
+    for b in batches:
+        _, vec = pd_oracle.compute(b, semantics=0)
+        _, ser = pd_oracle.compute(b, semantics=1)
+        st, ref = pd_reference.compute(b, engine=1)  # AVX2: vector kernel for full groups of 4, scalar for the tail
+        assert st == 0
+        nv = (b.batch // pd_reference.simd_width(1)) * pd_reference.simd_width(1)
+        assert ref[:nv].tobytes() == vec[:nv].tobytes()
+        assert ref[nv:].tobytes() == ser[nv:].tobytes()
+        st, ref0 = pd_reference.compute(b, engine=0)  # scalar engine = serial semantics everywhere
+        assert st == 0 and ref0.tobytes() == ser.tobytes()
+        if pd_reference.has_avx512():
+            st, ref2 = pd_reference.compute(b, engine=2)
+            nv2 = (b.batch // pd_reference.simd_width(2)) * pd_reference.simd_width(2)
+            assert st == 0 and np.max(np.abs(ref2[:nv2] - vec[:nv2])) < 1e-9  # gcc contracts FMAs in that TU
+
+
+def test_pdhmm_oracle_negative_quality_is_input_error(pd_oracle):
+    b = random_pd_batch(np.random.RandomState(1), 4)
+    b.read_ins_qual[0] = -3
+    st, _ = pd_oracle.compute(b)
+    assert st == 2  # PDHMM_INPUT_DATA_ERROR
+
+
+def test_pdhmm_library_tables_match_oracle(pd_oracle):
+    from gkl_amd import native
+    for w in (0, 1):
+        assert native.pdhmm_host_table(w).tobytes() == pd_oracle.table(w).tobytes()
+
+
+def test_pdhmm_no_gpu_fails_loudly():
+    import torch
+    from gkl_amd import native
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.RuntimeException):
+        native.PdhmmContext()
+
+
+# ------------------------------------------------------------------ HIP parity (GPU)
+@pytest.fixture(scope="module")
+def pd_ctx():
+    from gkl_amd import native
+    with native.PdhmmContext() as c:
+        yield c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", FILES)
+def test_pdhmm_gpu_fixture_files(pd_ctx, pd_oracle, fname):
+    b, exp = load_pdhmm_file(fname)
+    out = pd_ctx.compute(b)
+    assert np.max(np.abs(out - exp)) <= TOL                      # the reference's own bar
+    _, vec = pd_oracle.compute(b, semantics=0)
+    assert out.tobytes() == vec.tobytes()                         # and bit-exact vs GKL's AVX2 arithmetic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(flag_rate=0.5), dict(read_len=(200, 520), hap_len=(100, 400)),
+                                dict(read_len=(1, 8), hap_len=(1, 6), flag_rate=0.6),
+                                dict(read_len=(255, 257), hap_len=(60, 70))])
+def test_pdhmm_gpu_random_batches_bit_exact(pd_ctx, pd_oracle, kw):
+    rng = np.random.RandomState(77)
+    b = random_pd_batch(rng, 96, **kw)
+    out = pd_ctx.compute(b)
+    st, vec = pd_oracle.compute(b, semantics=0)
+    assert st == 0 and out.tobytes() == vec.tobytes()
+    # (the reference's scalar engine keeps the deletion state across rows and can differ from its own
+    #  vector kernels by 0.2 on such random flag patterns; parity is defined against the vector kernels)
+
+
+@pytest.mark.gpu
+def test_pdhmm_gpu_argument_errors(pd_ctx):
+    from gkl_amd import native
+    b = random_pd_batch(np.random.RandomState(5), 8)
+    bad = random_pd_batch(np.random.RandomState(5), 8)
+    bad.gcp[3] = -1
+    with pytest.raises(native.IllegalArgumentException):
+        pd_ctx.compute(bad)
+    bad2 = random_pd_batch(np.random.RandomState(5), 8)
+    bad2.hap_lengths[2] = 0
+    with pytest.raises(native.IllegalArgumentException):
+        pd_ctx.compute(bad2)
+    assert np.isfinite(pd_ctx.compute(b)).all()  # the context survives errors
+
+
+# ------------------------------------------------------------------ JNI shim (mock JNIEnv) + plugin mirror
+def test_pdhmm_jni_exports_and_field_errors():
+    import ctypes as C
+    from tests import mockjni
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(mockjni.PD_JNI_LIB)
+    for s in ("initNative", "computeLikelihoodsNative", "computePDHMMNative", "doneNative"):
+        assert hasattr(lib, "Java_com_intel_gkl_pdhmm_IntelPDHMM_" + s)
+    b = random_pd_batch(np.random.RandomState(2), 4)
+    rc, _, cls, msg = mockjni.run_pdhmm(b, flags=mockjni.PD_DROP_PDBASES_FIELD)
+    assert rc == 1 and cls == "java/lang/IllegalArgumentException" and msg == "Unable to get field ID"
+    rc, _, cls, msg = mockjni.run_pdhmm(b, flags=mockjni.PD_SKIP_INIT)
+    assert rc == 2 and cls == "java/lang/RuntimeException"
+
+
+def test_pdhmm_mirror_argument_validation():
+    # IntelPDHMMUnitTest.java:109-159: null -> NPE, wrong sizes -> IAE, before any native call
+    from gkl_amd.errors import IllegalArgumentException, NullPointerException
+    from gkl_amd.pdhmm import IntelPDHMM
+    hmm = IntelPDHMM()
+    with pytest.raises(NullPointerException):
+        hmm.computeLikelihoods(None, [], np.zeros(0))
+    with pytest.raises(IllegalArgumentException):
+        hmm.computeLikelihoods([object()], [object()], np.zeros(3))
+    z = np.zeros(4, np.int8)
+    with pytest.raises(NullPointerException):
+        hmm.computePDHMM(None, z, z, z, z, z, z, np.ones(2), np.ones(2), 2, 2, 2)
+    with pytest.raises(IllegalArgumentException):
+        hmm.computePDHMM(z, z, z, z, z, z, np.zeros(3, np.int8), np.ones(2), np.ones(2), 2, 2, 2)
+
+
+@pytest.mark.gpu
+def test_pdhmm_jni_flat_and_holder_paths(pd_oracle):
+    from tests import mockjni
+    b, exp = load_pdhmm_file(FILES[1])
+    rc, out, cls, msg = mockjni.run_pdhmm(b)
+    assert rc == 0, (cls, msg)
+    _, vec = pd_oracle.compute(b, semantics=0)
+    assert out.tobytes() == vec.tobytes() and np.max(np.abs(out - exp)) <= TOL
+    # holders: 7 reads x 5 haplotypes, read-major cross product, tiny memory budget -> several batches
+    rng = np.random.RandomState(9)
+    src = random_pd_batch(rng, 7, read_len=(20, 60), hap_len=(30, 80))
+    haps = random_pd_batch(rng, 5, read_len=(1, 2), hap_len=(30, 80))
+    rc, out, cls, msg = mockjni.run_pdhmm(None, holders=(src, haps), max_memory_mb=1)
+    assert rc == 0, (cls, msg)
+    pairs = []
+    for r in range(7):
+        for h in range(5):
+            R, H = int(src.read_lengths[r]), int(haps.hap_lengths[h])
+            rr = lambda a: a.reshape(7, src.max_read_len)[r, :R]  # noqa: E731
+            hh = lambda a: a.reshape(5, haps.max_hap_len)[h, :H]  # noqa: E731
+            pairs.append((hh(haps.hap_bases), hh(haps.hap_pdbases), rr(src.read_bases), rr(src.read_qual),
+                          rr(src.read_ins_qual), rr(src.read_del_qual), rr(src.gcp)))
+    _, vec = pd_oracle.compute(PdhmmBatch.from_pairs(pairs), semantics=0)
+    assert out.tobytes() == vec.tobytes()
+    bad = random_pd_batch(np.random.RandomState(2), 4)
+    bad.read_del_qual[1] = -7
+    rc, _, cls, msg = mockjni.run_pdhmm(bad)
+    assert rc == 2 and cls == "java/lang/IllegalArgumentException" and "aren't valid" in msg
+
+
+@pytest.mark.gpu
+def test_pdhmm_mirror_like_reference_unit_test():
+    # pdhmmPerformanceTest (IntelPDHMMUnitTest.java:161-257): computePDHMM on each data file, abs tol 1e-4
+    from gkl_amd.pdhmm import IntelPDHMM
+    hmm = IntelPDHMM()
+    assert hmm.load(None)
+    hmm.initialize(None)
+    for f in FILES:
+        b, exp = load_pdhmm_file(f)
+        out = hmm.computePDHMM(b.hap_bases, b.hap_pdbases, b.read_bases, b.read_qual, b.read_ins_qual,
+                               b.read_del_qual, b.gcp, b.hap_lengths, b.read_lengths, b.batch, b.max_hap_len,
+                               b.max_read_len)
+        assert np.max(np.abs(out - exp)) <= TOL
+    hmm.done()
