@@ -318,4 +318,31 @@ int mockjni_run_pdhmm(const char* lib_path, int n_a, int n_b, int max_hap, int m
   return rc_;
 }
 
+// ---- libgkl_utils.so (include/gkl_utils_jni.h): six natives, no JNIEnv use at all ----
+// out[0..5] = getFlushToZero(before), isAvx, isAvx2, isAvx512, ompThreads, getFlushToZero(after set true)
+int mockjni_run_utils(const char* lib_path, int* out) {
+  void* h = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return -1;
+  typedef jboolean (*bfn)(JNIEnv*, jobject);
+  typedef void (*sfn)(JNIEnv*, jobject, jboolean);
+  typedef jint (*ifn)(JNIEnv*, jobject);
+  bfn get = (bfn)dlsym(h, "Java_com_intel_gkl_IntelGKLUtils_getFlushToZeroNative");
+  sfn set = (sfn)dlsym(h, "Java_com_intel_gkl_IntelGKLUtils_setFlushToZeroNative");
+  bfn avx = (bfn)dlsym(h, "Java_com_intel_gkl_IntelGKLUtils_isAvxSupportedNative");
+  bfn avx2 = (bfn)dlsym(h, "Java_com_intel_gkl_IntelGKLUtils_isAvx2SupportedNative");
+  bfn avx512 = (bfn)dlsym(h, "Java_com_intel_gkl_IntelGKLUtils_isAvx512SupportedNative");
+  ifn omp = (ifn)dlsym(h, "Java_com_intel_gkl_IntelGKLUtils_getAvailableOmpThreadsNative");
+  if (!get || !set || !avx || !avx2 || !avx512 || !omp) return -2;
+  Mock m;
+  install_table(m);
+  JNIEnv* env = &m.env;
+  out[0] = get(env, nullptr);
+  out[1] = avx(env, nullptr); out[2] = avx2(env, nullptr); out[3] = avx512(env, nullptr);
+  out[4] = omp(env, nullptr);
+  set(env, nullptr, JNI_TRUE);
+  out[5] = get(env, nullptr);
+  set(env, nullptr, out[0] ? JNI_TRUE : JNI_FALSE);
+  return 0;
+}
+
 }  // extern "C"

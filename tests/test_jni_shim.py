@@ -100,3 +100,17 @@ def test_jni_argument_errors():
     assert rc == 2 and cls == "java/lang/IllegalArgumentException"
     rc, out, cls, msg, _ = mockjni.run(b, out_len=b.n_pairs - 1)
     assert rc == 2 and cls == "java/lang/IllegalArgumentException" and np.all(out == -12345.0)
+
+
+def test_utils_library_gates_on_the_gpu():
+    """libgkl_utils.so replacement: IntelPairHmm.load() asks isAvxSupported() first
+    (IntelPairHmm.java:66-75); here that answers "is a gfx950 device usable"."""
+    import torch
+    mockjni.build()
+    lib = C.CDLL(mockjni.SO)
+    out = (C.c_int * 6)()
+    path = os.path.join(ROOT, "gkl_amd", "lib", "libgkl_utils.so")
+    assert lib.mockjni_run_utils(path.encode(), out) == 0
+    have_gpu = torch.cuda.is_available()
+    assert bool(out[1]) == have_gpu and bool(out[2]) == have_gpu and out[3] == 0
+    assert out[4] >= 1 and out[5] == 1  # FTZ can be switched on, like utils.cc:44-55
