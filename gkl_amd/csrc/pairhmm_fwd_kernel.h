@@ -101,7 +101,9 @@ struct FwdArgs {
 // GKL_DPP_NOP=1 writes the DPP ops as inline asm that always carries an `s_nop 1` (in
 // tools/ubench_mix.hip a DPP op straight behind VALU work costs ~11 extra cycles, behind an
 // s_nop none).  In the real kernels it measured neutral (single chunk) to -4 % (dual chunk),
-// so the compiler-scheduled builtin stays the default.
+// so the compiler-scheduled builtin stays the default.  (Also measured neutral, +-1.5 %: issuing
+// step u+1's entry shift and LDS prior reads ahead of step u's arithmetic -- LDS latency is
+// already hidden by the other waves; and the LDS-crossbar ds_bpermute instead of DPP.)
 #ifndef GKL_DPP_NOP
 #define GKL_DPP_NOP 0
 #endif
