@@ -85,23 +85,33 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GKL_BENCH_SAME_DEVICE=1 + GKL_BENCH_BACKEND=gloo: dry-run of the N>1 code path on a 1-GPU box
+    same_device = os.environ.get("GKL_BENCH_SAME_DEVICE") == "1"
+    backend = os.environ.get("GKL_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+    dev_index = 0 if same_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # every rank: same haplotypes (seed), its own reads (read_seed)
     batch = make_batch(a.workload, a.reads, a.haps, seed=DEFAULT_SEED, read_seed=DEFAULT_SEED + 1 + rank)
     dbatch = native.DeviceBatch.upload(batch, dev)
-    ctx = native.PairHmmContext(use_double=a.double, device=local_rank, record_events=True)
+    ctx = native.PairHmmContext(use_double=a.double, device=dev_index, record_events=True)
     out = torch.empty(batch.n_pairs, dtype=torch.float64, device=dev)
     rows = [a.reads] * world
     stream = torch.cuda.current_stream(dev)
 
     def step():
         ctx.compute_device(dbatch, out, stream)
-        return gather_to_root(out, rows, a.haps, dist) if world > 1 else out
+        if world == 1:
+            return out
+        return gather_to_root(out if comm_dev == dev else out.to(comm_dev), rows, a.haps, dist)
 
     for _ in range(a.warmup):
         step()
@@ -121,10 +131,10 @@ def main():
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([float(batch.cells), float(batch.n_pairs)], dtype=torch.float64, device=dev)
+        c = torch.tensor([float(batch.cells), float(batch.n_pairs)], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells, total_pairs = float(c[0].item()), float(c[1].item())
     else:

@@ -877,6 +877,22 @@ int gklhip_get_raw(gklhip_ctx* c, float* raw32, double* raw64, uint8_t* used64) 
   return GKLHIP_OK;
 }
 
+int gklhip_plan_describe(int32_t n_reads, int32_t n_haps, const int64_t* read_off, const int64_t* hap_off,
+                         int32_t rows_per_lane, int32_t* lanes_out, int64_t lanes_cap, int32_t* n_groups_out,
+                         int32_t* n_long_out) {
+  if (n_reads < 0 || n_haps < 0 || !read_off || !hap_off || (rows_per_lane != 4 && rows_per_lane != 8))
+    return -fail(GKLHIP_ERR_INVALID_ARG, "bad arguments to gklhip_plan_describe");
+  Plan p;
+  build_plan(n_reads, n_haps, read_off, hap_off, rows_per_lane, 4096, &p);
+  if (n_groups_out) *n_groups_out = (int32_t)p.groups.size();
+  if (n_long_out) *n_long_out = (int32_t)p.long_reads.size();
+  if (lanes_out) {
+    const int64_t n = std::min<int64_t>(lanes_cap, (int64_t)p.lanes.size());
+    for (int64_t i = 0; i < n; i++) { lanes_out[2 * i] = p.lanes[i].read; lanes_out[2 * i + 1] = p.lanes[i].block; }
+  }
+  return p.n_chunks;
+}
+
 int64_t gklhip_get_table_f32(int which, float* dst, int64_t cap) {
   const HostTables<float>& t = host_tables_f32();
   const std::vector<float>* v = which == 0 ? &t.ph2pr : which == 1 ? &t.mm : which == 2 ? &t.div3 : nullptr;

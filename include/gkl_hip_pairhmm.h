@@ -130,6 +130,15 @@ int gklhip_get_raw(gklhip_ctx* ctx, float* raw32, double* raw64, uint8_t* used64
 int64_t gklhip_get_table_f32(int which, float* dst, int64_t cap);
 int64_t gklhip_get_table_f64(int which, double* dst, int64_t cap);
 
+/* Host-side work planning only (no device needed): how the reads of a batch would be packed into
+ * 64-lane chunks at `rows_per_lane` rows per lane and how many haplotype streams are formed.
+ * lanes_out (may be NULL) receives n_chunks*64 pairs {read index or -1, row block}; returns the number
+ * of chunks, or a negative status. n_groups_out / n_long_out (may be NULL): stream groups, reads
+ * routed to the striped long-read kernel. */
+int gklhip_plan_describe(int32_t n_reads, int32_t n_haps, const int64_t* read_off, const int64_t* hap_off,
+                         int32_t rows_per_lane, int32_t* lanes_out, int64_t lanes_cap, int32_t* n_groups_out,
+                         int32_t* n_long_out);
+
 const char* gklhip_strerror(int status);
 /* Thread-local detail message of the last failing call on this thread. */
 const char* gklhip_last_error(void);
