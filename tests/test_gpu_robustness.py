@@ -1,0 +1,85 @@
+"""Shapes and usage patterns beyond the parity suites: BASELINE config 4 size (1 M pairs), single read /
+single haplotype, many tiny haplotypes, repeated calls with changing sizes on one context, concurrent
+callers (GATK Spark calls computeLikelihoods from several Java threads)."""
+import threading
+
+import numpy as np
+import pytest
+
+from gkl_amd.synth import make_batch, random_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def native():
+    from gkl_amd import native as n
+    return n
+
+
+def test_config4_one_million_pairs(native, oracle):
+    b = make_batch("hc", 8000, 125, seed=20250418)  # 1 M pairs
+    with native.PairHmmContext(record_events=True) as c:
+        out = c.compute(b).reshape(8000, 125)
+        st = c.stats()
+        assert st["n_pairs"] == 1_000_000 and np.isfinite(out).all() and (out < 0).all()
+        # a random sample of reads against the oracle, bit-exact
+        pick = np.sort(np.random.RandomState(1).choice(8000, 24, replace=False))
+        for r in pick[:8]:
+            one = b.read_slice(int(r), int(r) + 1)
+            assert np.array_equal(bits(oracle.batch(one, n_threads=4)), bits(out[r]))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 300), (300, 1), (3, 2)])
+def test_degenerate_shapes(native, oracle, shape):
+    rng = np.random.RandomState(sum(shape))
+    b = random_batch(rng, shape[0], shape[1], read_len=(1, 120), hap_len=(1, 200))
+    with native.PairHmmContext() as c:
+        assert np.array_equal(bits(c.compute(b)), bits(oracle.batch(b, n_threads=4)))
+    with native.PairHmmContext(use_double=True) as c:
+        assert np.array_equal(bits(c.compute(b)), bits(oracle.batch(b, use_double=True, n_threads=4)))
+
+
+def test_many_tiny_haplotypes_and_reads(native, oracle):
+    rng = np.random.RandomState(8)
+    b = random_batch(rng, 200, 300, read_len=(1, 6), hap_len=(1, 5))
+    with native.PairHmmContext() as c:
+        assert np.array_equal(bits(c.compute(b)), bits(oracle.batch(b, n_threads=8)))
+
+
+def test_context_reuse_with_changing_sizes(native, oracle):
+    rng = np.random.RandomState(21)
+    with native.PairHmmContext() as c:
+        for n_reads, n_haps in [(5, 3), (400, 20), (2, 90), (150, 7), (1, 1), (60, 60)]:
+            b = make_batch("hc", n_reads, n_haps, seed=n_reads * 1000 + n_haps) if n_reads > 30 else \
+                random_batch(rng, n_reads, n_haps)
+            assert np.array_equal(bits(c.compute(b)), bits(oracle.batch(b, n_threads=8)))
+
+
+def test_concurrent_callers_on_one_context(native, oracle):
+    batches = [make_batch("hc", 120, 10, seed=s) for s in range(6)]
+    expect = [oracle.batch(b, n_threads=2) for b in batches]
+    results = [None] * len(batches)
+    with native.PairHmmContext() as c:
+        def work(i):
+            for _ in range(3):
+                results[i] = c.compute(batches[i])
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(batches))]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+    for r, e in zip(results, expect):
+        assert np.array_equal(bits(r), bits(e))
+
+
+def test_two_contexts_do_not_interfere(native, oracle):
+    b1, b2 = make_batch("hc", 200, 12, seed=1), make_batch("region", 150, 9, seed=2)
+    with native.PairHmmContext() as c1, native.PairHmmContext(use_double=True) as c2:
+        o1a = c1.compute(b1)
+        o2 = c2.compute(b2)
+        o1b = c1.compute(b1)
+    assert np.array_equal(bits(o1a), bits(o1b)) and np.array_equal(bits(o1a), bits(oracle.batch(b1, n_threads=8)))
+    assert np.array_equal(bits(o2), bits(oracle.batch(b2, use_double=True, n_threads=8)))
