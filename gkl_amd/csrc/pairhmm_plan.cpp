@@ -96,7 +96,10 @@ int pack_reads_windowed(const int32_t* order_in, int n, const int64_t* read_off,
     need_sum += need_of[i];
     if (useful_rows) *useful_rows += R;
   }
-  lanes->reserve(lanes->size() + (size_t)(need_sum + need_sum / 8 + 2 * kLanes));
+  {  // grow geometrically: callers (the PDHMM planner) may append thousands of small packings
+    const size_t want = lanes->size() + (size_t)(need_sum + need_sum / 8 + 2 * kLanes);
+    if (lanes->capacity() < want) lanes->reserve(std::max(want, 2 * lanes->capacity()));
+  }
   std::vector<int32_t> sorted((size_t)std::min(n, window));
   std::vector<uint8_t> sorted_need((size_t)std::min(n, window));
   std::vector<int32_t> next;  // per chunk of the current window: next chunk with the same free size

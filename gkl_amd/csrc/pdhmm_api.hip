@@ -16,6 +16,7 @@
 #include "../../include/gkl_hip_pairhmm.h"  // status codes
 #include "../../include/gkl_hip_pdhmm.h"
 #include "pdhmm_kernel.h"
+#include "pairhmm_plan.h"
 
 using namespace gklhip;
 
@@ -100,7 +101,7 @@ struct gklhip_pdhmm_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
-  Buf tables, inputs, entries, sums, misc, carry;
+  Buf tables, inputs, entries, sums, misc, carry, jobs;
   float last_ms = 0.f;
 };
 
@@ -151,7 +152,7 @@ int gklhip_pdhmm_done(gklhip_pdhmm_ctx* c) {
   if (!c) return GKLHIP_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->sums, &c->misc, &c->carry}) b->release();
+  for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->sums, &c->misc, &c->carry, &c->jobs}) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -199,13 +200,61 @@ int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, doubl
   PD_HIP_TRY(hipMemcpyAsync(d + o_hl, b->hap_lengths, n * 8, hipMemcpyHostToDevice, s));
   PD_HIP_TRY(hipMemcpyAsync(d + o_rl, b->read_lengths, n * 8, hipMemcpyHostToDevice, s));
 
-  const int entry_stride = (b->max_hap_len + 2 * kLanes + 63) / 64 * 64;
+  // ---- jobs: short pairs, ordered by haplotype length so that wavefront mates finish together, are
+  // packed best-fit into 64-lane chunks; a read that needs more than 64 lanes becomes a striped job ----
+  std::vector<PlanLane> lanes;
+  std::vector<int32_t> job_pair, job_steps;
+  std::vector<uint8_t> job_striped;
+  {
+    std::vector<int64_t> pair_off(n + 1, 0);  // pack_reads_windowed() addresses reads through offsets
+    for (size_t i = 0; i < n; i++) pair_off[i + 1] = pair_off[i] + b->read_lengths[i];
+    std::vector<int32_t> shorts;
+    shorts.reserve(n);
+    {  // counting sort by haplotype length, longest first (the big jobs start first)
+      std::vector<int32_t> cnt((size_t)b->max_hap_len + 2, 0);
+      size_t n_short = 0;
+      for (size_t i = 0; i < n; i++)
+        if (blocks_for((int)b->read_lengths[i], kPdRpl) <= kLanes) { cnt[(size_t)b->hap_lengths[i]]++; n_short++; }
+      int32_t acc = 0;
+      for (int64_t h = b->max_hap_len; h >= 0; h--) { const int32_t c = cnt[(size_t)h]; cnt[(size_t)h] = acc; acc += c; }
+      shorts.resize(n_short);
+      for (size_t i = 0; i < n; i++)
+        if (blocks_for((int)b->read_lengths[i], kPdRpl) <= kLanes) shorts[(size_t)cnt[(size_t)b->hap_lengths[i]]++] = (int32_t)i;
+    }
+    for (size_t i = 0; i < n; i++) {
+      if (blocks_for((int)b->read_lengths[i], kPdRpl) <= kLanes) continue;
+      job_pair.push_back((int32_t)i); job_striped.push_back(1); job_steps.push_back(0);
+      lanes.resize(lanes.size() + kLanes, PlanLane{-1, 0});  // striped job: its lane row stays unused
+    }
+    const int before = (int)(lanes.size() / kLanes);
+    const int made = pack_reads_windowed(shorts.data(), (int)shorts.size(), pair_off.data(), kPdRpl, 192, &lanes, nullptr);
+    for (int k = 0; k < made; k++) {
+      int32_t rep = -1, steps = 0;
+      const PlanLane* row = lanes.data() + (size_t)(before + k) * kLanes;
+      for (int l = 0; l < kLanes; l++) {
+        if (row[l].read < 0) continue;
+        if (rep < 0) rep = row[l].read;
+        steps = std::max(steps, (int32_t)b->hap_lengths[row[l].read] + row[l].block);
+      }
+      job_pair.push_back(rep); job_striped.push_back(0); job_steps.push_back(steps);
+    }
+  }
+  const int n_jobs = (int)job_pair.size();
+  const int entry_stride = (b->max_hap_len + 2 * kLanes + 1 + 63) / 64 * 64;
   const int carry_len = entry_stride;
-  const int n_blocks = (int)std::min<size_t>(n, 256 * 8);
+  const int n_blocks = std::min(n_jobs, 256 * 8);
   if ((rc = c->entries.reserve(n * (size_t)entry_stride * 4))) return rc;
   if ((rc = c->sums.reserve(n * 8))) return rc;
   if ((rc = c->misc.reserve(64))) return rc;
   if ((rc = c->carry.reserve((size_t)n_blocks * 2 * (6 * (size_t)carry_len + 64) * 8))) return rc;
+  const size_t o_jl = 0, o_jp = up(lanes.size() * sizeof(PlanLane)), o_jn = o_jp + up((size_t)n_jobs * 4),
+               o_js = o_jn + up((size_t)n_jobs * 4);
+  if ((rc = c->jobs.reserve(o_js + up((size_t)n_jobs)))) return rc;
+  unsigned char* dj = c->jobs.as<unsigned char>();
+  PD_HIP_TRY(hipMemcpyAsync(dj + o_jl, lanes.data(), lanes.size() * sizeof(PlanLane), hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(dj + o_jp, job_pair.data(), (size_t)n_jobs * 4, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(dj + o_jn, job_steps.data(), (size_t)n_jobs * 4, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(dj + o_js, job_striped.data(), (size_t)n_jobs, hipMemcpyHostToDevice, s));
   PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
 
   const PdTables& t = pd_tables();
@@ -229,6 +278,11 @@ int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, doubl
   a.next = c->misc.as<int32_t>() + 1;
   a.carry = c->carry.as<double>();
   a.carry_len = carry_len;
+  a.lanes = reinterpret_cast<const LaneSlot*>(dj + o_jl);
+  a.job_pair = reinterpret_cast<const int32_t*>(dj + o_jp);
+  a.job_steps = reinterpret_cast<const int32_t*>(dj + o_jn);
+  a.job_striped = dj + o_js;
+  a.n_jobs = n_jobs;
 
   hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, a);
   PD_HIP_TRY(hipEventRecord(c->ev0, s));

@@ -12,8 +12,11 @@
 // Mapping: the same systolic wavefront as the PairHMM kernel (pairhmm_fwd_kernel.h) -- each
 // lane owns RPL read rows in registers, the haplotype's columns stream through the lanes, the
 // row above arrives by DPP wave_shr:1 -- with three differences dictated by the algorithm:
-//   * every pair has its own haplotype, so a job is ONE (read, haplotype) pair; reads longer than
-//     64*RPL-1 rows run as consecutive stripes with the boundary row carried through memory;
+//   * every pair may have its own haplotype, so each lane reads its OWN column stream (one coalesced
+//     4-byte load per step, prefetched a step ahead) instead of receiving the column from the lane
+//     above; that lets pairs with different haplotypes sit side by side in one wavefront.  Reads
+//     longer than 64*RPL-1 rows run alone, as consecutive stripes with the boundary row carried
+//     through memory;
 //   * the per-column symbol is (base, SNP allele mask, state, DEL_END flag), too many values for
 //     an LDS prior table, so the match predicate is evaluated per cell (4 integer ops + select);
 //   * six values cross from lane to lane per step instead of three.
@@ -45,13 +48,21 @@ struct PdArgs {
   int32_t batch, max_hap, max_read;
   const double* q2err;         // [255]  10^(-q/10)
   const double* mm_prob;       // [32640] matchToMatchProb triangle
-  uint32_t* entries;           // [batch * entry_stride] per-pair column entries (+ idle padding)
-  int32_t entry_stride;        // max_hap + 64 + 64 rounded up
+  uint32_t* entries;           // [batch * entry_stride] per pair: 64 idle, the column entries, idle to the end
+  int32_t entry_stride;        // 64 + max_hap + 64 + 1 (prefetch) rounded up
   double* sums;                // [batch] raw sums (scaled by 2^1020)
   int32_t* status;             // [1] sticky PDHMM_INPUT_DATA_ERROR flag (negative quals)
   int32_t* next;               // [1] job counter
   double* carry;               // per persistent block: 2 x (6 x carry_len + 64)
   int32_t carry_len;
+  // jobs: one wavefront-load each.  Packed job: up to 64 lanes of whole pairs
+  // (lanes[job*64+lane] = {pair, row block} or {-1,0}), job_steps = max over its pairs of
+  // hap_len + blocks - 1; striped job: the single pair job_pair[job], whose read needs more than 64 lanes.
+  const LaneSlot* lanes;
+  const int32_t* job_pair;
+  const int32_t* job_steps;
+  const uint8_t* job_striped;
+  int32_t n_jobs;
 };
 
 // One thread per pair: walk the column state machine (pdhmm.h:437-449 -- it depends on the
@@ -63,6 +74,8 @@ __global__ void pdhmm_entries_kernel(PdArgs a) {
   const int8_t* hb = a.hap_bases + (int64_t)p * a.max_hap;
   const int8_t* pd = a.hap_pdbases + (int64_t)p * a.max_hap;
   uint32_t* e = a.entries + (int64_t)p * a.entry_stride;
+  for (int j = 0; j < kLanes; j++) e[j] = kPdIdle;
+  e += kLanes;
   int state = 0;
   for (int j = 0; j < H; j++) {
     const uint32_t flags = (uint32_t)pd[j] & 0x7fu;
@@ -71,7 +84,7 @@ __global__ void pdhmm_entries_kernel(PdArgs a) {
     if (flags & kPdDelStart) state = 1;
     if (flags & kPdDelEnd) state = 2;
   }
-  for (int j = H; j < a.entry_stride; j++) e[j] = kPdIdle;
+  for (int j = H; j < a.entry_stride - kLanes; j++) e[j] = kPdIdle;
 }
 
 __device__ __forceinline__ double pd_max(double x, double y) { return x > y ? x : y; }  // _mm256_max_pd on finite values
@@ -143,7 +156,7 @@ struct PdJob {
   }
 
   __device__ __forceinline__ void step(uint32_t entry) {
-    ent = dpp_shr1_keep(entry, ent);
+    ent = entry;
     const bool off = (ent & kPdIdle) != 0;
     const uint32_t y = ent & 0xffu;
     const uint32_t flags = (ent >> 8) & 0x7fu;
@@ -191,9 +204,10 @@ struct PdJob {
     fetch_above();
   }
 
-  // One stripe: stream `n_steps` entries through the loaded rows; cin / cout carry the boundary
-  // row between stripes (six values per stream position + the column-0 values in slot [6*clen..]).
-  __device__ __forceinline__ void run(const uint32_t* __restrict__ sp, int n_steps, int lane,
+  // One stripe: `n_steps` steps over the loaded rows; ep[t] is this lane's column entry at step t
+  // (the pair's entries shifted by the lane's skew); cin / cout carry the boundary row between
+  // stripes (six values per stream position + the column-0 values in slot [6*clen..]).
+  __device__ __forceinline__ void run(const uint32_t* __restrict__ ep, int n_steps, int lane,
                                       const double* __restrict__ cin, double* __restrict__ cout, int clen) {
     double ci[6], co[6];
 #pragma unroll
@@ -207,7 +221,9 @@ struct PdJob {
 #pragma unroll
       for (int k = 0; k < 6; k++) d[k] = cin[6 * clen + k];
     }
+    uint32_t cur = ep[0];
     for (int t = 0; t < n_steps; t++) {
+      const uint32_t nxt = ep[t + 1];
       if (cin) {
         if ((t & 63) == 0) {
 #pragma unroll
@@ -219,7 +235,8 @@ struct PdJob {
           if (lane == 0) r[k] = v;
         }
       }
-      step(sp[t]);
+      step(cur);
+      cur = nxt;
       if (cout) {
         const int p = t - (kLanes - 1);
         if (p >= 0) {
@@ -241,36 +258,51 @@ struct PdJob {
   }
 };
 
-// Persistent wavefronts pull pairs; each pair runs as ceil((R+1)/(64*RPL)) stripes.
+// Persistent wavefronts pull jobs (see PdArgs).
 __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_condition) {
   const int lane = threadIdx.x;
   const int64_t cstride = 6 * (int64_t)a.carry_len + 64;
   double* my = a.carry + (int64_t)blockIdx.x * 2 * cstride;
   PdJob job;
   for (;;) {
-    int p = 0;
-    if (lane == 0) p = atomicAdd(a.next, 1);
-    p = __builtin_amdgcn_readfirstlane(p);
-    if (p >= a.batch) break;
-    const int R = (int)a.read_len[p], H = (int)a.hap_len[p];
+    int j = 0;
+    if (lane == 0) j = atomicAdd(a.next, 1);
+    j = __builtin_amdgcn_readfirstlane(j);
+    if (j >= a.n_jobs) break;
+    const int rep = a.job_pair[j];
+    if (!a.job_striped[j]) {
+      const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
+      const bool active = sl.read >= 0;
+      const int p = active ? sl.read : rep;
+      const int n_blocks = ((int)a.read_len[p] + PdJob::RPL) / PdJob::RPL;
+      const double init = init_condition / (double)a.hap_len[p];  // pdhmm.h:867-878 (IEEE division, as on the host)
+      job.setup(a, p, sl.block, n_blocks, active, init);
+      // block k of a pair sees column j at step j + k
+      job.run(a.entries + (int64_t)p * a.entry_stride + kLanes - sl.block, a.job_steps[j], lane, nullptr, nullptr,
+              a.carry_len);
+      if (job.holds_last) a.sums[p] = job.sum;
+      continue;
+    }
+    const int H = (int)a.hap_len[rep];
+    const double init = init_condition / (double)H;
+    const uint32_t* ep = a.entries + (int64_t)rep * a.entry_stride + kLanes - lane;  // lane l sees column j at step j + l
+    const int n_steps = H + kLanes - 1;
+    const int R = (int)a.read_len[rep];
     const int n_blocks = (R + PdJob::RPL) / PdJob::RPL;
     const int n_stripes = (n_blocks + kLanes - 1) / kLanes;
     const int first_cnt = n_blocks - kLanes * (n_stripes - 1);
-    const double init = init_condition / (double)H;  // pdhmm.h:867-878 (IEEE division, same as the host)
-    const uint32_t* sp = a.entries + (int64_t)p * a.entry_stride;
-    const int n_steps = H + kLanes - 1;
     for (int st = 0; st < n_stripes; st++) {
       int block;
       bool active;
       if (st == 0) { active = lane >= kLanes - first_cnt; block = lane - (kLanes - first_cnt); }
       else { active = true; block = first_cnt + (st - 1) * kLanes + lane; }
-      job.setup(a, p, block, n_blocks, active, init);
+      job.setup(a, rep, block, n_blocks, active, init);
       const double* cin = st > 0 ? my + (int64_t)((st + 1) & 1) * cstride : nullptr;
       double* cout = st + 1 < n_stripes ? my + (int64_t)(st & 1) * cstride : nullptr;
-      job.run(sp, n_steps, lane, cin, cout, a.carry_len);
+      job.run(ep, n_steps, lane, cin, cout, a.carry_len);
       __threadfence_block();
     }
-    if (job.holds_last) a.sums[p] = job.sum;
+    if (job.holds_last) a.sums[rep] = job.sum;
   }
 }
 

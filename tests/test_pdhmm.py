@@ -142,6 +142,37 @@ def test_pdhmm_gpu_random_batches_bit_exact(pd_ctx, pd_oracle, kw):
     #  vector kernels by 0.2 on such random flag patterns; parity is defined against the vector kernels)
 
 
+def cross_product(rng, n_reads, n_haps, read_len, hap_len):
+    """reads x haplotypes, read-major: the batches IntelPDHMM.computeLikelihoods builds (IntelPDHMM.java:83-145)."""
+    src = random_pd_batch(rng, n_reads, read_len=read_len, hap_len=(1, 2))
+    haps = random_pd_batch(rng, n_haps, read_len=(1, 2), hap_len=hap_len)
+    pairs = []
+    for r in range(n_reads):
+        R = int(src.read_lengths[r])
+        rr = lambda a: a.reshape(n_reads, src.max_read_len)[r, :R]  # noqa: E731
+        for h in range(n_haps):
+            H = int(haps.hap_lengths[h])
+            hh = lambda a: a.reshape(n_haps, haps.max_hap_len)[h, :H]  # noqa: E731
+            pairs.append((hh(haps.hap_bases), hh(haps.hap_pdbases), rr(src.read_bases), rr(src.read_qual),
+                          rr(src.read_ins_qual), rr(src.read_del_qual), rr(src.gcp)))
+    return PdhmmBatch.from_pairs(pairs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 6, (1, 60), (1, 90)), (90, 3, (100, 151), (150, 260)),
+                                   (12, 4, (200, 600), (50, 300))])
+def test_pdhmm_gpu_cross_product_shares_haplotypes(pd_ctx, pd_oracle, shape):
+    # whole pairs (any haplotype) ride side by side in one wavefront; reads over 255 rows run striped
+    n_reads, n_haps, rl, hl = shape
+    b = cross_product(np.random.RandomState(n_reads), n_reads, n_haps, rl, hl)
+    got = pd_ctx.compute(b)
+    _, vec = pd_oracle.compute(b, semantics=0)
+    assert got.tobytes() == vec.tobytes()
+    # permuting the pairs must not change any result (packing must not leak between lanes)
+    perm = np.random.RandomState(1).permutation(b.batch)
+    assert pd_ctx.compute(b.subset(perm)).tobytes() == vec[perm].tobytes()
+
+
 @pytest.mark.gpu
 def test_pdhmm_gpu_argument_errors(pd_ctx):
     from gkl_amd import native

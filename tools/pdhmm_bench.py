@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Dev tool: PDHMM forward kernel throughput on (a) a reads x haplotypes cross product -- the batches
+IntelPDHMM.computeLikelihoods builds -- and (b) pairs with all-distinct haplotypes (the reference's
+test-data shape), with the reference's AVX-512/AVX2 kernel timed on one host thread beside it."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=600)
+    ap.add_argument("--haps", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    from gkl_amd import native
+    from tests.test_pdhmm import cross_product, random_pd_batch
+    rng = np.random.RandomState(7)
+    cases = {
+        "cross": cross_product(rng, a.reads, a.haps, (80, 151), (150, 300)),
+        "distinct": random_pd_batch(rng, a.reads * a.haps, read_len=(80, 151), hap_len=(150, 300)),
+    }
+    ctx = native.PdhmmContext()
+    for name, b in cases.items():
+        ctx.compute(b)
+        best_k, best_w = 1e9, 1e9
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            ctx.compute(b)
+            best_w = min(best_w, time.perf_counter() - t0)
+            best_k = min(best_k, ctx.last_kernel_ms())
+        line = (f"{name}: {b.batch} pairs {b.cells:.3e} cells  kernel {best_k:.3f} ms = "
+                f"{b.cells / best_k / 1e6:.1f} GCUPS   host-to-host {best_w * 1e3:.2f} ms = "
+                f"{b.cells / best_w / 1e9:.1f} GCUPS")
+        try:
+            from oracle.pdhmm import PdhmmReference
+            ref = PdhmmReference()
+            sub = b.subset(np.arange(min(b.batch, 1500)))
+            t0 = time.perf_counter()
+            ref.compute(sub, engine=2 if ref.simd_width(2) >= 8 else 1, threads=1)
+            dt = time.perf_counter() - t0
+            line += f"   reference 1 thread {sub.cells / dt / 1e9:.2f} GCUPS"
+        except Exception as e:  # noqa: BLE001
+            line += f"   (reference unavailable: {e})"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
