@@ -57,3 +57,28 @@ def load_pdhmm_file(name):
             pairs.append((c[0].encode(), pd, c[2].encode(), q(c[3]), q(c[4]), q(c[5]), q(c[6])))
             exp.append(float(c[7]))
     return PdhmmBatch.from_pairs(pairs), np.array(exp)
+
+
+def load_pdhmm_holders_file(name="pdhmm_new.txt"):
+    """The reference's reads-x-haplotypes PDHMM fixture (three '#' sections: reads with fastq-33 quals,
+    haplotypes with their PD byte lists, one expected log10 per (read, haplotype), read-major;
+    parsed like IntelPDHMMUnitTest.java:446-524).  Returns (reads, haps, expected[n_reads*n_haps])."""
+    reads, haps, exp = [], [], []
+    section = 0
+    q = lambda s: (np.frombuffer(s.encode("utf-8"), dtype=np.uint8).astype(np.int16) - 33).astype(np.int8)  # noqa: E731
+    with open(os.path.join(GOLDEN, name), encoding="utf-8") as f:
+        for line in f:
+            if line.startswith("#"):
+                section += 1
+                continue
+            c = line.rstrip("\n").split("\t")
+            if not c[0]:
+                continue
+            if section == 1:
+                reads.append((np.frombuffer(c[0].encode(), dtype=np.int8), q(c[1]), q(c[2]), q(c[3]), q(c[4])))
+            elif section == 2:
+                haps.append((np.frombuffer(c[0].encode(), dtype=np.int8),
+                             np.array([int(x) for x in c[1][1:-1].split(",")], dtype=np.int8)))
+            else:
+                exp.append(float(c[0]))
+    return reads, haps, np.array(exp)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from gkl_amd.pdhmm_batch import PdhmmBatch
-from tests.golden_io import load_pdhmm_file
+from tests.golden_io import load_pdhmm_file, load_pdhmm_holders_file
 
 FILES = ["pdhmm_syn_990_1_2.txt", "pdhmm_syn_199_68_51.txt", "pdhmm_syn_1412_129_223.head300.txt"]
 TOL = 1e-4
@@ -86,6 +86,21 @@ def test_pdhmm_oracle_bit_identical_to_reference_kernels(pd_oracle, pd_reference
             st, ref2 = pd_reference.compute(b, engine=2)
             nv2 = (b.batch // pd_reference.simd_width(2)) * pd_reference.simd_width(2)
             assert st == 0 and np.max(np.abs(ref2[:nv2] - vec[:nv2])) < 1e-9  # gcc contracts FMAs in that TU
+
+
+def holders_fixture_batch():
+    reads, haps, exp = load_pdhmm_holders_file()
+    pairs = [(h[0], h[1], r[0], r[1], r[2], r[3], r[4]) for r in reads for h in haps]  # read-major, JavaData.h:190
+    return reads, haps, PdhmmBatch.from_pairs(pairs), exp
+
+
+def test_pdhmm_oracle_matches_holders_fixture(pd_oracle):
+    # pdhmm_new.txt: 276 reads x 48 haplotypes, 13 248 expectations (the Java test keeps its asserts commented
+    # out, IntelPDHMMUnitTest.java:546-552; the values do pin the arithmetic: max |diff| 4.8e-6)
+    reads, haps, b, exp = holders_fixture_batch()
+    assert (len(reads), len(haps), exp.size) == (276, 48, 13248)
+    st, vec = pd_oracle.compute(b, semantics=0)
+    assert st == 0 and np.max(np.abs(vec - exp)) <= TOL
 
 
 def test_pdhmm_oracle_negative_quality_is_input_error(pd_oracle):
@@ -250,6 +265,40 @@ def test_pdhmm_jni_flat_and_holder_paths(pd_oracle):
     bad.read_del_qual[1] = -7
     rc, _, cls, msg = mockjni.run_pdhmm(bad)
     assert rc == 2 and cls == "java/lang/IllegalArgumentException" and "aren't valid" in msg
+
+
+@pytest.mark.gpu
+def test_pdhmm_mirror_compute_likelihoods_on_holders_fixture(pd_oracle):
+    # newPDHMMTest (IntelPDHMMUnitTest.java:446-556) with the asserts switched on
+    from gkl_amd.pdhmm import IntelPDHMM, PDHaplotypeDataHolder, ReadDataHolder
+    reads, haps, b, exp = holders_fixture_batch()
+    hmm = IntelPDHMM()
+    assert hmm.load(None)
+    hmm.initialize(None)
+    rd = []
+    for r in reads:
+        h = ReadDataHolder()
+        h.readBases, h.readQuals, h.insertionGOP, h.deletionGOP, h.overallGCP = r
+        rd.append(h)
+    hd = []
+    for x in haps:
+        h = PDHaplotypeDataHolder()
+        h.haplotypeBases, h.haplotypePDBases = x
+        hd.append(h)
+    out = np.zeros(len(rd) * len(hd))
+    hmm.computeLikelihoods(rd, hd, out)
+    hmm.done()
+    _, vec = pd_oracle.compute(b, semantics=0)
+    assert np.max(np.abs(out - exp)) <= TOL
+    assert out.tobytes() == vec.tobytes()
+    # the same holders through the JNI symbol computeLikelihoodsNative (mock JNIEnv), default memory budget
+    from tests import mockjni
+    one = np.zeros(1, np.int8)
+    src = PdhmmBatch.from_pairs([(one, one, *r) for r in reads])
+    hp = PdhmmBatch.from_pairs([(x[0], x[1], one, one, one, one, one) for x in haps])
+    rc, jout, cls, msg = mockjni.run_pdhmm(None, holders=(src, hp))
+    assert rc == 0, (cls, msg)
+    assert jout.tobytes() == vec.tobytes()
 
 
 @pytest.mark.gpu
