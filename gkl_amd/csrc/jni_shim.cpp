@@ -6,6 +6,10 @@
 //     being pinned one by one (50k pins at 10k reads) and described by a 56-byte
 //     testcase per PAIR (JavaData.h:94-110); local refs are deleted as we go
 //     (the reference leaks them until return, JavaData.h:135-145);
+//   * the flat batch lives in page-locked arenas that are kept across calls (gklhip_host_alloc), so
+//     the host-to-device copies are plain DMA, and every concurrent caller gets its own slot
+//     (context + stream + arenas, up to GKL_HIP_SLOTS, default 4): one Java thread marshals or
+//     finalises while another one's kernels run;
 //   * null holders / null byte[] fields / a too-short likelihood array raise
 //     IllegalArgumentException instead of crashing the JVM;
 //   * HIP failures raise java/lang/RuntimeException, allocation failures
@@ -13,7 +17,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -43,11 +50,51 @@ constexpr const char* kIAE = "java/lang/IllegalArgumentException";
 constexpr const char* kOOM = "java/lang/OutOfMemoryError";
 constexpr const char* kRTE = "java/lang/RuntimeException";
 
+// Grow-only page-locked byte arena (one per marshalled field and slot).
+struct PinnedBytes {
+  uint8_t* p = nullptr;
+  size_t cap = 0, len = 0;
+  PinnedBytes() = default;
+  PinnedBytes(const PinnedBytes&) = delete;
+  PinnedBytes& operator=(const PinnedBytes&) = delete;
+  ~PinnedBytes() { gklhip_host_free(p); }
+  void clear() { len = 0; }
+  uint8_t* grow(size_t add) {  // returns where the new bytes go
+    if (len + add > cap) {
+      const size_t want = std::max<size_t>(2 * cap, std::max<size_t>(len + add, 1 << 16));
+      uint8_t* q = static_cast<uint8_t*>(gklhip_host_alloc(want));
+      if (!q) throw std::bad_alloc();
+      if (len) memcpy(q, p, len);
+      gklhip_host_free(p);
+      p = q;
+      cap = want;
+    }
+    uint8_t* at = p + len;
+    len += add;
+    return at;
+  }
+};
+
+// Everything one call needs; a slot serves one caller at a time.
+struct Slot {
+  gklhip_ctx* ctx = nullptr;
+  PinnedBytes hap_bases, read_bases, read_quals, ins, del, gcp;
+  std::vector<int64_t> hap_off, read_off;
+  std::vector<double> out;
+  bool busy = false;
+  ~Slot() { if (ctx) gklhip_done(ctx); }
+};
+
 // Process-wide state, like the reference's globals (IntelPairHmm.cc:41-48) and the
 // static field IDs of JavaData (JavaData.h:160-176).
 struct State {
   std::mutex mu;
-  gklhip_ctx* ctx = nullptr;
+  std::condition_variable slot_free;
+  std::vector<std::unique_ptr<Slot>> slots;
+  int max_slots = 4;
+  int creating = 0;  // slots being initialised outside the lock
+  bool ready = false;
+  gklhip_config cfg;
   jfieldID readBases = nullptr, readQuals = nullptr, insertionGOP = nullptr, deletionGOP = nullptr,
            overallGCP = nullptr, haplotypeBases = nullptr;
 } g;
@@ -72,15 +119,10 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// Append holder[i].<field> (a byte[]) to dst; returns its length, or -1 after throwing.
-long append_field(JNIEnv* env, jobjectArray arr, jsize i, jfieldID fid, std::vector<uint8_t>& dst,
-                  long expect_at_least) {
-  jobject holder = gkljni::GetObjectArrayElement(env, arr, i);
-  if (gkljni::ExceptionCheck(env)) return -1;
-  if (!holder) { throw_java(env, kIAE, "null element in data holder array"); return -1; }
+// Append holder.<field> (a byte[]) to dst; returns its length, or -1 after throwing.
+long append_field(JNIEnv* env, jobject holder, jfieldID fid, PinnedBytes& dst, long expect_at_least) {
   jbyteArray bytes = (jbyteArray)gkljni::GetObjectField(env, holder, fid);
   if (!bytes) {
-    gkljni::DeleteLocalRef(env, holder);
     throw_java(env, kIAE, "null byte[] field in data holder");
     return -1;
   }
@@ -91,19 +133,80 @@ long append_field(JNIEnv* env, jobjectArray arr, jsize i, jfieldID fid, std::vec
     // for that many bytes. A shorter array is an error here (the reference reads past it).
     if (len < expect_at_least) {
       gkljni::DeleteLocalRef(env, bytes);
-      gkljni::DeleteLocalRef(env, holder);
       throw_java(env, kIAE, "read quality array shorter than readBases");
       return -1;
     }
     take = expect_at_least;
   }
-  const size_t at = dst.size();
-  dst.resize(at + (size_t)take);
-  if (take > 0) gkljni::GetByteArrayRegion(env, bytes, 0, (jsize)take, reinterpret_cast<jbyte*>(dst.data() + at));
+  if (take > 0) gkljni::GetByteArrayRegion(env, bytes, 0, (jsize)take, reinterpret_cast<jbyte*>(dst.grow((size_t)take)));
   gkljni::DeleteLocalRef(env, bytes);
-  gkljni::DeleteLocalRef(env, holder);
   if (gkljni::ExceptionCheck(env)) return -1;
   return take;
+}
+
+// holder = arr[i], or NULL after throwing.
+jobject holder_at(JNIEnv* env, jobjectArray arr, jsize i) {
+  jobject holder = gkljni::GetObjectArrayElement(env, arr, i);
+  if (gkljni::ExceptionCheck(env)) return nullptr;
+  if (!holder) throw_java(env, kIAE, "null element in data holder array");
+  return holder;
+}
+
+// A free slot, creating one (context + stream) while fewer than max_slots exist; blocks otherwise.
+// Returns NULL after throwing.
+Slot* acquire_slot(JNIEnv* env) {
+  std::unique_lock<std::mutex> lock(g.mu);
+  for (;;) {
+    if (!g.ready) {
+      lock.unlock();
+      throw_java(env, kRTE, "GKL-HIP PairHMM: computeLikelihoodsNative before initNative");
+      return nullptr;
+    }
+    for (auto& s : g.slots)
+      if (!s->busy) { s->busy = true; return s.get(); }
+    if ((int)g.slots.size() + g.creating < g.max_slots) {
+      g.creating++;
+      const gklhip_config cfg = g.cfg;
+      lock.unlock();
+      std::unique_ptr<Slot> s(new (std::nothrow) Slot());
+      const int st = s ? gklhip_init(&cfg, &s->ctx) : GKLHIP_ERR_OOM;
+      lock.lock();
+      g.creating--;
+      if (st != GKLHIP_OK) {
+        // could not add a slot (e.g. out of device memory): share the existing ones instead
+        g.max_slots = std::max<int>(1, (int)g.slots.size());
+        if (g.slots.empty()) { lock.unlock(); throw_status(env, st); return nullptr; }
+        continue;
+      }
+      s->busy = true;
+      g.slots.push_back(std::move(s));
+      return g.slots.back().get();
+    }
+    g.slot_free.wait(lock);
+  }
+}
+
+struct SlotLease {
+  Slot* s;
+  ~SlotLease() {
+    if (!s) return;
+    {
+      std::lock_guard<std::mutex> lock(g.mu);
+      s->busy = false;
+    }
+    g.slot_free.notify_one();
+  }
+};
+
+// Waits until no call is in flight, then drops every slot.
+void drop_slots(std::unique_lock<std::mutex>& lock) {
+  g.ready = false;
+  g.slot_free.wait(lock, [] {
+    if (g.creating) return false;
+    for (auto& s : g.slots) if (s->busy) return false;
+    return true;
+  });
+  g.slots.clear();
 }
 
 }  // namespace
@@ -113,7 +216,7 @@ extern "C" {
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
     JNIEnv* env, jclass, jclass readDataHolder, jclass haplotypeDataHolder, jboolean use_double,
     jint max_threads) {
-  std::lock_guard<std::mutex> lock(g.mu);
+  std::unique_lock<std::mutex> lock(g.mu);
   struct { jfieldID* dst; jclass cls; const char* name; } fields[] = {
       {&g.readBases, readDataHolder, "readBases"},       {&g.readQuals, readDataHolder, "readQuals"},
       {&g.insertionGOP, readDataHolder, "insertionGOP"}, {&g.deletionGOP, readDataHolder, "deletionGOP"},
@@ -121,13 +224,14 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
   for (auto& f : fields) {
     jfieldID id = f.cls ? gkljni::GetFieldID(env, f.cls, f.name, "[B") : nullptr;
     if (!id) {  // JavaData.h:127-133
+      lock.unlock();
       throw_java(env, kIAE, "Unable to get field ID");
       return;
     }
     *f.dst = id;
   }
-  if (g.ctx) { gklhip_done(g.ctx); g.ctx = nullptr; }
-  gklhip_config cfg;
+  drop_slots(lock);
+  gklhip_config& cfg = g.cfg;
   memset(&cfg, 0, sizeof cfg);
   cfg.abi_version = GKLHIP_ABI_VERSION;
   cfg.device = env_int("GKL_HIP_DEVICE", -1);
@@ -137,8 +241,13 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
   cfg.finalize = env_int("GKL_HIP_FINALIZE", GKLHIP_FINALIZE_REFERENCE_HOST);
   cfg.record_events = 0;
   cfg.rows_per_lane = 0;
-  const int st = gklhip_init(&cfg, &g.ctx);
-  if (st != GKLHIP_OK) { g.ctx = nullptr; throw_status(env, st); }
+  g.max_slots = std::max(1, env_int("GKL_HIP_SLOTS", 4));
+  // the first slot is created here so that "no GPU" surfaces from initNative, like a failed dlopen would
+  std::unique_ptr<Slot> first(new (std::nothrow) Slot());
+  const int st = first ? gklhip_init(&cfg, &first->ctx) : GKLHIP_ERR_OOM;
+  if (st != GKLHIP_OK) { lock.unlock(); throw_status(env, st); return; }
+  g.slots.push_back(std::move(first));
+  g.ready = true;
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative(
@@ -148,30 +257,34 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     throw_java(env, kIAE, "null argument");  // the Java wrapper already raised NPE (IntelPairHmm.java:134-136)
     return;
   }
-  gklhip_ctx* ctx;
-  {
-    std::lock_guard<std::mutex> lock(g.mu);
-    ctx = g.ctx;
-  }
-  if (!ctx) { throw_java(env, kRTE, "GKL-HIP PairHMM: computeLikelihoodsNative before initNative"); return; }
+  SlotLease lease{acquire_slot(env)};
+  Slot* sl = lease.s;
+  if (!sl) return;
   try {
     const jsize n_reads = gkljni::GetArrayLength(env, readDataArray);
     const jsize n_haps = gkljni::GetArrayLength(env, haplotypeDataArray);
-    std::vector<uint8_t> hap_bases, read_bases, read_quals, ins, del, gcp;
-    std::vector<int64_t> hap_off((size_t)n_haps + 1, 0), read_off((size_t)n_reads + 1, 0);
+    for (PinnedBytes* a : {&sl->hap_bases, &sl->read_bases, &sl->read_quals, &sl->ins, &sl->del, &sl->gcp}) a->clear();
+    sl->hap_off.assign((size_t)n_haps + 1, 0);
+    sl->read_off.assign((size_t)n_reads + 1, 0);
     for (jsize h = 0; h < n_haps; h++) {
-      const long len = append_field(env, haplotypeDataArray, h, g.haplotypeBases, hap_bases, -1);
+      jobject holder = holder_at(env, haplotypeDataArray, h);
+      if (!holder) return;
+      const long len = append_field(env, holder, g.haplotypeBases, sl->hap_bases, -1);
+      gkljni::DeleteLocalRef(env, holder);
       if (len < 0) return;
-      hap_off[h + 1] = hap_off[h] + len;
+      sl->hap_off[h + 1] = sl->hap_off[h] + len;
     }
     for (jsize r = 0; r < n_reads; r++) {
-      const long len = append_field(env, readDataArray, r, g.readBases, read_bases, -1);
-      if (len < 0) return;
-      if (append_field(env, readDataArray, r, g.insertionGOP, ins, len) < 0) return;
-      if (append_field(env, readDataArray, r, g.deletionGOP, del, len) < 0) return;
-      if (append_field(env, readDataArray, r, g.overallGCP, gcp, len) < 0) return;
-      if (append_field(env, readDataArray, r, g.readQuals, read_quals, len) < 0) return;
-      read_off[r + 1] = read_off[r] + len;
+      jobject holder = holder_at(env, readDataArray, r);
+      if (!holder) return;
+      const long len = append_field(env, holder, g.readBases, sl->read_bases, -1);
+      const bool ok = len >= 0 && append_field(env, holder, g.insertionGOP, sl->ins, len) >= 0 &&
+                      append_field(env, holder, g.deletionGOP, sl->del, len) >= 0 &&
+                      append_field(env, holder, g.overallGCP, sl->gcp, len) >= 0 &&
+                      append_field(env, holder, g.readQuals, sl->read_quals, len) >= 0;
+      gkljni::DeleteLocalRef(env, holder);
+      if (!ok) return;
+      sl->read_off[r + 1] = sl->read_off[r] + len;
     }
     const int64_t n_pairs = (int64_t)n_reads * n_haps;
     if (n_pairs > 0x7fffffffLL) { throw_java(env, kIAE, "more than 2^31 read x haplotype pairs"); return; }
@@ -182,21 +295,21 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     if (n_pairs == 0) return;
     gklhip_batch b;
     b.n_reads = n_reads; b.n_haps = n_haps;
-    b.read_off = read_off.data(); b.hap_off = hap_off.data();
-    b.read_bases = read_bases.data(); b.read_quals = read_quals.data(); b.ins_gop = ins.data();
-    b.del_gop = del.data(); b.gcp = gcp.data(); b.hap_bases = hap_bases.data();
-    std::vector<double> out((size_t)n_pairs);
-    const int st = gklhip_compute(ctx, &b, out.data());
+    b.read_off = sl->read_off.data(); b.hap_off = sl->hap_off.data();
+    b.read_bases = sl->read_bases.p; b.read_quals = sl->read_quals.p; b.ins_gop = sl->ins.p;
+    b.del_gop = sl->del.p; b.gcp = sl->gcp.p; b.hap_bases = sl->hap_bases.p;
+    sl->out.resize((size_t)n_pairs);
+    const int st = gklhip_compute(sl->ctx, &b, sl->out.data());
     if (st != GKLHIP_OK) { throw_status(env, st); return; }
-    gkljni::SetDoubleArrayRegion(env, likelihoodArray, 0, (jsize)n_pairs, out.data());
+    gkljni::SetDoubleArrayRegion(env, likelihoodArray, 0, (jsize)n_pairs, sl->out.data());
   } catch (const std::bad_alloc&) {
     throw_java(env, kOOM, "Unable to allocate the PairHMM batch");
   }
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv*, jobject) {
-  std::lock_guard<std::mutex> lock(g.mu);
-  if (g.ctx) { gklhip_done(g.ctx); g.ctx = nullptr; }
+  std::unique_lock<std::mutex> lock(g.mu);
+  drop_slots(lock);
 }
 
 }  // extern "C"

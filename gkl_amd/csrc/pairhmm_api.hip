@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -103,6 +105,13 @@ __global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8
   stream[i] = e;
 }
 
+// Host finalisation (reference-exact log10f / log10 of the host libm) needs, per pair, either the raw
+// fp32 sum or the raw fp64 sum: one 8-byte word carries both cases -- the double's bits, or
+// 0xFFFFFFFF:float bits (a double whose high word is all ones is a NaN no computation here produces; if
+// one ever does it is replaced by the default NaN, which finalises to NaN all the same).
+constexpr int kModePacked = -2;
+constexpr uint64_t kPackedF32Tag = 0xFFFFFFFF00000000ull;
+
 struct FinalizeArgs {
   const float* raw32;
   const double* raw64;
@@ -113,7 +122,7 @@ struct FinalizeArgs {
   int32_t* read_fail;  // [n_reads] number of haplotypes each read must be recomputed against
   int32_t n_haps;
   int64_t n;
-  int mode;            // gklhip_finalize (device modes only) or -1: leave `out` to the host
+  int mode;            // gklhip_finalize (device modes only), -1: no output, kModePacked: `out` = packed raw sums
   float log10_init_f;  // log10f(2^120), host libm
   double log10_init32_as_f64;  // log10(2^120) in double
   double log10_init_d;         // log10(2^1020)
@@ -127,6 +136,7 @@ __global__ void policy_kernel(FinalizeArgs a) {
   const float v = a.raw32[i];
   if (v < 1e-28f) {  // NaN compares false and stays fp32, like the reference
     a.used64[i] = 1;
+    if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[i] = 0;  // "pending": filled in by finalize64_kernel
     const int k = atomicAdd(a.count, 1);
     a.list[k] = (int32_t)i;
     atomicAdd(a.read_fail + (int32_t)(i / a.n_haps), 1);
@@ -136,6 +146,8 @@ __global__ void policy_kernel(FinalizeArgs a) {
       a.out[i] = log10((double)v) - a.log10_init32_as_f64;
     } else if (a.mode == GKLHIP_FINALIZE_DEVICE_REF32) {
       a.out[i] = (double)((float)log10((double)v) - a.log10_init_f);
+    } else if (a.mode == kModePacked) {
+      reinterpret_cast<uint64_t*>(a.out)[i] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
     }
   }
 }
@@ -148,6 +160,11 @@ __global__ void finalize64_kernel(FinalizeArgs a, int use_list) {
   const int64_t p = use_list ? (int64_t)a.list[i] : i;
   if (!use_list) a.used64[p] = 1;
   if (a.mode >= 0) a.out[p] = log10(a.raw64[p]) - a.log10_init_d;
+  if (a.mode == kModePacked) {
+    uint64_t bits = (uint64_t)__double_as_longlong(a.raw64[p]);
+    if ((bits & kPackedF32Tag) == kPackedF32Tag) bits = 0x7FF8000000000000ull;
+    reinterpret_cast<uint64_t*>(a.out)[p] = bits;
+  }
 }
 
 // Packed fp64 fallback, step 2 (device): for every chunk of the second read packing, find the
@@ -287,6 +304,72 @@ __global__ __launch_bounds__(64) void pack_windows_kernel(const int32_t* __restr
 
 }  // namespace gklhip
 
+// ------------------------------------------------------------------ host worker pool
+// Persistent helper threads for the host-side log10 finalisation (spawning threads per call costs more
+// than the work on GATK-sized batches).  parallel_for blocks until every slice is done.
+namespace {
+class WorkerPool {
+ public:
+  ~WorkerPool() { stop(); }
+  void parallel_for(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn) {
+    if (threads <= 1 || n < 16384) { fn(0, n); return; }
+    ensure(threads - 1);
+    const int64_t per = (n + threads - 1) / threads;
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      fn_ = &fn; n_ = n; per_ = per; slices_ = threads; next_ = 1; pending_ = threads - 1;
+      gen_++;
+    }
+    cv_.notify_all();
+    fn(0, std::min(n, per));
+    std::unique_lock<std::mutex> l(mu_);
+    done_.wait(l, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+    workers_.clear();
+    quit_ = false;
+  }
+
+ private:
+  void ensure(int n) {
+    while ((int)workers_.size() < n) workers_.emplace_back([this] { loop(); });
+  }
+  void loop() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+      cv_.wait(l, [&] { return quit_ || (gen_ != seen && next_ < slices_); });
+      if (quit_) return;
+      while (next_ < slices_) {
+        const int k = next_++;
+        const int64_t lo = k * per_, hi = std::min(n_, lo + per_);
+        const auto* fn = fn_;
+        l.unlock();
+        if (lo < hi) (*fn)(lo, hi);
+        l.lock();
+        if (--pending_ == 0) done_.notify_all();
+      }
+      seen = gen_;
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
+  int64_t n_ = 0, per_ = 0;
+  int slices_ = 0, next_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool quit_ = false;
+};
+}  // namespace
+
 // ------------------------------------------------------------------ context
 struct gklhip_ctx {
   gklhip_config cfg;
@@ -304,8 +387,12 @@ struct gklhip_ctx {
   // per-call device scratch
   DevBuf raw32, raw64, used64, list, counters, stream_buf, read_off_dev, out_dev;
   DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist;
-  // host-API device copies of the batch
-  DevBuf batch_dev;
+  // host-API device copies of the batch, packed results (device + pinned), finalisation workers
+  DevBuf batch_dev, res_dev;
+  PinBuf res_pin, res_pin2;
+  WorkerPool workers;
+  hipStream_t copy_stream = nullptr;  // early D2H of the fp32 results while the fp64 pass runs
+  hipEvent_t policy_done = nullptr, early_copy_done = nullptr;
   // events
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // last call
@@ -605,6 +692,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa);
+    if (finalize_mode == kModePacked) HIP_TRY(hipEventRecord(c->policy_done, s));
     // ---- fp64 recomputation of the underflowed pairs ----
     FwdArgs<double> d{};
     fill_common(d);
@@ -683,27 +771,72 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   return GKLHIP_OK;
 }
 
-void finalize_on_host(const float* raw32, const double* raw64, const uint8_t* used, double* out,
-                      int64_t n, int threads) {
-  // IntelPairHmm.cc:159-165 verbatim in meaning: host libm log10f / log10.
-  const float lf = host_tables_f32().log10_initial;
-  const double ld = host_tables_f64().log10_initial;
-  auto work = [&](int64_t lo, int64_t hi) {
-    for (int64_t i = lo; i < hi; i++) {
-      if (used[i]) out[i] = log10(raw64[i]) - ld;
-      else         out[i] = (double)(log10f(raw32[i]) - lf);
-    }
-  };
-  if (threads <= 1 || n < 16384) { work(0, n); return; }
-  std::vector<std::thread> pool;
-  const int64_t per = (n + threads - 1) / threads;
-  for (int t = 0; t < threads; t++) {
-    const int64_t lo = t * per, hi = std::min<int64_t>(n, lo + per);
-    if (lo >= hi) break;
-    pool.emplace_back(work, lo, hi);
+// IntelPairHmm.cc:159-165 verbatim in meaning (host libm log10f / log10) over the packed raw sums.
+// phase 1 (`early`): finalise the fp32-tagged words and remember where the others are (their fp64 sums are
+// still being computed); phase 2 (`late`): finalise those from the complete copy.  With pending == nullptr
+// one pass does everything.  Returns the number of pairs that took the fp64 path.
+struct HostFinalizer {
+  float lf = host_tables_f32().log10_initial;
+  double ld = host_tables_f64().log10_initial;
+  std::vector<std::vector<int32_t>> pending;  // per slice
+
+  static inline bool is_f32(uint64_t w) { return (w & kPackedF32Tag) == kPackedF32Tag; }
+  inline double fin32(uint64_t w) const {
+    const uint32_t lo32 = (uint32_t)w;
+    float f;
+    memcpy(&f, &lo32, 4);
+    return (double)(log10f(f) - lf);
   }
-  for (auto& th : pool) th.join();
-}
+  inline double fin64(uint64_t w) const {
+    double d;
+    memcpy(&d, &w, 8);
+    return log10(d) - ld;
+  }
+
+  int64_t all(WorkerPool* pool, const uint64_t* packed, double* out, int64_t n, int threads) const {
+    std::atomic<int64_t> n64{0};
+    const std::function<void(int64_t, int64_t)> work = [&](int64_t lo, int64_t hi) {
+      int64_t cnt = 0;
+      for (int64_t i = lo; i < hi; i++) {
+        const uint64_t w = packed[i];
+        if (is_f32(w)) out[i] = fin32(w);
+        else { out[i] = fin64(w); cnt++; }
+      }
+      n64 += cnt;
+    };
+    pool->parallel_for(n, threads, work);
+    return n64.load();
+  }
+  void early(WorkerPool* pool, const uint64_t* packed, double* out, int64_t n, int threads) {
+    const int slices = (threads <= 1 || n < 16384) ? 1 : threads;
+    const int64_t per = (n + slices - 1) / slices;
+    pending.assign((size_t)slices, {});
+    const std::function<void(int64_t, int64_t)> work = [&](int64_t lo, int64_t hi) {
+      std::vector<int32_t>& mine = pending[(size_t)(lo / per)];
+      for (int64_t i = lo; i < hi; i++) {
+        const uint64_t w = packed[i];
+        if (is_f32(w)) out[i] = fin32(w);
+        else mine.push_back((int32_t)i);  // whatever the word holds: the fp64 pass may be writing it right now
+      }
+    };
+    pool->parallel_for(n, threads, work);
+  }
+  int64_t late(WorkerPool* pool, const uint64_t* packed, double* out, int threads) const {
+    int64_t total = 0;
+    for (const auto& v : pending) total += (int64_t)v.size();
+    const std::function<void(int64_t, int64_t)> work = [&](int64_t lo, int64_t hi) {
+      // slice [lo, hi) of the concatenated pending lists
+      int64_t at = 0;
+      for (const auto& v : pending) {
+        const int64_t a = std::max<int64_t>(lo - at, 0), b = std::min<int64_t>(hi - at, (int64_t)v.size());
+        for (int64_t k = a; k < b; k++) out[v[(size_t)k]] = fin64(packed[v[(size_t)k]]);
+        at += (int64_t)v.size();
+      }
+    };
+    pool->parallel_for(total, threads, work);
+    return total;
+  }
+};
 
 }  // namespace
 
@@ -765,6 +898,10 @@ int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
   auto bail = [&](int status) { gklhip_done(c); return status; };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
   if (hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  if (hipEventCreateWithFlags(&c->policy_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->early_copy_done, hipEventDisableTiming) != hipSuccess)
+    return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
   if (hipEventRecord(c->stage_free, c->stream) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventRecord failed"));
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
@@ -780,9 +917,14 @@ int gklhip_done(gklhip_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev, &c->raw32, &c->raw64, &c->used64, &c->list,
                     &c->counters, &c->stream_buf, &c->read_off_dev, &c->out_dev, &c->batch_dev, &c->read_fail,
-                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry})
+                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->res_dev})
     b->release();
   c->stage.release();
+  c->res_pin.release();
+  c->res_pin2.release();
+  if (c->policy_done) (void)hipEventDestroy(c->policy_done);
+  if (c->early_copy_done) (void)hipEventDestroy(c->early_copy_done);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -834,23 +976,47 @@ int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
     HIP_TRY(hipStreamSynchronize(s));
     return GKLHIP_OK;
   }
-  // reference-exact finalisation on the host
-  if ((rc = run_device(c, &db, nullptr, -1, s))) return rc;
-  std::vector<float> r32((size_t)n_pairs);
-  std::vector<double> r64((size_t)n_pairs);
-  std::vector<uint8_t> used((size_t)n_pairs);
-  if (!c->cfg.use_double)
-    HIP_TRY(hipMemcpyAsync(r32.data(), c->raw32.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(r64.data(), c->raw64.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(used.data(), c->used64.p, (size_t)n_pairs, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  // reference-exact finalisation on the host: one packed 8-byte word per pair comes back through pinned
+  // memory.  The fp32 results are final as soon as the policy kernel has run, so they are copied out on a
+  // second stream and finalised by the host WHILE the fp64 recomputation pass runs; only the recomputed
+  // pairs are left for after the last kernel.
   int threads = c->cfg.max_threads;
   if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  finalize_on_host(r32.data(), r64.data(), used.data(), out_host, n_pairs, threads);
-  int64_t nf = 0;
-  for (uint8_t u : used) nf += u;
-  c->stats.n_fallback = nf;
+  const size_t bytes = (size_t)n_pairs * 8;
+  if ((rc = c->res_dev.reserve(bytes))) return rc;
+  if ((rc = c->res_pin.reserve(bytes))) return rc;
+  HostFinalizer fin;
+  if (c->cfg.use_double) {
+    if ((rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+    return GKLHIP_OK;
+  }
+  if ((rc = c->res_pin2.reserve(bytes))) return rc;
+  if ((rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s))) return rc;  // records policy_done
+  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->policy_done, 0));
+  HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+  HIP_TRY(hipEventRecord(c->early_copy_done, c->copy_stream));
+  HIP_TRY(hipMemcpyAsync(c->res_pin2.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));  // after the last kernel
+  HIP_TRY(hipEventSynchronize(c->early_copy_done));
+  fin.early(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+  HIP_TRY(hipStreamSynchronize(s));
+  c->stats.n_fallback = fin.late(&c->workers, c->res_pin2.as<uint64_t>(), out_host, threads);
   return GKLHIP_OK;
+}
+
+void* gklhip_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void gklhip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int gklhip_get_stats(gklhip_ctx* c, gklhip_stats* out) {

@@ -7,6 +7,7 @@ namespace gklhip {
 
 namespace {
 constexpr int kLanes = 64;
+constexpr int kWantedJobs = 4096;
 }
 
 void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off,
@@ -36,6 +37,18 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   }
   if (target_cols < 256) target_cols = 256;
   int n_groups = (int)((total_cols + target_cols - 1) / target_cols);
+  if (rows_per_lane > 0) {
+    // Small batches (one active region of GATK is a few hundred reads x a few dozen haplotypes): a job is one
+    // (chunk, group) and the chip has 1024 SIMDs x 4 wavefront slots, so cut the stream finer -- down to one
+    // haplotype per group -- until there are about that many jobs; the price is 63 fill/drain steps per job.
+    int64_t blocks = 0;
+    for (int r = 0; r < n_reads; r++) {
+      const int nb = blocks_for((int)(read_off[r + 1] - read_off[r]), rows_per_lane);
+      if (nb <= kLanes) blocks += nb;
+    }
+    const int64_t chunks_est = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
+    n_groups = (int)std::max<int64_t>(n_groups, (kWantedJobs + chunks_est - 1) / chunks_est);
+  }
   n_groups = std::max(1, std::min(n_groups, n_haps));
   const int64_t per_group = (total_cols + n_groups - 1) / n_groups;
   p.stream_src.reserve((size_t)total_cols + (size_t)(n_groups + 1) * kLanes);

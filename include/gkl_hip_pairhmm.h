@@ -27,6 +27,7 @@
 #ifndef GKL_HIP_PAIRHMM_H
 #define GKL_HIP_PAIRHMM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -111,8 +112,17 @@ typedef struct {
 int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx);
 int gklhip_done(gklhip_ctx* ctx);
 
-/* Host buffers in, host doubles out (n_reads*n_haps). What the JNI shim calls. */
+/* Host buffers in, host doubles out (n_reads*n_haps). What the JNI shim calls.  The byte arrays
+ * are copied to the device asynchronously; when they live in memory from gklhip_host_alloc the
+ * copies are true DMA (no bounce through the runtime's staging pages).  Results come back as one
+ * 8-byte word per pair through pinned memory owned by the context. */
 int gklhip_compute(gklhip_ctx* ctx, const gklhip_batch* host_batch, double* out_host);
+
+/* Page-locked host memory for a binder's marshalling buffers (replaces the per-array
+ * Get<T>ArrayElements pins of JavaData.h:135-154 with one flat, DMA-able staging area that is
+ * reused across calls).  NULL on failure.  Not tied to a context. */
+void* gklhip_host_alloc(size_t bytes);
+void gklhip_host_free(void* p);
 
 /* Byte arrays and `out_dev` in HBM; launches on `hip_stream` (a hipStream_t; NULL = HIP's
  * default stream) and returns without a host sync when record_events == 0 (the fp64

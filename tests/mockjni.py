@@ -16,7 +16,7 @@ DROP_GCP_FIELD, NULL_READQUALS, SKIP_INIT, SHORT_QUALS, NULL_READ_ELEMENT = 1, 2
 def build():
     src = os.path.join(HERE, "native", "mock_jni.cpp")
     if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
-        subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", src, "-o", SO, "-ldl"], check=True)
+        subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", src, "-o", SO, "-ldl", "-lpthread"], check=True)
 
 
 def run(batch, use_double=False, max_threads=1, flags=0, out_len=None, lib_path=JNI_LIB):
@@ -42,6 +42,30 @@ def run(batch, use_double=False, max_threads=1, flags=0, out_len=None, lib_path=
                          *[a.ctypes.data_as(C.c_void_p) for a in arrs], out.ctypes.data_as(C.c_void_p),
                          int(n), int(flags), ec, em, counters)
     return rc, out[:n], ec.value.decode(), em.value.decode(), (counters[0], counters[1])
+
+
+def run_concurrent(batch, n_threads, iters=1, use_double=False, max_threads=1, lib_path=JNI_LIB):
+    """One initNative, n_threads concurrent callers (own JNIEnv each) over read slices, one doneNative.
+    Returns (rc, out, exception_class, exception_message, wall_ms)."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    build()
+    lib = C.CDLL(SO)
+    out = np.zeros(max(batch.n_pairs, 1), np.float64)
+    ec, em = C.create_string_buffer(256), C.create_string_buffer(512)
+    wall = C.c_double(0.0)
+    ro = np.ascontiguousarray(batch.read_off, np.int64)
+    ho = np.ascontiguousarray(batch.hap_off, np.int64)
+    arrs = [np.ascontiguousarray(a, np.uint8) for a in (batch.read_bases, batch.read_quals, batch.ins_gop,
+                                                        batch.del_gop, batch.gcp, batch.hap_bases)]
+    lib.mockjni_run_concurrent.restype = C.c_int
+    rc = lib.mockjni_run_concurrent(lib_path.encode(), int(use_double), int(max_threads), int(n_threads), int(iters),
+                                    batch.n_reads, batch.n_haps, ro.ctypes.data_as(C.c_void_p),
+                                    ho.ctypes.data_as(C.c_void_p), *[a.ctypes.data_as(C.c_void_p) for a in arrs],
+                                    out.ctypes.data_as(C.c_void_p), ec, em, C.byref(wall))
+    return rc, out[:batch.n_pairs], ec.value.decode(), em.value.decode(), wall.value
 
 
 # ---------------------------------------------------------------- PDHMM

@@ -17,7 +17,9 @@
 #include <map>
 #include <memory>
 #include <set>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../gkl_amd/csrc/jni_min.h"
@@ -233,6 +235,91 @@ int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_rea
     snprintf(exc_msg, 512, "%s", m.exc_msg.c_str());
   }
   if (counters) { counters[0] = m.refs_created; counters[1] = m.refs_deleted; }
+  return rc_;
+}
+
+
+// Concurrent callers (GATK Spark): one initNative, then `n_threads` threads, each with its own JNIEnv,
+// call computeLikelihoodsNative `iters` times on its own contiguous slice of the reads (all haplotypes),
+// then one doneNative.  out = the whole batch's likelihoods, read-major.  Returns 0, or 1/2 like
+// mockjni_run (first failing thread's exception), -1 on load errors.  wall_ms = time of the threaded part.
+int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads, int n_threads, int iters,
+                           int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off,
+                           const uint8_t* rb, const uint8_t* rq, const uint8_t* ri, const uint8_t* rd,
+                           const uint8_t* rc, const uint8_t* hb, double* out, char* exc_class, char* exc_msg,
+                           double* wall_ms) {
+  exc_class[0] = exc_msg[0] = 0;
+  void* h = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { snprintf(exc_msg, 512, "dlopen: %s", dlerror()); return -1; }
+  init_fn f_init = (init_fn)dlsym(h, "Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative");
+  compute_fn f_compute = (compute_fn)dlsym(h, "Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative");
+  done_fn f_done = (done_fn)dlsym(h, "Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative");
+  if (!f_init || !f_compute || !f_done) { snprintf(exc_msg, 512, "missing JNI symbol"); return -1; }
+
+  Mock m;
+  install_table(m);
+  Obj* read_cls = m.make(Obj::CLASS);
+  read_cls->class_fields = {"readBases", "readQuals", "insertionGOP", "deletionGOP", "overallGCP"};
+  Obj* hap_cls = m.make(Obj::CLASS);
+  hap_cls->class_fields = {"haplotypeBases"};
+  std::vector<Obj*> read_holders;
+  for (int r = 0; r < n_reads; r++) {
+    const int64_t a = read_off[r], n = read_off[r + 1] - a;
+    Obj* holder = m.make(Obj::HOLDER);
+    holder->fields["readBases"] = bytes_obj(m, rb + a, n);
+    holder->fields["readQuals"] = bytes_obj(m, rq + a, n);
+    holder->fields["insertionGOP"] = bytes_obj(m, ri + a, n);
+    holder->fields["deletionGOP"] = bytes_obj(m, rd + a, n);
+    holder->fields["overallGCP"] = bytes_obj(m, rc + a, n);
+    read_holders.push_back(holder);
+  }
+  Obj* haps = m.make(Obj::OBJARRAY);
+  for (int k = 0; k < n_haps; k++) {
+    Obj* holder = m.make(Obj::HOLDER);
+    holder->fields["haplotypeBases"] = bytes_obj(m, hb + hap_off[k], hap_off[k + 1] - hap_off[k]);
+    haps->elems.push_back(holder);
+  }
+  f_init(&m.env, nullptr, reinterpret_cast<jclass>(read_cls), reinterpret_cast<jclass>(hap_cls),
+         use_double ? JNI_TRUE : JNI_FALSE, max_threads);
+  if (m.pending) {
+    snprintf(exc_class, 256, "%s", m.exc_class.c_str());
+    snprintf(exc_msg, 512, "%s", m.exc_msg.c_str());
+    return 1;
+  }
+  std::vector<std::unique_ptr<Mock>> envs;
+  std::vector<Obj*> slices, results;
+  std::vector<int> first(n_threads + 1, 0);
+  for (int t = 0; t < n_threads; t++) {
+    envs.emplace_back(new Mock());
+    install_table(*envs.back());
+    first[t + 1] = (int)((int64_t)n_reads * (t + 1) / n_threads);
+    Obj* arr = envs.back()->make(Obj::OBJARRAY);
+    for (int r = first[t]; r < first[t + 1]; r++) arr->elems.push_back(read_holders[r]);
+    Obj* res = envs.back()->make(Obj::DOUBLES);
+    res->doubles.assign((size_t)(first[t + 1] - first[t]) * n_haps, -12345.0);
+    slices.push_back(arr);
+    results.push_back(res);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> pool;
+  for (int t = 0; t < n_threads; t++)
+    pool.emplace_back([&, t] {
+      for (int k = 0; k < iters && !envs[t]->pending; k++)
+        f_compute(&envs[t]->env, nullptr, reinterpret_cast<jobjectArray>(slices[t]),
+                  reinterpret_cast<jobjectArray>(haps), reinterpret_cast<jdoubleArray>(results[t]));
+    });
+  for (auto& th : pool) th.join();
+  if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  f_done(&m.env, nullptr);
+  int rc_ = 0;
+  for (int t = 0; t < n_threads; t++) {
+    memcpy(out + (size_t)first[t] * n_haps, results[t]->doubles.data(), sizeof(double) * results[t]->doubles.size());
+    if (envs[t]->pending && rc_ == 0) {
+      rc_ = 2;
+      snprintf(exc_class, 256, "%s", envs[t]->exc_class.c_str());
+      snprintf(exc_msg, 512, "%s", envs[t]->exc_msg.c_str());
+    }
+  }
   return rc_;
 }
 

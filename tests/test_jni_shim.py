@@ -102,6 +102,19 @@ def test_jni_argument_errors():
     assert rc == 2 and cls == "java/lang/IllegalArgumentException" and np.all(out == -12345.0)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_threads,slots", [(6, None), (3, "1")])
+def test_jni_concurrent_callers_get_their_own_slot(oracle, n_threads, slots, monkeypatch):
+    # computeLikelihoodsNative is re-entrant in the reference (SURVEY 8b "Threading"); here every concurrent
+    # caller leases a slot (context + stream + pinned arenas; GKL_HIP_SLOTS bounds them, callers queue beyond it)
+    if slots:
+        monkeypatch.setenv("GKL_HIP_SLOTS", slots)
+    b = make_batch("hc", 240, 12, seed=77)
+    rc, out, cls, msg, _ = mockjni.run_concurrent(b, n_threads=n_threads, iters=4, max_threads=2)
+    assert rc == 0, (cls, msg)
+    assert out.tobytes() == oracle.batch(b, n_threads=8).tobytes()
+
+
 def test_utils_library_gates_on_the_gpu():
     """libgkl_utils.so replacement: IntelPairHmm.load() asks isAvxSupported() first
     (IntelPairHmm.java:66-75); here that answers "is a gfx950 device usable"."""
