@@ -500,8 +500,15 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 // Rows per lane.  fp32 main pass: 8 (one chunk per wavefront; 4 = the dual-chunk packed-math
 // kernel, opt-in).  fp64 passes: 4.  A read of length R needs R+1 rows; reads that exceed
 // 64*RPL rows go to the striped long-read kernel of the same RPL.
-constexpr int kRplF64 = 4;
-int pick_rpl_f32(int forced) { return forced == 4 ? 4 : 8; }
+#ifndef GKL_RPL_F64
+#define GKL_RPL_F64 6
+#endif
+constexpr int kRplF64 = GKL_RPL_F64;
+#ifndef GKL_RPL_F32
+#define GKL_RPL_F32 8
+#endif
+constexpr int kRplF32 = GKL_RPL_F32;
+int pick_rpl_f32(int forced) { return forced == 4 ? 4 : kRplF32; }
 
 // The whole device-side pipeline on stream `s`; `db` holds DEVICE byte arrays, host offsets.
 int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int finalize_mode, hipStream_t s) {
@@ -659,14 +666,14 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.tab = c->dt64;
     a.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
     a.raw = c->raw64.as<double>();
-    if (n_main_blocks > 0) launch_stream<double, 4>(a, fma, n_main_blocks, s);
+    if (n_main_blocks > 0) launch_stream<double, kRplF64>(a, fma, n_main_blocks, s);
     if (n_long_main > 0) {
       FwdArgs<double> la = a;
       la.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.long_lanes);
       la.jobs = reinterpret_cast<const FwdJob*>(dp + L.long_jobs);
       la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
       la.job_next = c->counters.as<int32_t>() + 7;
-      launch_long<double, 4>(la, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
+      launch_long<double, kRplF64>(la, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
@@ -679,7 +686,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.raw = c->raw32.as<float>();
     if (n_main_blocks > 0) {
       if (rpl_main == 4) launch_stream2<4>(a, fma, ((plan.n_chunks + 1) / 2) * (int)plan.groups.size(), s);
-      else               launch_stream<float, 8>(a, fma, n_main_blocks, s);
+      else               launch_stream<float, kRplF32>(a, fma, n_main_blocks, s);
     }
     if (n_long_main > 0) {
       FwdArgs<float> la = a;
@@ -688,7 +695,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
       la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
       la.job_next = c->counters.as<int32_t>() + 7;
       if (rpl_main == 4) launch_long<float, 4>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
-      else               launch_long<float, 8>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
+      else               launch_long<float, kRplF32>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa);
@@ -728,7 +735,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     d.chunk_lanes = c->lanes2.as<LaneSlot>();
     d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
     d.jobs = c->jobs.as<FwdJob>();
-    launch_jobs<double, 4>(d, fma, (int)std::min<int64_t>(n_pairs, 256 * 16), s);
+    launch_jobs<double, kRplF64>(d, fma, (int)std::min<int64_t>(n_pairs, 256 * 16), s);
     if (n_long64 > 0) {
       // reads too long for a chunk: one pseudo-chunk each, same run detection, striped kernel
       if ((rc = c->jobs_long.reserve((size_t)n_long64 * ((size_t)(n_haps + 1) / 2 + n_groups) * sizeof(FwdJob)))) return rc;
@@ -743,7 +750,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
       ld.jobs = c->jobs_long.as<FwdJob>();
       ld.job_count = cnts + 8;
       ld.job_next = cnts + 9;
-      launch_long<double, 4>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
+      launch_long<double, kRplF64>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
