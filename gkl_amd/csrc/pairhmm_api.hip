@@ -208,6 +208,35 @@ __global__ void build_jobs_kernel(const LaneSlot* __restrict__ lanes, const int3
   }  // chunk loop
 }
 
+// Packed fp64 fallback, step 3 (device): order the job list by decreasing length (counting sort on
+// columns / 128, one block), so that the persistent wavefronts of the jobs kernel start the long runs
+// first and the kernel's tail is made of short ones.
+constexpr int kJobClasses = 64;
+__global__ __launch_bounds__(1024) void sort_jobs_kernel(const FwdJob* __restrict__ jobs, const int32_t* __restrict__ job_count,
+                                                         const int32_t* __restrict__ hap_pos,
+                                                         const int32_t* __restrict__ hap_len, FwdJob* __restrict__ sorted) {
+  __shared__ int32_t cnt[kJobClasses], base[kJobClasses];
+  const int n = *job_count;
+  if (threadIdx.x < kJobClasses) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  auto cls_of = [&](const FwdJob& j) {
+    const int cols = hap_pos[j.hap_end - 1] + hap_len[j.hap_end - 1] - hap_pos[j.hap_begin];
+    const int c = cols >> 7;
+    return kJobClasses - 1 - (c < kJobClasses - 1 ? c : kJobClasses - 1);  // class 0 = longest
+  };
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&cnt[cls_of(jobs[i])], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = 0; c < kJobClasses; c++) { base[c] = acc; acc += cnt[c]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const FwdJob j = jobs[i];
+    sorted[atomicAdd(&base[cls_of(j)], 1)] = j;
+  }
+}
+
 // ---- packed fp64 fallback, step 1 (device): order the affected reads by how many haplotypes
 // they failed against (counting sort, most first) and pack them, window by window, into 64-lane
 // chunks with best-fit-decreasing -- the device twin of pack_reads_windowed(), so the pass needs
@@ -504,6 +533,7 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 #define GKL_RPL_F64 6
 #endif
 constexpr int kRplF64 = GKL_RPL_F64;
+constexpr int kTargetCols = 3072;  // columns of a full-size haplotype group (sweep 1024..8000: flat optimum 2048..4096)
 #ifndef GKL_RPL_F32
 #define GKL_RPL_F32 8
 #endif
@@ -527,7 +557,8 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   Plan& plan = c->plan;
   const int rpl64 = kRplF64;
   const int rpl_main = use_double ? rpl64 : pick_rpl_f32(c->cfg.rows_per_lane);
-  build_plan(n_reads, n_haps, db->read_off, db->hap_off, rpl_main, 4096, &plan);
+  static const int target_cols_env = [] { const char* v = getenv("GKLHIP_TARGET_COLS"); return v ? atoi(v) : 0; }();
+  build_plan(n_reads, n_haps, db->read_off, db->hap_off, rpl_main, target_cols_env > 0 ? target_cols_env : kTargetCols, &plan);
   // Long reads: pseudo-chunks (lane 0 names the read) + one striped job per (read, stream group)
   // for the main pass; for the fp64 fallback the same pseudo-chunks feed build_jobs_kernel.
   std::vector<PlanLane>& long_lanes = c->long_lanes;
@@ -714,7 +745,8 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     if ((rc = c->fail_hist.reserve((size_t)(2 * (n_haps + 2)) * 4))) return rc;
     if ((rc = c->fail_order.reserve((size_t)n_reads * 4))) return rc;
     if ((rc = c->lanes2.reserve((size_t)n_reads * kLanes * sizeof(LaneSlot)))) return rc;
-    if ((rc = c->jobs.reserve((size_t)n_reads * ((size_t)(n_haps + 1) / 2 + n_groups) * sizeof(FwdJob)))) return rc;
+    const size_t max_jobs = (size_t)n_reads * ((size_t)(n_haps + 1) / 2 + n_groups);
+    if ((rc = c->jobs.reserve(2 * max_jobs * sizeof(FwdJob)))) return rc;  // as built + sorted by length
     int32_t* hist = c->fail_hist.as<int32_t>();
     int32_t* pos = hist + (n_haps + 2);
     int32_t* cnts = c->counters.as<int32_t>();  // [0] pairs [2] jobs [3] next job [4] fail reads [5] chunks
@@ -732,9 +764,12 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
                        (size_t)(kLanes + 1) * 4 + (size_t)n_haps, s, c->lanes2.as<LaneSlot>(), cnts + 5,
                        c->used64.as<uint8_t>(), n_haps, reinterpret_cast<const int32_t*>(dp + L.hap_orig),
                        reinterpret_cast<const int32_t*>(dp + L.hap_group), c->jobs.as<FwdJob>(), cnts + 2);
+    hipLaunchKernelGGL(sort_jobs_kernel, dim3(1), dim3(1024), 0, s, c->jobs.as<FwdJob>(), cnts + 2,
+                       reinterpret_cast<const int32_t*>(dp + L.hap_pos), reinterpret_cast<const int32_t*>(dp + L.hap_len),
+                       c->jobs.as<FwdJob>() + max_jobs);
     d.chunk_lanes = c->lanes2.as<LaneSlot>();
     d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
-    d.jobs = c->jobs.as<FwdJob>();
+    d.jobs = c->jobs.as<FwdJob>() + max_jobs;
     launch_jobs<double, kRplF64>(d, fma, (int)std::min<int64_t>(n_pairs, 256 * 16), s);
     if (n_long64 > 0) {
       // reads too long for a chunk: one pseudo-chunk each, same run detection, striped kernel
@@ -1056,7 +1091,7 @@ int gklhip_plan_describe(int32_t n_reads, int32_t n_haps, const int64_t* read_of
   if (n_reads < 0 || n_haps < 0 || !read_off || !hap_off || (rows_per_lane != 4 && rows_per_lane != 8))
     return -fail(GKLHIP_ERR_INVALID_ARG, "bad arguments to gklhip_plan_describe");
   Plan p;
-  build_plan(n_reads, n_haps, read_off, hap_off, rows_per_lane, 4096, &p);
+  build_plan(n_reads, n_haps, read_off, hap_off, rows_per_lane, kTargetCols, &p);
   if (n_groups_out) *n_groups_out = (int32_t)p.groups.size();
   if (n_long_out) *n_long_out = (int32_t)p.long_reads.size();
   if (lanes_out) {

@@ -693,8 +693,8 @@ __global__ __launch_bounds__(64) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
   using Job = WaveJob<T, RPL, FMA>;
   __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
-  const int chunk = blockIdx.x / a.n_groups;
-  const int g = blockIdx.x - chunk * a.n_groups;
+  const int g = blockIdx.x / a.n_chunks;  // group-major: the groups come in order of decreasing length
+  const int chunk = blockIdx.x - g * a.n_chunks;
   const HapGroup grp = a.groups[g];
   Job job;
   job.lds = lds;
@@ -709,8 +709,9 @@ __global__ __launch_bounds__(64) void pairhmm_fwd_stream2_kernel(FwdArgs<float> 
   using Job = WaveJob2<RPL, FMA>;
   __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
-  const int pair = blockIdx.x / a.n_groups;
-  const int g = blockIdx.x - pair * a.n_groups;
+  const int n_pairs_of_chunks = (a.n_chunks + 1) / 2;
+  const int g = blockIdx.x / n_pairs_of_chunks;
+  const int pair = blockIdx.x - g * n_pairs_of_chunks;
   const HapGroup grp = a.groups[g];
   const int ca = 2 * pair, cb = 2 * pair + 1;
   LaneSlot sa = a.chunk_lanes[(int64_t)ca * kLanes + lane];

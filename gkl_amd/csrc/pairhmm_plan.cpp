@@ -37,6 +37,7 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   }
   if (target_cols < 256) target_cols = 256;
   int n_groups = (int)((total_cols + target_cols - 1) / target_cols);
+  bool equal_split = true;
   if (rows_per_lane > 0) {
     // Small batches (one active region of GATK is a few hundred reads x a few dozen haplotypes): a job is one
     // (chunk, group) and the chip has 1024 SIMDs x 4 wavefront slots, so cut the stream finer -- down to one
@@ -47,20 +48,38 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
       if (nb <= kLanes) blocks += nb;
     }
     const int64_t chunks_est = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
-    n_groups = (int)std::max<int64_t>(n_groups, (kWantedJobs + chunks_est - 1) / chunks_est);
+    const int64_t by_jobs = (kWantedJobs + chunks_est - 1) / chunks_est;
+    if (by_jobs >= n_groups) n_groups = (int)by_jobs;
+    else equal_split = false;
   }
   n_groups = std::max(1, std::min(n_groups, n_haps));
-  const int64_t per_group = (total_cols + n_groups - 1) / n_groups;
-  p.stream_src.reserve((size_t)total_cols + (size_t)(n_groups + 1) * kLanes);
+  // Group sizes.  Jobs are dispatched group by group (all chunks of group 0, then of group 1, ...), and the
+  // kernel ends when the slowest wavefront does, so big batches get full-size groups first and a short tail of
+  // halving groups (T/2, T/4, T/8, T/8): the last jobs in flight are 8x shorter than the first ones.
+  std::vector<int64_t> want;
+  if (equal_split || total_cols < 3 * (int64_t)target_cols) {
+    const int64_t per_group = (total_cols + n_groups - 1) / n_groups;
+    want.assign((size_t)n_groups, per_group);
+  } else {
+    const int64_t tail[4] = {target_cols / 2, target_cols / 4, target_cols / 8, target_cols / 8};
+    const int64_t head = total_cols - target_cols;  // the tail sums to target_cols
+    const int n_big = (int)std::max<int64_t>(1, (head + target_cols / 2) / target_cols);
+    want.assign((size_t)n_big, (head + n_big - 1) / n_big);
+    want.insert(want.end(), tail, tail + 4);
+  }
+  p.stream_src.reserve((size_t)total_cols + (want.size() + (size_t)n_haps / 8 + 2) * kLanes);
   {
     int h = 0;
+    size_t gi = 0;
     while (h < n_haps) {
       PlanGroup g;
       g.hap_begin = h;
       g.stream_begin = (int32_t)p.stream_src.size();
       g.pad_ = 0;
       int64_t cols = 0;
-      // at least one haplotype per group; stop once the group reached its share
+      const bool last = gi + 1 >= want.size();
+      const int64_t share = want[std::min(gi, want.size() - 1)];
+      // at least one haplotype per group; stop once the group reached its share (the last group takes the rest)
       do {  // h is a stream-order index here
         p.hap_pos[h] = (int32_t)p.stream_src.size();
         p.hap_group[h] = (int32_t)p.groups.size();
@@ -69,10 +88,11 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
         p.stream_src.push_back(-2 - h);  // separator of stream-order hap h
         cols += p.hap_len[h] + 1;
         h++;
-      } while (h < n_haps && cols < per_group);
+      } while (h < n_haps && (last || cols + (p.hap_len[h] + 1) / 2 < share));
       g.hap_end = h;
       for (int i = 0; i < kLanes; i++) p.stream_src.push_back(-1);  // drain room
       p.groups.push_back(g);
+      gi++;
     }
   }
 
