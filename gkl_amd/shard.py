@@ -71,6 +71,70 @@ def gather_to_root(local, rows_per_rank: Sequence[int], n_haps: int, dist_module
     return None
 
 
+class PipelinedGather:
+    """The same exchange step for a STREAM of equal-shaped batches: the gather of step k is issued
+    asynchronously and runs (on RCCL's own stream) while step k+1 computes; `depth` result buffers
+    rotate, and a buffer is only written again after the gather that read it has completed.
+
+        g = PipelinedGather(rows_per_rank, n_haps, device, dist)
+        for k in range(steps):
+            out = g.buffer(k)          # waits (stream-level for RCCL) for the gather of step k-depth
+            compute_into(out)
+            g.submit(k)
+        full = g.finish()              # last step's concatenated result on root, None elsewhere
+    """
+
+    def __init__(self, rows_per_rank: Sequence[int], n_haps: int, device, dist_module=None, root: int = 0,
+                 depth: int = 2):
+        import torch
+        self.dist = dist_module
+        if self.dist is None:
+            import torch.distributed as dist
+            self.dist = dist
+        self.rows, self.n_haps, self.root, self.depth = list(rows_per_rank), n_haps, root, depth
+        self.world, self.rank = self.dist.get_world_size(), self.dist.get_rank()
+        self.n_local = self.rows[self.rank] * n_haps
+        self.max_n = max(self.rows) * n_haps
+        # local buffers are allocated at the padded size; the compute writes the first n_local entries
+        self.local = [torch.zeros(self.max_n, dtype=torch.float64, device=device) for _ in range(depth)]
+        self.parts = None
+        if self.rank == root and self.world > 1:
+            self.parts = [[torch.empty(self.max_n, dtype=torch.float64, device=device) for _ in range(self.world)]
+                          for _ in range(depth)]
+        self.works = [None] * depth
+        self.last = -1
+
+    def buffer(self, k: int):
+        w = self.works[k % self.depth]
+        if w is not None:
+            w.wait()
+            self.works[k % self.depth] = None
+        return self.local[k % self.depth][: self.n_local]
+
+    def submit(self, k: int) -> None:
+        self.last = k
+        if self.world == 1:
+            return
+        slot = k % self.depth
+        self.works[slot] = self.dist.gather(self.local[slot], gather_list=self.parts[slot] if self.parts else None,
+                                            dst=self.root, async_op=True)
+
+    def finish(self):
+        import torch
+        for i, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[i] = None
+        if self.last < 0:
+            return None
+        slot = self.last % self.depth
+        if self.world == 1:
+            return self.local[slot][: self.n_local]
+        if self.rank != self.root:
+            return None
+        return torch.cat([p[: self.rows[g] * self.n_haps] for g, p in enumerate(self.parts[slot])])
+
+
 def compute_sharded(batch: FlatBatch, compute_local: Callable, device: str = "cpu",
                     dist_module=None) -> Optional[np.ndarray]:
     """Shard `batch` over the initialised process group, run `compute_local(shard) -> float64

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gkl_amd.shard import compute_sharded, partition_reads, shard_batch
+from gkl_amd.shard import PipelinedGather, compute_sharded, partition_reads, shard_batch
 from gkl_amd.synth import make_batch
 
 
@@ -52,6 +52,20 @@ def _worker(rank, world, port, ret):
             ret["ok"] = bool(full is not None and full.tobytes() == expect.tobytes())
         else:
             assert full is None
+        # the pipelined variant bench.py uses: 5 steps, 2 rotating buffers, every step a different batch
+        shard, bounds = shard_batch(batch, rank, world)
+        rows = [bounds[g + 1] - bounds[g] for g in range(world)]
+        g = PipelinedGather(rows, batch.n_haps, "cpu", dist)
+        for k in range(5):
+            out = g.buffer(k)
+            out.copy_(torch.from_numpy(oracle.batch(shard, n_threads=1)) + float(k))
+            g.submit(k)
+        last = g.finish()
+        if rank == 0:
+            ret["ok_pipelined"] = bool(last is not None and
+                                       np.array_equal(last.numpy(), oracle.batch(batch, n_threads=1) + 4.0))
+        else:
+            assert last is None
     finally:
         dist.destroy_process_group()
 
@@ -65,3 +79,4 @@ def test_world_size_2_gloo_gather_matches_single_process():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret.get("ok") is True
+    assert ret.get("ok_pipelined") is True
