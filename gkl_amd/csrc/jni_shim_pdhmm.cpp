@@ -100,7 +100,12 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_initNative(JNIEnv* en
   if (g.ctx) { gklhip_pdhmm_done(g.ctx); g.ctx = nullptr; }
   const char* dev = getenv("GKL_HIP_DEVICE");
   const int st = gklhip_pdhmm_init((dev && *dev) ? atoi(dev) : -1, &g.ctx);
-  if (st != GKLHIP_OK) { g.ctx = nullptr; throw_status(env, st); }
+  if (st != GKLHIP_OK) { g.ctx = nullptr; throw_status(env, st); return; }
+  const char* fm = getenv("GKL_HIP_FMA_MODE");  // 1 (default): GKL's AVX-512 arithmetic, 0: its AVX2 arithmetic
+  if (fm && *fm) {
+    const int st2 = gklhip_pdhmm_set_fma_mode(g.ctx, atoi(fm));
+    if (st2 != GKLHIP_OK) throw_status(env, st2);
+  }
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNative(

@@ -103,6 +103,7 @@ struct gklhip_pdhmm_ctx {
   std::mutex mu;
   Buf tables, inputs, entries, sums, misc, carry, jobs;
   float last_ms = 0.f;
+  int fma_mode = 1;  // 1 = arithmetic of GKL's AVX-512 object (default), 0 = of its AVX2 object
 };
 
 extern "C" {
@@ -157,6 +158,14 @@ int gklhip_pdhmm_done(gklhip_pdhmm_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  return GKLHIP_OK;
+}
+
+int gklhip_pdhmm_set_fma_mode(gklhip_pdhmm_ctx* c, int fma_mode) {
+  if (!c) return pd_fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
+  if (fma_mode != 0 && fma_mode != 1) return pd_fail(GKLHIP_ERR_INVALID_ARG, "fma_mode %d (0 or 1)", fma_mode);
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->fma_mode = fma_mode;
   return GKLHIP_OK;
 }
 
@@ -286,7 +295,8 @@ int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, doubl
 
   hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, a);
   PD_HIP_TRY(hipEventRecord(c->ev0, s));
-  hipLaunchKernelGGL(pdhmm_fwd_kernel, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
+  if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
+  else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
   PD_HIP_TRY(hipEventRecord(c->ev1, s));
   PD_HIP_TRY(hipGetLastError());
   std::vector<double> sums(n);

@@ -89,6 +89,9 @@ __global__ void pdhmm_entries_kernel(PdArgs a) {
 
 __device__ __forceinline__ double pd_max(double x, double y) { return x > y ? x : y; }  // _mm256_max_pd on finite values
 
+// FMA = true: the arithmetic of GKL's AVX-512 object (gcc contracts a*b + c*d to fma(c, d, a*b));
+// FMA = false: of its AVX2 object (separate multiplies and adds).  See oracle/pdhmm_oracle.c semantics 2 / 0.
+template <bool FMA>
 struct PdJob {
   static constexpr int RPL = kPdRpl;
   // six matrices, per row: match, insertion, deletion and their branch copies
@@ -186,11 +189,17 @@ struct PdJob {
       const uint32_t xi = xinfo[s];
       const bool match = ((xi & 0xffu) == y) || (xi & 0x8000u) || y_is_n || (((xi >> 8) & allele) != 0u);
       const double pr = off ? 0.0 : (match ? ptrue[s] : pfalse[s]);
-      nmm[s] = pr * (mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]));   // pdhmm.h:427-429
-      ndm[s] = mmL * tmd[s] + dmL * tdd[s];                            // :431
-      const double ia = del_end ? pd_max(bmmT, mmT) : mmT;            // :434-443
+      const double ia = del_end ? pd_max(bmmT, mmT) : mmT;            // pdhmm.h:434-443
       const double ib = del_end ? pd_max(bimT, imT) : imT;
-      nim[s] = ia * tmi[s] + ib * tii[s];
+      if (FMA) {
+        nmm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
+        ndm[s] = __builtin_fma(dmL, tdd[s], mmL * tmd[s]);
+        nim[s] = __builtin_fma(ib, tii[s], ia * tmi[s]);
+      } else {
+        nmm[s] = pr * (mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]));   // :427-429
+        ndm[s] = mmL * tmd[s] + dmL * tdd[s];                            // :431
+        nim[s] = ia * tmi[s] + ib * tii[s];
+      }
     }
 #pragma unroll
     for (int s = 0; s < RPL; s++) {
@@ -259,11 +268,13 @@ struct PdJob {
 };
 
 // Persistent wavefronts pull jobs (see PdArgs).
+template <bool FMA>
 __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_condition) {
   const int lane = threadIdx.x;
   const int64_t cstride = 6 * (int64_t)a.carry_len + 64;
   double* my = a.carry + (int64_t)blockIdx.x * 2 * cstride;
-  PdJob job;
+  using Job = PdJob<FMA>;
+  Job job;
   for (;;) {
     int j = 0;
     if (lane == 0) j = atomicAdd(a.next, 1);
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_con
       const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
       const bool active = sl.read >= 0;
       const int p = active ? sl.read : rep;
-      const int n_blocks = ((int)a.read_len[p] + PdJob::RPL) / PdJob::RPL;
+      const int n_blocks = ((int)a.read_len[p] + Job::RPL) / Job::RPL;
       const double init = init_condition / (double)a.hap_len[p];  // pdhmm.h:867-878 (IEEE division, as on the host)
       job.setup(a, p, sl.block, n_blocks, active, init);
       // block k of a pair sees column j at step j + k
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_con
     const uint32_t* ep = a.entries + (int64_t)rep * a.entry_stride + kLanes - lane;  // lane l sees column j at step j + l
     const int n_steps = H + kLanes - 1;
     const int R = (int)a.read_len[rep];
-    const int n_blocks = (R + PdJob::RPL) / PdJob::RPL;
+    const int n_blocks = (R + Job::RPL) / Job::RPL;
     const int n_stripes = (n_blocks + kLanes - 1) / kLanes;
     const int first_cnt = n_blocks - kLanes * (n_stripes - 1);
     for (int st = 0; st < n_stripes; st++) {

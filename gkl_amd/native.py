@@ -254,6 +254,8 @@ def load_pdhmm_library(path: Optional[str] = None):
     lib = C.CDLL(p)
     lib.gklhip_pdhmm_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.gklhip_pdhmm_init.restype = C.c_int
+    lib.gklhip_pdhmm_set_fma_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.gklhip_pdhmm_set_fma_mode.restype = C.c_int
     lib.gklhip_pdhmm_compute.argtypes = [C.c_void_p, C.POINTER(CPdhmmBatch), C.c_void_p]
     lib.gklhip_pdhmm_compute.restype = C.c_int
     lib.gklhip_pdhmm_done.argtypes = [C.c_void_p]
@@ -279,13 +281,17 @@ def pdhmm_host_table(which: int) -> np.ndarray:
 class PdhmmContext:
     """One gklhip_pdhmm context (= IntelPDHMM.initNative)."""
 
-    def __init__(self, device: int = -1):
+    def __init__(self, device: int = -1, fma_mode: int = 1):
+        """fma_mode 1: bit-identical to GKL's AVX-512 PDHMM object, 0: to its AVX2 object."""
         self.lib = load_pdhmm_library()
         h = C.c_void_p()
         st = self.lib.gklhip_pdhmm_init(device, C.byref(h))
         if st != OK:
             self._raise(st)
         self.handle = h
+        st = self.lib.gklhip_pdhmm_set_fma_mode(self.handle, int(fma_mode))
+        if st != OK:
+            self._raise(st)
 
     def _raise(self, status):
         msg = (self.lib.gklhip_pdhmm_last_error() or b"").decode()

@@ -9,7 +9,8 @@
  *                         (pdhmm.h:1133-1290), on the padded 1:1 batch IntelPDHMM.computePDHMM passes
  *                         (src/main/java/com/intel/gkl/pdhmm/IntelPDHMM.java:147-186)
  *   gklhip_pdhmm_done     doneNative
- * Arithmetic: the reference's vector (AVX2) kernels for every pair; see gkl_amd/csrc/pdhmm_kernel.h.
+ * Arithmetic: the reference's vector kernels for every pair -- by default as its AVX-512 object computes
+ * (gcc-contracted FMAs), optionally as its AVX2 object does; see gkl_amd/csrc/pdhmm_kernel.h.
  */
 #ifndef GKL_HIP_PDHMM_H
 #define GKL_HIP_PDHMM_H
@@ -41,6 +42,10 @@ typedef struct {
 } gklhip_pdhmm_batch;
 
 int gklhip_pdhmm_init(int device /* -1 = current */, gklhip_pdhmm_ctx** out_ctx);
+/* 1 (default) = bit-identical to GKL's AVX-512 PDHMM object (avx512_impl.cc: a*b + c*d contracted to
+ * fma(c, d, a*b)); 0 = bit-identical to its AVX2 object (avx2_impl.cc: no FMA).  Same switch as
+ * gklhip_config.fma_mode of the PairHMM. */
+int gklhip_pdhmm_set_fma_mode(gklhip_pdhmm_ctx* ctx, int fma_mode);
 /* Host buffers in, out_host[batch] = log10 likelihoods. Negative ins/del/gcp quals ->
  * GKLHIP_ERR_INVALID_ARG (PDHMM_INPUT_DATA_ERROR in the reference). */
 int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_batch* batch, double* out_host);

@@ -63,7 +63,7 @@ def random_pd_batch(rng, n, read_len=(1, 60), hap_len=(1, 80), flag_rate=0.15, l
 def test_pdhmm_oracle_matches_expected_files(pd_oracle):
     for f in FILES:
         b, exp = load_pdhmm_file(f)
-        for sem in (0, 1):
+        for sem in (0, 1, 2):
             st, out = pd_oracle.compute(b, semantics=sem)
             assert st == 0 and np.max(np.abs(out - exp)) <= TOL, (f, sem)
 
@@ -85,7 +85,24 @@ def test_pdhmm_oracle_bit_identical_to_reference_kernels(pd_oracle, pd_reference
         if pd_reference.has_avx512():
             st, ref2 = pd_reference.compute(b, engine=2)
             nv2 = (b.batch // pd_reference.simd_width(2)) * pd_reference.simd_width(2)
-            assert st == 0 and np.max(np.abs(ref2[:nv2] - vec[:nv2])) < 1e-9  # gcc contracts FMAs in that TU
+            _, vec_fma = pd_oracle.compute(b, semantics=2)  # gcc contracts FMAs in that TU: semantics 2
+            assert st == 0 and ref2[:nv2].tobytes() == vec_fma[:nv2].tobytes()
+            assert ref2[nv2:].tobytes() == ser[nv2:].tobytes()
+
+
+def test_pdhmm_oracle_fma_pattern_is_the_avx512_objects(pd_oracle, pd_reference):
+    # 4000 random pairs: semantics 2 (fma(c, d, a*b) for a*b + c*d) reproduces GKL's AVX-512 object bit for
+    # bit, the unfused semantics 0 does not (and reproduces the AVX2 object instead)
+    if not pd_reference.has_avx512():
+        pytest.skip("host CPU has no AVX-512")
+    b = random_pd_batch(np.random.RandomState(5), 4000, read_len=(20, 150), hap_len=(20, 200))
+    _, ref512 = pd_reference.compute(b, engine=2)
+    _, ref2 = pd_reference.compute(b, engine=1)
+    _, fused = pd_oracle.compute(b, semantics=2)
+    _, plain = pd_oracle.compute(b, semantics=0)
+    assert fused.tobytes() == ref512.tobytes()      # 4000 = 500 full groups of 8: no scalar tail
+    assert plain.tobytes() == ref2.tobytes()
+    assert plain.tobytes() != fused.tobytes()
 
 
 def holders_fixture_batch():
@@ -126,10 +143,14 @@ def test_pdhmm_no_gpu_fails_loudly():
 
 
 # ------------------------------------------------------------------ HIP parity (GPU)
-@pytest.fixture(scope="module")
-def pd_ctx():
+SEMANTICS_OF_FMA_MODE = {1: 2, 0: 0}  # fma_mode of the HIP path -> oracle semantics (AVX-512 / AVX2 arithmetic)
+
+
+@pytest.fixture(scope="module", params=[1, 0], ids=["avx512-arith", "avx2-arith"])
+def pd_ctx(request):
     from gkl_amd import native
-    with native.PdhmmContext() as c:
+    with native.PdhmmContext(fma_mode=request.param) as c:
+        c.sem = SEMANTICS_OF_FMA_MODE[request.param]
         yield c
 
 
@@ -139,8 +160,8 @@ def test_pdhmm_gpu_fixture_files(pd_ctx, pd_oracle, fname):
     b, exp = load_pdhmm_file(fname)
     out = pd_ctx.compute(b)
     assert np.max(np.abs(out - exp)) <= TOL                      # the reference's own bar
-    _, vec = pd_oracle.compute(b, semantics=0)
-    assert out.tobytes() == vec.tobytes()                         # and bit-exact vs GKL's AVX2 arithmetic
+    _, vec = pd_oracle.compute(b, semantics=pd_ctx.sem)
+    assert out.tobytes() == vec.tobytes()                         # and bit-exact vs GKL's AVX-512 / AVX2 arithmetic
 
 
 @pytest.mark.gpu
@@ -151,7 +172,7 @@ def test_pdhmm_gpu_random_batches_bit_exact(pd_ctx, pd_oracle, kw):
     rng = np.random.RandomState(77)
     b = random_pd_batch(rng, 96, **kw)
     out = pd_ctx.compute(b)
-    st, vec = pd_oracle.compute(b, semantics=0)
+    st, vec = pd_oracle.compute(b, semantics=pd_ctx.sem)
     assert st == 0 and out.tobytes() == vec.tobytes()
     # (the reference's scalar engine keeps the deletion state across rows and can differ from its own
     #  vector kernels by 0.2 on such random flag patterns; parity is defined against the vector kernels)
@@ -181,7 +202,7 @@ def test_pdhmm_gpu_cross_product_shares_haplotypes(pd_ctx, pd_oracle, shape):
     n_reads, n_haps, rl, hl = shape
     b = cross_product(np.random.RandomState(n_reads), n_reads, n_haps, rl, hl)
     got = pd_ctx.compute(b)
-    _, vec = pd_oracle.compute(b, semantics=0)
+    _, vec = pd_oracle.compute(b, semantics=pd_ctx.sem)
     assert got.tobytes() == vec.tobytes()
     # permuting the pairs must not change any result (packing must not leak between lanes)
     perm = np.random.RandomState(1).permutation(b.batch)
@@ -243,7 +264,7 @@ def test_pdhmm_jni_flat_and_holder_paths(pd_oracle):
     b, exp = load_pdhmm_file(FILES[1])
     rc, out, cls, msg = mockjni.run_pdhmm(b)
     assert rc == 0, (cls, msg)
-    _, vec = pd_oracle.compute(b, semantics=0)
+    _, vec = pd_oracle.compute(b, semantics=2)
     assert out.tobytes() == vec.tobytes() and np.max(np.abs(out - exp)) <= TOL
     # holders: 7 reads x 5 haplotypes, read-major cross product, tiny memory budget -> several batches
     rng = np.random.RandomState(9)
@@ -259,7 +280,7 @@ def test_pdhmm_jni_flat_and_holder_paths(pd_oracle):
             hh = lambda a: a.reshape(5, haps.max_hap_len)[h, :H]  # noqa: E731
             pairs.append((hh(haps.hap_bases), hh(haps.hap_pdbases), rr(src.read_bases), rr(src.read_qual),
                           rr(src.read_ins_qual), rr(src.read_del_qual), rr(src.gcp)))
-    _, vec = pd_oracle.compute(PdhmmBatch.from_pairs(pairs), semantics=0)
+    _, vec = pd_oracle.compute(PdhmmBatch.from_pairs(pairs), semantics=2)
     assert out.tobytes() == vec.tobytes()
     bad = random_pd_batch(np.random.RandomState(2), 4)
     bad.read_del_qual[1] = -7
@@ -288,7 +309,7 @@ def test_pdhmm_mirror_compute_likelihoods_on_holders_fixture(pd_oracle):
     out = np.zeros(len(rd) * len(hd))
     hmm.computeLikelihoods(rd, hd, out)
     hmm.done()
-    _, vec = pd_oracle.compute(b, semantics=0)
+    _, vec = pd_oracle.compute(b, semantics=2)
     assert np.max(np.abs(out - exp)) <= TOL
     assert out.tobytes() == vec.tobytes()
     # the same holders through the JNI symbol computeLikelihoodsNative (mock JNIEnv), default memory budget
