@@ -333,3 +333,123 @@ class PdhmmContext:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------- Smith-Waterman (include/gkl_hip_sw.h)
+SW_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgklhip_sw.so")
+SW_SOFTCLIP, SW_INDEL, SW_LEADING_INDEL, SW_IGNORE = 9, 10, 11, 12
+_sw_lib = None
+
+
+class CSwParams(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("open", C.c_int32), ("extend", C.c_int32)]
+
+
+def load_sw_library(path: Optional[str] = None):
+    global _sw_lib
+    if _sw_lib is not None and path is None:
+        return _sw_lib
+    p = path or SW_LIB_PATH
+    try:
+        import torch  # noqa: F401  (HIP runtime load order, see load_library)
+    except ImportError:
+        pass
+    if not os.path.exists(p):
+        raise RuntimeException(f"{p} is not built (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(p)
+    lib.gklhip_sw_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.gklhip_sw_init.restype = C.c_int
+    lib.gklhip_sw_done.argtypes = [C.c_void_p]
+    lib.gklhip_sw_done.restype = C.c_int
+    lib.gklhip_sw_align.argtypes = [C.c_void_p, C.POINTER(CSwParams), C.c_int32, C.c_char_p, C.c_int32, C.c_char_p,
+                                    C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+    lib.gklhip_sw_align.restype = C.c_int
+    lib.gklhip_sw_align_batch.argtypes = [C.c_void_p, C.POINTER(CSwParams), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.gklhip_sw_align_batch.restype = C.c_int
+    lib.gklhip_sw_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.gklhip_sw_last_kernel_ms.restype = C.c_float
+    lib.gklhip_sw_last_error.restype = C.c_char_p
+    if path is None:
+        _sw_lib = lib
+    return lib
+
+
+class SwContext:
+    """One gklhip_sw context (= IntelSmithWaterman.initNative)."""
+
+    def __init__(self, device: int = -1):
+        self.lib = load_sw_library()
+        h = C.c_void_p()
+        st = self.lib.gklhip_sw_init(device, C.byref(h))
+        if st != OK:
+            self._raise(st)
+        self.handle = h
+
+    def _raise(self, status):
+        msg = (self.lib.gklhip_sw_last_error() or b"").decode()
+        if status == ERR_INVALID_ARG:
+            raise IllegalArgumentException(msg)
+        if status == ERR_OOM:
+            raise OutOfMemoryError(msg)
+        raise RuntimeException(msg)
+
+    def align(self, ref: bytes, alt: bytes, params, strategy: int, cigar_len: Optional[int] = None):
+        """(cigar bytes, cigar_count, offset) of one pair; cigar_len defaults to the Java side's 2*max(len)."""
+        ref, alt = bytes(ref), bytes(alt)
+        if cigar_len is None:
+            cigar_len = 2 * max(len(ref), len(alt))
+        buf = C.create_string_buffer(max(cigar_len, 1))
+        cnt, off = C.c_uint32(0), C.c_int32(0)
+        p = CSwParams(*[int(v) for v in params])
+        st = self.lib.gklhip_sw_align(self.handle, C.byref(p), int(strategy), ref, len(ref), alt, len(alt), buf,
+                                      int(cigar_len), C.byref(cnt), C.byref(off))
+        if st != OK:
+            self._raise(st)
+        return buf.raw[:cigar_len].rstrip(b"\0"), cnt.value, off.value
+
+    def align_batch(self, refs, alts, params, strategy: int, cigar_stride: Optional[int] = None):
+        """Lists of byte strings in, (list of cigar bytes, counts, offsets) out -- one launch for all pairs."""
+        n = len(refs)
+        if n != len(alts):
+            raise IllegalArgumentException("refs and alts differ in length")
+        refs, alts = [bytes(r) for r in refs], [bytes(a) for a in alts]
+        if cigar_stride is None:
+            cigar_stride = 2 * max([1] + [max(len(r), len(a)) for r, a in zip(refs, alts)])
+        ro = np.zeros(n + 1, np.int64)
+        ao = np.zeros(n + 1, np.int64)
+        np.cumsum([len(r) for r in refs], out=ro[1:])
+        np.cumsum([len(a) for a in alts], out=ao[1:])
+        rb = np.frombuffer(b"".join(refs) or b"\0", dtype=np.uint8)
+        ab = np.frombuffer(b"".join(alts) or b"\0", dtype=np.uint8)
+        cig = np.zeros(max(n, 1) * cigar_stride, np.uint8)
+        cnt = np.zeros(max(n, 1), np.uint32)
+        off = np.zeros(max(n, 1), np.int32)
+        p = CSwParams(*[int(v) for v in params])
+        st = self.lib.gklhip_sw_align_batch(self.handle, C.byref(p), int(strategy), n, rb.ctypes.data, ro.ctypes.data,
+                                            ab.ctypes.data, ao.ctypes.data, cig.ctypes.data, int(cigar_stride),
+                                            cnt.ctypes.data, off.ctypes.data)
+        if st != OK:
+            self._raise(st)
+        rows = cig.reshape(max(n, 1), cigar_stride)
+        return [rows[k].tobytes().rstrip(b"\0") for k in range(n)], cnt[:n].copy(), off[:n].copy()
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.gklhip_sw_last_kernel_ms(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gklhip_sw_done(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,160 @@
+"""Smith-Waterman: oracle pins on CPU, HIP parity on the GPU.  Integer work: every
+comparison is exact (CIGAR bytes, their count, the alignment offset)."""
+import numpy as np
+import pytest
+
+from oracle.sw import IGNORE, INDEL, LEADING_INDEL, SOFTCLIP, STRATEGIES
+
+PARAM_SETS = [(200, -150, -260, -11),   # SmithWatermanUnitTest.java:44 (GATK's haplotype-to-reference set)
+              (3, -1, -4, -3), (25, -50, -110, -6), (10, -5, -10, -10), (1, -1, -1, -1), (5, -4, 0, 0),
+              (64 * 1024, -5, -10, -10)]  # MAXIMUM_SW_MATCH_VALUE
+
+
+@pytest.fixture(scope="module")
+def sw_oracle():
+    from oracle.sw import SwOracle
+    return SwOracle()
+
+
+@pytest.fixture(scope="module")
+def sw_reference():
+    from oracle.sw import SwReference
+    try:
+        return SwReference()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+
+
+def mutate(rng, s, rate):
+    out = bytearray()
+    for c in s:
+        u = rng.rand()
+        if u < rate / 3:
+            continue
+        if u < 2 * rate / 3:
+            out.append(int(rng.choice(list(b"ACGT"))))
+            out.append(c)
+            continue
+        if u < rate:
+            out.append(int(rng.choice(list(b"ACGT"))))
+            continue
+        out.append(c)
+    return bytes(out) or b"A"
+
+
+def random_pairs(rng, n, lengths=(1, 2, 3, 5, 8, 17, 33, 64, 100, 150, 300)):
+    """Related and unrelated sequence pairs: point mutations, a window of the reference, random, with a tail."""
+    pairs = []
+    for _ in range(n):
+        L = int(rng.choice(lengths))
+        ref = bytes(rng.choice(list(b"ACGT"), size=L).tolist())
+        kind = rng.randint(4)
+        if kind == 0:
+            alt = mutate(rng, ref, 0.1)
+        elif kind == 1:
+            alt = mutate(rng, ref[L // 4:L // 4 + max(1, L // 2)], 0.2)
+        elif kind == 2:
+            alt = bytes(rng.choice(list(b"ACGT"), size=max(1, int(L * rng.uniform(0.3, 1.7)))).tolist())
+        else:
+            alt = mutate(rng, ref, 0.02) + bytes(rng.choice(list(b"ACGT"), size=rng.randint(0, 20)).tolist())
+        pairs.append((ref, alt))
+    return pairs
+
+
+# ------------------------------------------------------------------ oracle pins (CPU)
+def test_sw_oracle_reference_unit_test_cases(sw_oracle):
+    # singleElementSequencesAlignmentTest / twoElementSequencesAlignmentTest (SmithWatermanUnitTest.java:171-205)
+    assert sw_oracle.align(b"C", b"C", (3, -2, -2, -1), IGNORE)[1] == b"1M"
+    assert sw_oracle.align(b"AD", b"AT", (3, -5, -2, -1), IGNORE)[1] == b"1M1I"
+
+
+def test_sw_oracle_bit_identical_to_reference_objects(sw_oracle, sw_reference):
+    rng = np.random.RandomState(1)
+    engines = (1, 2) if sw_reference.has_avx512() else (1,)
+    n = 0
+    for ref, alt in random_pairs(rng, 400):
+        p = PARAM_SETS[rng.randint(len(PARAM_SETS))]
+        for s in STRATEGIES:
+            mine = sw_oracle.align(ref, alt, p, s)
+            for eng in engines:
+                assert mine == sw_reference.align(ref, alt, p, s, engine=eng), (eng, s, p, ref, alt)
+                n += 1
+    assert n >= 3200
+    # longer than one 1024-wide matrix of the reference (D_MAX_SEQ_LEN grows, PairWiseSW.h:463-469), and a
+    # CIGAR buffer too small for the text (elements that do not fit are skipped, :442-447)
+    ref = bytes(rng.choice(list(b"ACGT"), size=1500).tolist())
+    alt = mutate(rng, ref[100:1400], 0.05)
+    for s in STRATEGIES:
+        assert sw_oracle.align(ref, alt, PARAM_SETS[0], s) == sw_reference.align(ref, alt, PARAM_SETS[0], s)
+        for cl in (1, 2, 3, 5, 9):
+            assert sw_oracle.align(ref, alt, PARAM_SETS[0], s, cigar_len=cl) == \
+                sw_reference.align(ref, alt, PARAM_SETS[0], s, cigar_len=cl)
+
+
+def test_sw_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gkl_amd import native
+    from gkl_amd.errors import RuntimeException
+    with pytest.raises(RuntimeException):
+        native.SwContext()
+
+
+# ------------------------------------------------------------------ HIP parity (GPU)
+@pytest.fixture(scope="module")
+def sw_ctx():
+    from gkl_amd import native
+    with native.SwContext() as c:
+        yield c
+
+
+@pytest.mark.gpu
+def test_sw_gpu_reference_unit_test_cases(sw_ctx):
+    assert sw_ctx.align(b"C", b"C", (3, -2, -2, -1), IGNORE)[0] == b"1M"
+    assert sw_ctx.align(b"AD", b"AT", (3, -5, -2, -1), IGNORE)[0] == b"1M1I"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_sw_gpu_batch_bit_exact(sw_ctx, sw_oracle, strategy):
+    rng = np.random.RandomState(100 + strategy)
+    pairs = random_pairs(rng, 300)
+    for p in PARAM_SETS[:4]:
+        cig, cnt, off = sw_ctx.align_batch([r for r, _ in pairs], [a for _, a in pairs], p, strategy)
+        stride = 2 * max(max(len(r), len(a)) for r, a in pairs)
+        for k, (r, a) in enumerate(pairs):
+            st, ecig, ecnt, eoff = sw_oracle.align(r, a, p, strategy, cigar_len=stride)
+            assert st == 0 and (cig[k], int(cnt[k]), int(off[k])) == (ecig, ecnt, eoff), (k, p, r, a)
+
+
+@pytest.mark.gpu
+def test_sw_gpu_single_pair_long_and_striped(sw_ctx, sw_oracle):
+    # more than 256 rows -> several stripes with the boundary row carried through HBM; odd / even widths
+    rng = np.random.RandomState(7)
+    for L, M in ((257, 300), (300, 257), (513, 64), (1000, 999), (1500, 1300), (64, 1500), (255, 256), (256, 255)):
+        ref = bytes(rng.choice(list(b"ACGT"), size=L).tolist())
+        alt = mutate(rng, (ref * 2)[L // 7:L // 7 + M], 0.06)
+        for s in STRATEGIES:
+            st, ecig, ecnt, eoff = sw_oracle.align(ref, alt, PARAM_SETS[0], s)
+            assert sw_ctx.align(ref, alt, PARAM_SETS[0], s) == (ecig, ecnt, eoff), (L, M, s)
+
+
+@pytest.mark.gpu
+def test_sw_gpu_small_cigar_buffer_and_argument_errors(sw_ctx, sw_oracle):
+    from gkl_amd.errors import IllegalArgumentException
+    ref, alt = b"ACGTACGTTTGACCA" * 5, b"ACGTACGTGACCAACG" * 4
+    for cl in (1, 2, 3, 4, 6, 11):
+        st, ecig, ecnt, eoff = sw_oracle.align(ref, alt, PARAM_SETS[1], SOFTCLIP, cigar_len=cl)
+        assert sw_ctx.align(ref, alt, PARAM_SETS[1], SOFTCLIP, cigar_len=cl) == (ecig, ecnt, eoff)
+    with pytest.raises(IllegalArgumentException):
+        sw_ctx.align(b"", b"AC", PARAM_SETS[1], IGNORE, cigar_len=4)          # emptyReferenceSequence...Test
+    with pytest.raises(IllegalArgumentException):
+        sw_ctx.align(b"AC", b"", PARAM_SETS[1], IGNORE, cigar_len=4)
+    with pytest.raises(IllegalArgumentException):
+        sw_ctx.align(b"A" * 32768, b"TCCG", (10, -5, -10, -10), IGNORE)       # ...SequenceLengthTooLong
+    with pytest.raises(IllegalArgumentException):
+        sw_ctx.align(b"ACCG", b"TCCG", (64 * 1024 + 1, -5, -10, -10), IGNORE)  # ...MatchValueGreaterThanMaxAllowed
+    with pytest.raises(IllegalArgumentException):
+        sw_ctx.align(b"ACCG", b"TCCG", (3, -1, -4, -3), 13)
+    assert sw_ctx.align(b"ACCG", b"TCCG", (3, -1, -4, -3), IGNORE)[0]         # the context survives errors
