@@ -12,7 +12,8 @@
 // Slots used (spec index): FindClass 6, ThrowNew 14, ExceptionClear 17,
 // DeleteLocalRef 23, GetFieldID 94, GetObjectField 95, GetArrayLength 171,
 // GetObjectArrayElement 173, GetByteArrayRegion 200, SetDoubleArrayRegion 214,
-// ExceptionCheck 228; the PDHMM shim adds NewDoubleArray 182 and GetLongArrayRegion 204.
+// ExceptionCheck 228; the PDHMM shim adds NewDoubleArray 182 and GetLongArrayRegion 204, the
+// Smith-Waterman shim SetByteArrayRegion 208.
 #pragma once
 #include <stdint.h>
 
@@ -61,6 +62,7 @@ enum {
   kJniSlotNewDoubleArray = 182,
   kJniSlotGetByteArrayRegion = 200,
   kJniSlotGetLongArrayRegion = 204,
+  kJniSlotSetByteArrayRegion = 208,
   kJniSlotSetDoubleArrayRegion = 214,
   kJniSlotExceptionCheck = 228,
   kJniSlotCount = 235  // JNI 9+: GetModule is 233, IsVirtualThread (21) is 234
@@ -111,6 +113,9 @@ inline jdoubleArray NewDoubleArray(JNIEnv* e, jsize len) {
 }
 inline void GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize start, jsize len, jlong* buf) {
   fn<void (*)(JNIEnv*, jlongArray, jsize, jsize, jlong*)>(e, kJniSlotGetLongArrayRegion)(e, a, start, len, buf);
+}
+inline void SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, const jbyte* buf) {
+  fn<void (*)(JNIEnv*, jbyteArray, jsize, jsize, const jbyte*)>(e, kJniSlotSetByteArrayRegion)(e, a, start, len, buf);
 }
 inline void SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
   fn<void (*)(JNIEnv*, jdoubleArray, jsize, jsize, const jdouble*)>(e, kJniSlotSetDoubleArrayRegion)(e, a, start, len, buf);

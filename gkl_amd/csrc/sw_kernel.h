@@ -224,15 +224,16 @@ __device__ __forceinline__ void sw_find_max(const SwArgs& a, const SwPair& p, in
   *out_j = __builtin_amdgcn_readfirstlane(max_j);
 }
 
-// fast_itoa of smithwaterman_common.cc:26-58 (0 has no digits; negatives get a '-')
-__device__ __forceinline__ int sw_itoa(char* ptr, int32_t number) {
+// fast_itoa of smithwaterman_common.cc:26-58 (0 has no digits; negatives get a '-').  Wave-uniform: every lane
+// runs it, `store` (lane 0) alone writes.
+__device__ __forceinline__ int sw_itoa(char* ptr, int32_t number, bool store) {
   const bool neg = number < 0;
   if (neg) number = -number;
   int digits = 0;
   for (int32_t c = number; c > 0; c /= 10) digits++;
   if (!ptr) return digits + (neg ? 1 : 0);
-  if (neg) *(ptr++) = '-';
-  for (int k = digits - 1; k >= 0; k--) { ptr[k] = (char)('0' + number % 10); number /= 10; }
+  if (neg) { if (store) *ptr = '-'; ptr++; }
+  for (int k = digits - 1; k >= 0; k--) { if (store) ptr[k] = (char)('0' + number % 10); number /= 10; }
   return digits + (neg ? 1 : 0);
 }
 
@@ -251,7 +252,7 @@ __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int p
   int32_t cur_len = 0;
   auto push = [&](int op, int32_t len) {  // adjacent equal operations merge (:397-415)
     if (op == cur_op) { cur_len += len; return; }
-    if (cur_op >= 0) { if (lane == 0) ops[n_ops] = (cur_op << 28) | (cur_len & 0xffff); n_ops++; }
+    if (cur_op >= 0) { if (lane == 0) ops[n_ops] = (int32_t)(((uint32_t)cur_op << 28) | ((uint32_t)cur_len & 0xffffu)); n_ops++; }
     cur_op = op; cur_len = len;
   };
   int i, j;
@@ -295,23 +296,27 @@ __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int p
     else if (j > 0) push(kSwInsert, j);
     offset = 0;
   }
-  if (cur_op >= 0) { if (lane == 0) ops[n_ops] = (cur_op << 28) | (cur_len & 0xffff); n_ops++; }
+  if (cur_op >= 0) { if (lane == 0) ops[n_ops] = (int32_t)(((uint32_t)cur_op << 28) | ((uint32_t)cur_len & 0xffffu)); n_ops++; }
   __threadfence();
-  // text, last operation first (:417-449); lengths are int16 in the reference
+  // text, last operation first (:417-449); lengths are int16 in the reference.  Executed by the whole
+  // wavefront with lane 0 storing: a lane-0-only region at the end of the persistent loop invites the compiler
+  // to thread it into the next iteration's lane-0 atomic, which tears the wavefront apart (observed: hang).
+  const bool store = lane == 0;
   int cur_size = 0;
-  if (lane == 0) {
-    char* text = a.text + p.text_off;
-    for (int k = n_ops - 1; k >= 0; k--) {
-      const int32_t v = ops[k];
-      const int op = (int)((uint32_t)v >> 28);
-      const int32_t len = (int16_t)(v & 0xffff);
-      const char c = op == kSwMatch ? 'M' : op == kSwInsert ? 'I' : op == kSwDelete ? 'D' : op == kSwSoftclip ? 'S' : 'R';
-      const int need = sw_itoa(nullptr, len) + 1;
-      if (need > 1 && cur_size + need <= p.cigar_len) {
-        cur_size += sw_itoa(text + cur_size, len);
-        text[cur_size++] = c;
-      }
+  char* text = a.text + p.text_off;
+  for (int k = n_ops - 1; k >= 0; k--) {
+    const int32_t v = __builtin_amdgcn_readfirstlane(ops[k]);
+    const int op = (int)((uint32_t)v >> 28);
+    const int32_t len = (int16_t)(v & 0xffff);
+    const char c = op == kSwMatch ? 'M' : op == kSwInsert ? 'I' : op == kSwDelete ? 'D' : op == kSwSoftclip ? 'S' : 'R';
+    const int need = sw_itoa(nullptr, len, false) + 1;
+    if (need > 1 && cur_size + need <= p.cigar_len) {
+      cur_size += sw_itoa(text + cur_size, len, store);
+      if (store) text[cur_size] = c;
+      cur_size++;
     }
+  }
+  if (store) {
     int32_t* r = a.result + (int64_t)pair_index * 4;
     r[0] = offset; r[1] = cur_size; r[2] = max_i; r[3] = budget > 0 ? max_j : -1;
   }
@@ -330,6 +335,7 @@ __global__ __launch_bounds__(64) void sw_align_kernel(SwArgs a) {
     int32_t max_i = 0, max_j = 0;
     sw_find_max(a, p, lane, &max_i, &max_j);
     sw_trace(a, p, pi, lane, max_i, max_j);
+    __syncthreads();  // one wavefront per block: free, and it keeps the iterations of the persistent loop apart
   }
 }
 

@@ -1,0 +1,39 @@
+/*
+ * gkl_sw_jni.h -- the JNI symbols of libgkl_smithwaterman.so: what GKL's
+ * com.intel.gkl.smithwaterman.IntelSmithWaterman binds (reference
+ * src/main/java/com/intel/gkl/smithwaterman/IntelSmithWaterman.java:188-190; native prototypes
+ * src/main/native/smithwaterman/IntelSmithWaterman.h:32-52; bodies IntelSmithWaterman.cc:47-132).
+ * Thin shims (gkl_amd/csrc/jni_shim_sw.cpp) over the C ABI of include/gkl_hip_sw.h.
+ */
+#ifndef GKL_SW_JNI_H
+#define GKL_SW_JNI_H
+
+#ifdef GKL_USE_SYSTEM_JNI
+#include <jni.h>
+#else
+#include "../gkl_amd/csrc/jni_min.h"
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* private native static void initNative()   (IntelSmithWaterman.cc:47-66: picks the AVX2 or AVX-512 engine;
+ * here: creates the device context; no usable gfx950 device -> java/lang/RuntimeException) */
+JNIEXPORT void JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_initNative(JNIEnv* env, jclass cls);
+
+/* private native static int alignNative(byte[] refArray, byte[] altArray, byte[] cigar, int match, int mismatch,
+ *                                        int open, int extend, byte strategy)          (IntelSmithWaterman.cc:71-124)
+ * Writes the CIGAR text into `cigar` (the Java side sized it 2*max(ref, alt) and trims the trailing zeros) and
+ * returns the alignment offset; on error throws IllegalArgumentException / OutOfMemoryError and returns -1. */
+JNIEXPORT jint JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_alignNative(
+    JNIEnv* env, jclass cls, jbyteArray ref, jbyteArray alt, jbyteArray cigar, jint match, jint mismatch, jint open,
+    jint extend, jbyte strategy);
+
+/* private native static void doneNative()   (IntelSmithWaterman.cc:130-132) */
+JNIEXPORT void JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_doneNative(JNIEnv* env, jclass cls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKL_SW_JNI_H */

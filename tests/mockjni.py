@@ -105,3 +105,30 @@ def run_pdhmm(b, flags=0, max_memory_mb=512, holders=None):
                                hl.ctypes.data_as(C.c_void_p), rl.ctypes.data_as(C.c_void_p),
                                out.ctypes.data_as(C.c_void_p), int(out_len), int(flags), int(max_memory_mb), ec, em)
     return rc, out[:out_len], ec.value.decode(), em.value.decode()
+
+
+# ---------------------------------------------------------------- Smith-Waterman
+SW_JNI_LIB = os.path.join(ROOT, "gkl_amd", "lib", "libgkl_smithwaterman.so")
+SW_SKIP_INIT, SW_NULL_REF = 1, 2
+
+
+def run_sw(ref, alt, params, strategy, cigar_len=None, flags=0, iters=1):
+    """initNative -> alignNative x iters -> doneNative through the mock JNIEnv.
+    Returns (rc, cigar bytes (trimmed like IntelSmithWaterman.java:150), offset, exception_class, message, wall_ms)."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    build()
+    lib = C.CDLL(SO)
+    ref, alt = bytes(ref), bytes(alt)
+    if cigar_len is None:
+        cigar_len = 2 * max(len(ref), len(alt))
+    out = C.create_string_buffer(max(cigar_len, 1))
+    ec, em = C.create_string_buffer(256), C.create_string_buffer(512)
+    off, wall = C.c_int(0), C.c_double(0.0)
+    lib.mockjni_run_sw.restype = C.c_int
+    rc = lib.mockjni_run_sw(SW_JNI_LIB.encode(), ref, len(ref), alt, len(alt), int(cigar_len), int(params[0]),
+                            int(params[1]), int(params[2]), int(params[3]), int(strategy), int(flags), int(iters), out,
+                            C.byref(off), ec, em, C.byref(wall))
+    return rc, out.raw[:cigar_len].rstrip(b"\0"), off.value, ec.value.decode(), em.value.decode(), wall.value

@@ -104,6 +104,14 @@ void m_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, jbyte
   }
   memcpy(buf, o->bytes.data() + start, (size_t)len);
 }
+void m_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, const jbyte* buf) {
+  Obj* o = O(a);
+  if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->bytes.size()) {
+    M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "byte region");
+    return;
+  }
+  memcpy(o->bytes.data() + start, buf, (size_t)len);
+}
 void m_SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
   Obj* o = O(a);
   if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->doubles.size()) {
@@ -148,6 +156,7 @@ void install_table(Mock& m) {
   m.table.slot[kJniSlotGetArrayLength] = (void*)&m_GetArrayLength;
   m.table.slot[kJniSlotGetObjectArrayElement] = (void*)&m_GetObjectArrayElement;
   m.table.slot[kJniSlotGetByteArrayRegion] = (void*)&m_GetByteArrayRegion;
+  m.table.slot[kJniSlotSetByteArrayRegion] = (void*)&m_SetByteArrayRegion;
   m.table.slot[kJniSlotSetDoubleArrayRegion] = (void*)&m_SetDoubleArrayRegion;
   m.table.slot[kJniSlotNewDoubleArray] = (void*)&m_NewDoubleArray;
   m.table.slot[kJniSlotGetLongArrayRegion] = (void*)&m_GetLongArrayRegion;
@@ -404,6 +413,55 @@ int mockjni_run_pdhmm(const char* lib_path, int n_a, int n_b, int max_hap, int m
   if (m.pending) { snprintf(exc_class, 256, "%s", m.exc_class.c_str()); snprintf(exc_msg, 512, "%s", m.exc_msg.c_str()); }
   return rc_;
 }
+
+// ---- Smith-Waterman: IntelSmithWaterman natives (include/gkl_sw_jni.h) ----
+typedef void (*sw_init_fn)(JNIEnv*, jclass);
+typedef jint (*sw_align_fn)(JNIEnv*, jclass, jbyteArray, jbyteArray, jbyteArray, jint, jint, jint, jint, jbyte);
+typedef void (*sw_done_fn)(JNIEnv*, jclass);
+enum { SW_SKIP_INIT = 1, SW_NULL_REF = 2 };
+
+// initNative -> `iters` x alignNative -> doneNative.  cigar_out[cigar_len] = the Java byte[] after the call.
+// Returns 0, 1 (exception after initNative), 2 (after alignNative), -1 (load error); *offset = alignNative's value.
+int mockjni_run_sw(const char* lib_path, const uint8_t* ref, int ref_len, const uint8_t* alt, int alt_len, int cigar_len,
+                   int match, int mismatch, int open, int extend, int strategy, int flags, int iters, uint8_t* cigar_out,
+                   int* offset, char* exc_class, char* exc_msg, double* wall_ms) {
+  exc_class[0] = exc_msg[0] = 0;
+  void* h = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { snprintf(exc_msg, 512, "dlopen: %s", dlerror()); return -1; }
+  sw_init_fn f_init = (sw_init_fn)dlsym(h, "Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_initNative");
+  sw_align_fn f_align = (sw_align_fn)dlsym(h, "Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_alignNative");
+  sw_done_fn f_done = (sw_done_fn)dlsym(h, "Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_doneNative");
+  if (!f_init || !f_align || !f_done) { snprintf(exc_msg, 512, "missing JNI symbol"); return -1; }
+  Mock m;
+  install_table(m);
+  JNIEnv* env = &m.env;
+  Obj* jref = bytes_obj(m, ref, ref_len);
+  Obj* jalt = bytes_obj(m, alt, alt_len);
+  Obj* jcig = m.make(Obj::BYTES);
+  jcig->bytes.assign((size_t)cigar_len, 0);
+  int rc_ = 0;
+  if (!(flags & SW_SKIP_INIT)) {
+    f_init(env, nullptr);
+    if (m.pending) rc_ = 1;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < iters && rc_ == 0; k++) {
+    std::fill(jcig->bytes.begin(), jcig->bytes.end(), 0);  // the Java wrapper allocates a fresh array per call
+    *offset = f_align(env, nullptr, (flags & SW_NULL_REF) ? nullptr : reinterpret_cast<jbyteArray>(jref),
+                      reinterpret_cast<jbyteArray>(jalt), reinterpret_cast<jbyteArray>(jcig), match, mismatch, open,
+                      extend, (jbyte)strategy);
+    if (m.pending) rc_ = 2;
+  }
+  if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  f_done(env, nullptr);
+  memcpy(cigar_out, jcig->bytes.data(), (size_t)cigar_len);
+  if (m.pending) {
+    snprintf(exc_class, 256, "%s", m.exc_class.c_str());
+    snprintf(exc_msg, 512, "%s", m.exc_msg.c_str());
+  }
+  return rc_;
+}
+
 
 // ---- libgkl_utils.so (include/gkl_utils_jni.h): six natives, no JNIEnv use at all ----
 // out[0..5] = getFlushToZero(before), isAvx, isAvx2, isAvx512, ompThreads, getFlushToZero(after set true)

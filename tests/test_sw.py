@@ -158,3 +158,75 @@ def test_sw_gpu_small_cigar_buffer_and_argument_errors(sw_ctx, sw_oracle):
     with pytest.raises(IllegalArgumentException):
         sw_ctx.align(b"ACCG", b"TCCG", (3, -1, -4, -3), 13)
     assert sw_ctx.align(b"ACCG", b"TCCG", (3, -1, -4, -3), IGNORE)[0]         # the context survives errors
+
+
+# ------------------------------------------------------------------ JNI shim (mock JNIEnv) + plugin mirror
+def test_sw_jni_exports_and_errors_without_a_call():
+    import ctypes as C
+    from tests import mockjni
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(mockjni.SW_JNI_LIB)
+    for s in ("initNative", "alignNative", "doneNative"):
+        assert hasattr(lib, "Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_" + s)
+    rc, _, _, cls, msg, _ = mockjni.run_sw(b"ACGT", b"ACGT", (3, -1, -4, -3), IGNORE, flags=mockjni.SW_SKIP_INIT)
+    assert rc == 2 and cls == "java/lang/RuntimeException"
+    rc, _, _, cls, msg, _ = mockjni.run_sw(b"ACGT", b"ACGT", (3, -1, -4, -3), IGNORE,
+                                           flags=mockjni.SW_SKIP_INIT | mockjni.SW_NULL_REF)
+    assert rc == 2 and cls == "java/lang/IllegalArgumentException" and msg == "Arrays aren't valid."
+
+
+def test_sw_mirror_argument_validation():
+    # SmithWatermanUnitTest.java:33-166: null -> NPE; too long / match too large / empty -> IAE, before any native call
+    from gkl_amd.errors import IllegalArgumentException, NullPointerException
+    from gkl_amd.smithwaterman import IntelSmithWaterman, SWOverhangStrategy, SWParameters
+    sw = IntelSmithWaterman()
+    prm = SWParameters(200, -150, -260, -11)
+    for args in ((None, b"AC", prm, SWOverhangStrategy.SOFTCLIP), (b"AC", None, prm, SWOverhangStrategy.SOFTCLIP),
+                 (b"AC", b"AC", None, SWOverhangStrategy.SOFTCLIP), (b"AC", b"AC", prm, None)):
+        with pytest.raises(NullPointerException):
+            sw.align(*args)
+    too_long = b"A" * (IntelSmithWaterman.MAX_SW_SEQUENCE_LENGTH + 1)
+    small = SWParameters(10, -5, -10, -10)
+    with pytest.raises(IllegalArgumentException):
+        sw.align(too_long, b"TCCG", small, SWOverhangStrategy.IGNORE)
+    with pytest.raises(IllegalArgumentException):
+        sw.align(b"TCCG", too_long, small, SWOverhangStrategy.IGNORE)
+    with pytest.raises(IllegalArgumentException):
+        sw.align(b"ACCG", b"TCCG", SWParameters(IntelSmithWaterman.MAXIMUM_SW_MATCH_VALUE + 1, -5, -10, -10),
+                 SWOverhangStrategy.IGNORE)
+    with pytest.raises(IllegalArgumentException):
+        sw.align(b"", b"AC", SWParameters(3, -2, -2, -1), SWOverhangStrategy.IGNORE)
+    with pytest.raises(IllegalArgumentException):
+        sw.align(b"AC", b"", SWParameters(3, -2, -2, -1), SWOverhangStrategy.IGNORE)
+
+
+@pytest.mark.gpu
+def test_sw_jni_and_mirror_paths(sw_oracle):
+    from gkl_amd.smithwaterman import IntelSmithWaterman, SWOverhangStrategy, SWParameters
+    from tests import mockjni
+    rng = np.random.RandomState(12)
+    sw = IntelSmithWaterman()
+    assert sw.load(None)
+    # singleElementSequencesAlignmentTest / twoElementSequencesAlignmentTest
+    assert sw.align(b"C", b"C", SWParameters(3, -2, -2, -1), SWOverhangStrategy.IGNORE).cigar == "1M"
+    assert sw.align(b"AD", b"AT", SWParameters(3, -5, -2, -1), SWOverhangStrategy.IGNORE).cigar == "1M1I"
+    for ref, alt in random_pairs(rng, 12, lengths=(20, 90, 260, 400)):
+        for strat in SWOverhangStrategy:
+            st, ecig, _, eoff = sw_oracle.align(ref, alt, PARAM_SETS[0], strat.value)
+            res = sw.align(ref, alt, SWParameters(*PARAM_SETS[0]), strat)
+            assert (res.cigar, res.alignment_offset) == (ecig.decode(), eoff)
+            rc, jcig, joff, cls, msg, _ = mockjni.run_sw(ref, alt, PARAM_SETS[0], strat.value)
+            assert rc == 0, (cls, msg)
+            assert (jcig, joff) == (ecig, eoff)
+    sw.close()
+    # maxSequenceFullAlignmentTest (disabled in the reference: 32767 x 32767 with match 65536) at a tenth of the size
+    n = 3277
+    ref = bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    sw = IntelSmithWaterman()
+    assert sw.load(None)
+    assert sw.align(ref, ref, SWParameters(IntelSmithWaterman.MAXIMUM_SW_MATCH_VALUE, -5, -10, -10),
+                    SWOverhangStrategy.IGNORE).cigar == f"{n}M"
+    sw.close()
