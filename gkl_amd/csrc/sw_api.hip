@@ -149,16 +149,18 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
     p.alt_off = (int64_t)up(ref_bytes) + alt_off[k];
     p.nrow = (int32_t)rl;
     p.ncol = (int32_t)al;
-    const size_t ncolp = ((size_t)al + 1) & ~(size_t)1;
+    p.rpl = rl > 4 * kLanes ? 8 : 4;   // 4 rows per lane while the reference fits one 256-row stripe, else 8
     p.bt_off = (int64_t)bt_units;
-    bt_units += up(((size_t)rl + kSwRpl - 1) / kSwRpl * ncolp, 64);
+    {
+      const size_t stripe_rows = (size_t)kLanes * (size_t)p.rpl;
+      bt_units += (((size_t)rl + stripe_rows - 1) / stripe_rows) * ((size_t)al + kLanes) * kLanes;
+    }
     p.aux_off = (int64_t)aux_units;
     aux_units += up((size_t)al + 1 + (size_t)rl + 1 + 4 * ((size_t)al + 65), 16);
     p.ops_off = (int64_t)ops_units;
     ops_units += up((size_t)rl + (size_t)al + 4, 16);
     p.text_off = (int64_t)k * cigar_stride;
     p.cigar_len = cigar_stride;
-    p.pad_ = 0;
   }
   // longest pairs first: the persistent wavefronts finish together
   std::vector<int32_t> order((size_t)n);
@@ -187,7 +189,7 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
   const size_t o_text = 0, o_res = up(text_bytes), out_total = o_res + up((size_t)n * 16);
   if ((rc = c->dev_out.reserve(out_total))) return rc;
   if ((rc = c->stage_out.reserve(out_total))) return rc;
-  if ((rc = c->bt.reserve(bt_units * 2))) return rc;
+  if ((rc = c->bt.reserve(bt_units * 4))) return rc;
   if ((rc = c->aux.reserve(aux_units * 4))) return rc;
   if ((rc = c->ops.reserve(ops_units * 4))) return rc;
   SW_HIP_TRY(hipMemsetAsync(c->dev_out.p, 0, out_total, s));   // a fresh Java byte[] is zero
@@ -201,7 +203,7 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
   a.n_pairs = n;
   a.match = prm->match; a.mismatch = prm->mismatch; a.open = prm->open; a.extend = prm->extend;
   a.strategy = strategy;
-  a.bt = c->bt.as<uint16_t>();
+  a.bt = c->bt.as<uint32_t>();
   a.aux = c->aux.as<int32_t>();
   a.ops = c->ops.as<int32_t>();
   a.text = reinterpret_cast<char*>(dout + o_text);

@@ -8,14 +8,18 @@
 // "skip what does not fit / has length 0" rule.  Integer work: results are bit-exact (oracle/sw_oracle.c).
 //
 // Mapping: the reference sweeps anti-diagonals with one SIMD vector; here a 64-lane wavefront is a systolic
-// array like the PairHMM kernels' -- lane L owns 4 consecutive rows (reference bases) in registers, the
+// array like the PairHMM kernels' -- lane L owns 4 or 8 consecutive rows (reference bases) in registers, the
 // alternate sequence streams through the lanes one column per step, the row above arrives by DPP
-// wave_shr:1 (H and F, 2 values per step).  Sequences longer than 256 rows run as consecutive stripes, the
+// wave_shr:1 (H and F, 2 values per step).  Sequences longer than 64 lanes' worth of rows run as stripes, the
 // boundary row (H, F per column) carried through HBM.  One wavefront owns one pair from fill to text;
 // persistent wavefronts pull pairs (longest first) from a counter.
-//   * back-track: 4 bits per cell (2 direction bits + the two gap-extension bits), 16 bits per (4-row
-//     block, column), written as one dword per two columns: nrow*ncol/2 bytes per pair instead of the
-//     reference's 2 bytes per cell of a 1024-stride matrix;
+//   * back-track: 4 bits per cell (two "who won" bits + the two gap-extension bits), shifted into one 32-bit
+//     word per (row block, column) by compare + add-with-carry and stored step-major ([step][lane], the
+//     anti-diagonal order the wavefront produces them in): one fully coalesced 256-byte store per step, about
+//     nrow*ncol/2 bytes per pair with 8 rows per lane instead of the reference's 2 bytes per cell of a
+//     1024-stride matrix;
+//   * most steps have every lane inside its column range: that steady phase runs without a single select
+//     (ramp-up and drain keep the guarded step);
 //   * maximum: H of the last row / last column goes to two small arrays; the order-dependent tie rule only
 //     ever matters among candidates equal to the global maximum, so a wave-parallel max is followed by an
 //     in-order pass over those candidates (ballot + scalar loop);
@@ -29,21 +33,24 @@
 
 namespace gklhip {
 
-constexpr int kSwRpl = 4;
-constexpr int kSwStripeRows = kLanes * kSwRpl;
 constexpr int32_t kSwLow = INT32_MIN / 2;      // LOW_INIT_VALUE, smithwaterman_common.h:85
 constexpr int32_t kSwCutoff = -100000000;      // MATRIX_MIN_CUTOFF, :84
 enum { kSwMatch = 0, kSwInsert = 1, kSwDelete = 2, kSwInsertExt = 4, kSwDeleteExt = 8 };
 enum { kSwSoftclip = 9, kSwIndel = 10, kSwLeadingIndel = 11, kSwIgnore = 12 };
+// back-track word of one (row block, column): 4 bits per row, row 0 of the block in the highest used nibble;
+// nibble = insert-extension << 3 | delete-extension << 2 | "insert beats match" << 1 | "delete beats both"
+enum { kBtDel = 1, kBtIns = 2, kBtDelExt = 4, kBtInsExt = 8 };
 
 struct SwPair {
   int64_t ref_off, alt_off;  // into SwArgs::seq
   int32_t nrow, ncol;        // len1 (reference, rows), len2 (alternate, columns)
-  int64_t bt_off;            // 16-bit units: [(nrow + 3) / 4][ncolp], ncolp = ncol rounded up to even
+  int64_t bt_off;            // 32-bit words: [stripe][step t < ncol + 64][lane]: what lane L stored at step t
+                             // belongs to row block stripe*64 + L, column t - L + 1
   int64_t aux_off;           // int32 units: last_row[ncol + 1], last_col[nrow + 1], 2 x (carryH, carryF)[ncol + 65]
   int64_t ops_off;           // int32 units: run-length ops of the walk, [nrow + ncol + 4]
   int64_t text_off;          // bytes: CIGAR text, [cigar_len], zero-filled by the host API
-  int32_t cigar_len, pad_;
+  int32_t cigar_len;
+  int32_t rpl;               // rows per lane of this pair's fill: 4 (up to 256 rows per stripe) or 8
 };
 
 struct SwArgs {
@@ -52,7 +59,7 @@ struct SwArgs {
   const int32_t* order;      // pair indices, longest first
   int32_t n_pairs;
   int32_t match, mismatch, open, extend, strategy;
-  uint16_t* bt;
+  uint32_t* bt;
   int32_t* aux;
   int32_t* ops;
   char* text;
@@ -64,10 +71,69 @@ __device__ __forceinline__ int32_t sw_readlane(int32_t v, int src) { return __bu
 __device__ __forceinline__ int32_t sw_max(int32_t a, int32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ int32_t sw_abs(int32_t a) { return a < 0 ? -a : a; }
 
-// ---- phase 1: fill.  Writes back-track nibbles, last_row[1..ncol], last_col[1..nrow].
+// lane 0 of v = a scalar (no select, no exec juggling)
+__device__ __forceinline__ void sw_writelane0(int32_t& v, int32_t scalar) {
+  asm("v_writelane_b32 %0, %1, 0" : "+v"(v) : "s"(scalar));
+}
+
+// acc = 2 * acc + (a > b) / (a >= b): compare into VCC, then add-with-carry shifts the flag in -- two VALU
+// instructions per back-track bit and no SGPR-pair traffic (the compiler's cmp + cndmask + or takes three
+// plus wait states).
+__device__ __forceinline__ void sw_flag_gt(uint32_t& acc, int32_t x, int32_t y) {
+  asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void sw_flag_ge(uint32_t& acc, int32_t x, int32_t y) {
+  asm("v_cmp_ge_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+}
+
+// One lane's rows of one stripe.
+template <int RPL>
+struct SwLane {
+  int32_t hl[RPL], e[RPL];   // H[i][j-1], E[i][j-1]
+  uint32_t x[RPL];           // reference base of the row (0x100: no row)
+  int32_t hd;                // H[i0-1][j-1]: diagonal input of the first row
+  int32_t in_h, in_f;        // H, F of the row above at this step's column
+  int32_t out_h, out_f;      // H, F of this lane's last row at the column just finished
+  uint32_t ent;              // alternate base of this lane's column, 0x100 = none
+
+  // MAIN_CODE (PairWiseSW.h:27-62) for the lane's RPL cells of one column.  kAll: every lane is inside its
+  // column range (steady phase), so nothing needs protecting; otherwise `act` guards the state.
+  template <bool kAll>
+  __device__ __forceinline__ uint32_t step(int32_t open, int32_t extend, int32_t match, int32_t mismatch, bool act) {
+    int32_t top_h = in_h, top_f = in_f, diag = hd;
+    uint32_t word = 0;
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+      const int32_t open_h = hl[s] + open, ext_h = e[s] + extend;        // :29-33
+      const int32_t e11 = sw_max(open_h, ext_h);
+      sw_flag_ge(word, ext_h, open_h);                                   // INSERT_EXT unless open > ext, :34-35
+      const int32_t ext_v = top_f + extend, open_v = top_h + open;       // :39-42
+      const int32_t f11 = sw_max(ext_v, open_v);
+      sw_flag_ge(word, ext_v, open_v);                                   // DELETE_EXT unless open > ext, :43-44
+      const int32_t m11 = diag + (x[s] == ent ? match : mismatch);       // :47-51
+      const int32_t h0 = sw_max(kSwCutoff, m11);                          // :52
+      sw_flag_gt(word, e11, h0);                                         // insertion beats the diagonal, :53,55
+      const int32_t h1 = sw_max(h0, e11);
+      sw_flag_gt(word, f11, h1);                                         // deletion beats both, :56,58
+      const int32_t h11 = sw_max(h1, f11);
+      diag = hl[s];
+      hl[s] = (kAll || act) ? h11 : hl[s];
+      e[s] = (kAll || act) ? e11 : e[s];
+      top_h = h11;
+      top_f = f11;
+    }
+    hd = (kAll || act) ? in_h : hd;
+    out_h = top_h;
+    out_f = top_f;
+    return word;
+  }
+};
+
+// ---- phase 1: fill.  Writes back-track words, last_row[1..ncol], last_col[1..nrow].
+template <int RPL>
 __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int lane) {
+  constexpr int kStripeRows = kLanes * RPL;
   const int nrow = p.nrow, ncol = p.ncol;
-  const int ncolp = (ncol + 1) & ~1;
   const uint8_t* ref = a.seq + p.ref_off;
   const uint8_t* alt = a.seq + p.alt_off;
   const bool indel = a.strategy == kSwIndel || a.strategy == kSwLeadingIndel;
@@ -76,43 +142,40 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
   int32_t* last_col = last_row + (ncol + 1);
   int32_t* carry = last_col + (nrow + 1);
   const int cstride = ncol + 65;
-  uint16_t* bt = a.bt + p.bt_off;
-  const int n_stripes = (nrow + kSwStripeRows - 1) / kSwStripeRows;
+  uint32_t* bt = a.bt + p.bt_off;
+  const int n_stripes = (nrow + kStripeRows - 1) / kStripeRows;
   for (int st = 0; st < n_stripes; st++) {
-    const int row0 = st * kSwStripeRows + lane * kSwRpl;  // rows row0+1 .. row0+4
-    const int rows_here = nrow - st * kSwStripeRows;      // rows of this stripe (may exceed 256)
-    const int lanes_used = rows_here >= kSwStripeRows ? kLanes : (rows_here + kSwRpl - 1) / kSwRpl;
+    const int row0 = st * kStripeRows + lane * RPL;       // rows row0+1 .. row0+RPL
+    const int rows_here = nrow - st * kStripeRows;        // rows from this stripe on
+    const int lanes_used = rows_here >= kStripeRows ? kLanes : (rows_here + RPL - 1) / RPL;
     const int n_steps = ncol + lanes_used - 1;
     const int32_t* cin_h = carry + ((st + 1) & 1) * 2 * cstride;
     const int32_t* cin_f = cin_h + cstride;
     int32_t* cout_h = carry + (st & 1) * 2 * cstride;
     int32_t* cout_f = cout_h + cstride;
     const bool has_next = st + 1 < n_stripes;
-    int32_t hl[kSwRpl], e[kSwRpl];
-    uint32_t x[kSwRpl];
-    bool valid[kSwRpl];
+    const bool mine = lane < lanes_used;                  // lanes past the last row stay out of memory
+    SwLane<RPL> L;
 #pragma unroll
-    for (int s = 0; s < kSwRpl; s++) {
+    for (int s = 0; s < RPL; s++) {
       const int i = row0 + 1 + s;
-      valid[s] = i <= nrow;
-      x[s] = valid[s] ? ref[i - 1] : 0x100u;               // never equals a byte
-      hl[s] = indel ? open + (i - 1) * extend : 0;          // H[i][0], PairWiseSW.h:194-203
-      e[s] = kSwLow;                                        // :205
+      L.x[s] = i <= nrow ? (uint32_t)ref[i - 1] : 0x100u;  // never equals a byte
+      L.hl[s] = indel ? open + (i - 1) * extend : 0;       // H[i][0], PairWiseSW.h:194-203
+      L.e[s] = kSwLow;                                     // :205
     }
-    // H[row0][0]: the diagonal input of this lane's first row at column 1
-    int32_t hd = (row0 == 0 || !indel) ? 0 : open + (row0 - 1) * extend;
-    int32_t in_h = 0, in_f = kSwLow;     // row above at this step's column (lane > 0: by DPP)
-    int32_t out_h = 0, out_f = kSwLow;
-    uint32_t ent = 0x100u;               // alternate base of this lane's column, 0x100 = none
-    uint32_t acc = 0;
+    L.hd = (row0 == 0 || !indel) ? 0 : open + (row0 - 1) * extend;  // H[row0][0]
+    L.in_h = 0; L.in_f = kSwLow; L.out_h = 0; L.out_f = kSwLow;
+    L.ent = 0x100u;
     int32_t ci_h = 0, ci_f = kSwLow;
-    const int blk = row0 / kSwRpl;
-    const int last_s = nrow - 1 - row0;  // row slot that holds row nrow in this lane (if 0..3)
-    for (int t = 0; t < n_steps; t++) {
+    const int last_s = nrow - 1 - row0;                    // row slot that holds row nrow in this lane (if 0..RPL-1)
+    const bool holds_last = last_s >= 0 && last_s < RPL;
+    uint32_t* bt_st = bt + (int64_t)st * (ncol + kLanes) * kLanes + lane;  // [t * 64]: one coalesced 256-byte store per step
+
+    auto general_step = [&](int t) {
       const uint32_t entry = t < ncol ? (uint32_t)alt[t] : 0x100u;
-      ent = dpp_shr1_keep(entry, ent);
+      L.ent = dpp_shr1_keep(entry, L.ent);
       const int j = t - lane + 1;
-      const bool act = j >= 1 && j <= ncol && valid[0];  // lanes past the last row stay out of memory
+      const bool act = j >= 1 && j <= ncol && mine;
       if (st > 0) {                      // lane 0's row above comes from the previous stripe
         if ((t & 63) == 0) {
           const int c = t + 1 + lane;
@@ -120,60 +183,66 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
           ci_f = c <= ncol ? cin_f[c] : kSwLow;
         }
         const int32_t vh = sw_readlane(ci_h, t & 63), vf = sw_readlane(ci_f, t & 63);
-        if (lane == 0) { in_h = vh; in_f = vf; }
+        if (lane == 0) { L.in_h = vh; L.in_f = vf; }
       } else if (lane == 0) {
-        in_h = indel ? open + (j - 1) * extend : 0;         // H[0][j]
-        in_f = kSwLow;                                      // F[0][j], :204
+        L.in_h = indel ? open + (j - 1) * extend : 0;       // H[0][j]
+        L.in_f = kSwLow;                                    // F[0][j], :204
       }
-      int32_t top_h = in_h, top_f = in_f, diag = hd;
-      uint32_t nib = 0;
-      int32_t h_last = 0;
-#pragma unroll
-      for (int s = 0; s < kSwRpl; s++) {
-        const int32_t open_h = hl[s] + open, ext_h = e[s] + extend;        // MAIN_CODE :29-33
-        const int32_t e11 = sw_max(open_h, ext_h);
-        uint32_t code = open_h > ext_h ? 0u : (uint32_t)kSwInsertExt;       // :34-35
-        const int32_t ext_v = top_f + extend, open_v = top_h + open;       // :39-42
-        const int32_t f11 = sw_max(ext_v, open_v);
-        code |= open_v > ext_v ? 0u : (uint32_t)kSwDeleteExt;               // :43-44
-        const int32_t m11 = diag + (x[s] == ent ? match : mismatch);       // :47-51
-        int32_t h11 = sw_max(kSwCutoff, m11);                               // :52
-        uint32_t dir = e11 > h11 ? (uint32_t)kSwInsert : (uint32_t)kSwMatch;  // :53,55
-        h11 = sw_max(h11, e11);
-        dir = f11 > h11 ? (uint32_t)kSwDelete : dir;                        // :56,58
-        h11 = sw_max(h11, f11);
-        nib |= (code | dir) << (4 * s);
-        diag = hl[s];
-        hl[s] = act ? h11 : hl[s];
-        e[s] = act ? e11 : e[s];
-        top_h = h11;
-        top_f = f11;
-        if (s == last_s) h_last = h11;
-      }
-      hd = act ? in_h : hd;
-      out_h = top_h;
-      out_f = top_f;
+      const uint32_t word = L.template step<false>(open, extend, match, mismatch, act);
+      bt_st[(int64_t)t * kLanes] = word;   // unconditionally: slots outside the matrix are never read
       if (act) {
-        // two columns of 4 nibbles per dword; an odd last column goes out alone
-        if (((j - 1) & 1) == 0) {
-          acc = nib;
-          if (j == ncol) *reinterpret_cast<uint32_t*>(bt + (int64_t)blk * ncolp + (j - 1)) = acc;
-        } else {
-          acc |= nib << 16;
-          *reinterpret_cast<uint32_t*>(bt + (int64_t)blk * ncolp + (j - 2)) = acc;
+        if (holds_last) {
+          int32_t h_last = L.hl[0];
+#pragma unroll
+          for (int s = 1; s < RPL; s++) h_last = s == last_s ? L.hl[s] : h_last;
+          last_row[j] = h_last;
         }
-        if (last_s >= 0 && last_s < kSwRpl) last_row[j] = h_last;
         if (j == ncol) {
 #pragma unroll
-          for (int s = 0; s < kSwRpl; s++)
-            if (valid[s]) last_col[row0 + 1 + s] = hl[s];
+          for (int s = 0; s < RPL; s++)
+            if (row0 + 1 + s <= nrow) last_col[row0 + 1 + s] = L.hl[s];
         }
-        if (has_next && lane == kLanes - 1) { cout_h[j] = out_h; cout_f[j] = out_f; }
+        if (has_next && lane == kLanes - 1) { cout_h[j] = L.out_h; cout_f[j] = L.out_f; }
       }
       // the row above for the next step: lane L-1 has just finished the column lane L takes next
-      const int32_t nh = (int32_t)dpp_shr1_zero((uint32_t)out_h), nf = (int32_t)dpp_shr1_zero((uint32_t)out_f);
-      if (lane != 0) { in_h = nh; in_f = nf; }
+      const int32_t nh = (int32_t)dpp_shr1_zero((uint32_t)L.out_h), nf = (int32_t)dpp_shr1_zero((uint32_t)L.out_f);
+      if (lane != 0) { L.in_h = nh; L.in_f = nf; }
+    };
+
+    int t = 0;
+    if (st == 0 && !has_next) {
+      // single stripe (every pair up to 64*RPL rows): ramp-up with guards, then a steady phase in which every
+      // lane is inside its column range -- no selects, lane 0's boundary value from a scalar register -- then
+      // the drain with guards again.
+      const int steady_end = ncol;                       // steps [lanes_used - 1, ncol) have all lanes active
+      for (; t < lanes_used - 1 && t < n_steps; t++) general_step(t);
+      int32_t bnd = indel ? open + t * extend : 0;        // H[0][t + 1]
+      const int32_t bnd_step = indel ? extend : 0;
+      for (; t < steady_end; t++) {
+        L.ent = dpp_shr1_keep((uint32_t)alt[t], L.ent);
+        sw_writelane0(L.in_h, bnd);
+        sw_writelane0(L.in_f, kSwLow);
+        bnd += bnd_step;
+        const uint32_t word = L.template step<true>(open, extend, match, mismatch, true);
+        bt_st[(int64_t)t * kLanes] = word;
+        if (mine) {
+          if (holds_last) {
+            int32_t h_last = L.hl[0];
+#pragma unroll
+            for (int s = 1; s < RPL; s++) h_last = s == last_s ? L.hl[s] : h_last;
+            last_row[t - lane + 1] = h_last;
+          }
+          if (t - lane + 1 == ncol) {
+#pragma unroll
+            for (int s = 0; s < RPL; s++)
+              if (row0 + 1 + s <= nrow) last_col[row0 + 1 + s] = L.hl[s];
+          }
+        }
+        L.in_h = (int32_t)dpp_shr1_zero((uint32_t)L.out_h);
+        L.in_f = (int32_t)dpp_shr1_zero((uint32_t)L.out_f);
+      }
     }
+    for (; t < n_steps; t++) general_step(t);
     __threadfence();  // carry rows, last_row/last_col and the back-track are read back by this wavefront
   }
 }
@@ -243,9 +312,9 @@ __device__ __forceinline__ int sw_itoa(char* ptr, int32_t number, bool store) {
 __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int pair_index, int lane, int32_t max_i,
                                          int32_t max_j) {
   const int nrow = p.nrow, ncol = p.ncol;
-  const int ncolp = (ncol + 1) & ~1;
-  const uint32_t* bt32 = reinterpret_cast<const uint32_t*>(a.bt + p.bt_off);
-  const int row_dwords = ncolp >> 1;
+  const uint32_t* bt = a.bt + p.bt_off;
+  const int rpl = p.rpl, rshift = rpl == 8 ? 3 : 2;
+  const int64_t stripe_words = (int64_t)(ncol + kLanes) * kLanes;
   int32_t* ops = a.ops + p.ops_off;  // run-length ops in walk order: op << 28 | length
   int n_ops = 0;
   int cur_op = -1;
@@ -263,17 +332,21 @@ __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int p
   int state = 0;
   int budget = nrow + ncol + 2;  // every step consumes a row or a column: a hard bound, whatever the memory holds
   while (i > 0 && j > 0 && budget > 0) {
-    // tile: 4 row blocks (16 rows) x 16 dwords (32 columns) ending at the walker's block / dword
-    const int b0 = (i - 1) >> 2, c0 = (j - 1) >> 1;
+    // tile: 4 row blocks x 16 columns of back-track words ending at the walker's block / column
+    const int b0 = (i - 1) >> rshift, c0 = j - 1;
     const int tb = b0 - (lane >> 4), tc = c0 - (lane & 15);
     uint32_t tile = 0;
-    if (tb >= 0 && tc >= 0) tile = bt32[(int64_t)tb * row_dwords + tc];
+    if (tb >= 0 && tc >= 0)  // block tb = stripe tb / 64, lane tb % 64, stored at step tc + lane
+      tile = bt[(int64_t)(tb >> 6) * stripe_words + (int64_t)(tc + (tb & 63)) * kLanes + (tb & 63)];
     while (i > 0 && j > 0 && budget > 0) {
-      const int b = (i - 1) >> 2, c = (j - 1) >> 1;
+      const int b = (i - 1) >> rshift, c = j - 1;
       if (b0 - b > 3 || c0 - c > 15) break;
       budget--;
       const uint32_t w = (uint32_t)sw_readlane((int32_t)tile, ((b0 - b) << 4) | (c0 - c));
-      const int btr = (int)((w >> (16 * ((j - 1) & 1) + 4 * ((i - 1) & 3))) & 0xfu);
+      const int nib = (int)((w >> (4 * (rpl - 1 - ((i - 1) & (rpl - 1))))) & 0xfu);
+      // the reference's encoding (smithwaterman_common.h:44-48): direction in bits 0-1, extensions in bits 2-3
+      const int btr = ((nib & kBtDel) ? kSwDelete : (nib & kBtIns) ? kSwInsert : kSwMatch) |
+                      ((nib & kBtInsExt) ? kSwInsertExt : 0) | ((nib & kBtDelExt) ? kSwDeleteExt : 0);
       if (state == kSwInsertExt) { j--; cur_len++; state = btr & kSwInsertExt; }
       else if (state == kSwDeleteExt) { i--; cur_len++; state = btr & kSwDeleteExt; }
       else {
@@ -331,7 +404,8 @@ __global__ __launch_bounds__(64) void sw_align_kernel(SwArgs a) {
     if (k >= a.n_pairs) break;
     const int pi = a.order[k];
     const SwPair p = a.pairs[pi];
-    sw_fill(a, p, lane);
+    if (p.rpl == 8) sw_fill<8>(a, p, lane);
+    else sw_fill<4>(a, p, lane);
     int32_t max_i = 0, max_j = 0;
     sw_find_max(a, p, lane, &max_i, &max_j);
     sw_trace(a, p, pi, lane, max_i, max_j);

@@ -61,7 +61,24 @@ def random_pairs(rng, n, lengths=(1, 2, 3, 5, 8, 17, 33, 64, 100, 150, 300)):
     return pairs
 
 
+def golden_vectors():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sw_vectors.json")) as f:
+        return json.load(f)["vectors"]
+
+
 # ------------------------------------------------------------------ oracle pins (CPU)
+def test_sw_oracle_matches_reference_generated_vectors(sw_oracle):
+    # tests/golden/sw_vectors.json: answers of GKL's AVX2 and AVX-512 objects (generator beside it)
+    vs = golden_vectors()
+    assert len(vs) >= 250
+    for v in vs:
+        st, cig, cnt, off = sw_oracle.align(v["ref"].encode(), v["alt"].encode(), v["params"], v["strategy"],
+                                            cigar_len=v["cigar_len"])
+        assert st == 0 and (cig.decode(), cnt, off) == (v["cigar"], v["count"], v["offset"]), v
+
+
 def test_sw_oracle_reference_unit_test_cases(sw_oracle):
     # singleElementSequencesAlignmentTest / twoElementSequencesAlignmentTest (SmithWatermanUnitTest.java:171-205)
     assert sw_oracle.align(b"C", b"C", (3, -2, -2, -1), IGNORE)[1] == b"1M"
@@ -113,6 +130,14 @@ def sw_ctx():
 def test_sw_gpu_reference_unit_test_cases(sw_ctx):
     assert sw_ctx.align(b"C", b"C", (3, -2, -2, -1), IGNORE)[0] == b"1M"
     assert sw_ctx.align(b"AD", b"AT", (3, -5, -2, -1), IGNORE)[0] == b"1M1I"
+
+
+@pytest.mark.gpu
+def test_sw_gpu_matches_reference_generated_vectors(sw_ctx):
+    for v in golden_vectors():
+        cig, cnt, off = sw_ctx.align(v["ref"].encode(), v["alt"].encode(), v["params"], v["strategy"],
+                                     cigar_len=v["cigar_len"])
+        assert (cig.decode(), cnt, off) == (v["cigar"], v["count"], v["offset"]), v
 
 
 @pytest.mark.gpu
