@@ -150,15 +150,12 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
     p.nrow = (int32_t)rl;
     p.ncol = (int32_t)al;
     p.rpl = rl > 4 * kLanes ? 8 : 4;   // 4 rows per lane while the reference fits one 256-row stripe, else 8
-    p.bt_off = (int64_t)bt_units;
     {
       const size_t stripe_rows = (size_t)kLanes * (size_t)p.rpl;
-      bt_units += (((size_t)rl + stripe_rows - 1) / stripe_rows) * ((size_t)al + kLanes) * kLanes;
+      bt_units = std::max(bt_units, (((size_t)rl + stripe_rows - 1) / stripe_rows) * ((size_t)al + kLanes) * kLanes);
     }
-    p.aux_off = (int64_t)aux_units;
-    aux_units += up((size_t)al + 1 + (size_t)rl + 1 + 4 * ((size_t)al + 65), 16);
-    p.ops_off = (int64_t)ops_units;
-    ops_units += up((size_t)rl + (size_t)al + 4, 16);
+    aux_units = std::max(aux_units, up((size_t)al + 1 + (size_t)rl + 1 + 4 * ((size_t)al + 65), 16));
+    ops_units = std::max(ops_units, up((size_t)rl + (size_t)al + 4, 16));
     p.text_off = (int64_t)k * cigar_stride;
     p.cigar_len = cigar_stride;
   }
@@ -189,9 +186,14 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
   const size_t o_text = 0, o_res = up(text_bytes), out_total = o_res + up((size_t)n * 16);
   if ((rc = c->dev_out.reserve(out_total))) return rc;
   if ((rc = c->stage_out.reserve(out_total))) return rc;
-  if ((rc = c->bt.reserve(bt_units * 4))) return rc;
-  if ((rc = c->aux.reserve(aux_units * 4))) return rc;
-  if ((rc = c->ops.reserve(ops_units * 4))) return rc;
+  // scratch slabs: one per persistent wavefront, each big enough for the largest pair of the batch; the slab
+  // budget (default 8 GiB of the 288) caps the wavefront count when a batch holds very long sequences
+  const size_t slab_bytes = (bt_units + aux_units + ops_units) * 4;
+  const size_t budget = (size_t)8 << 30;
+  const int n_waves = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n, (size_t)256 * 16, budget / std::max<size_t>(slab_bytes, 1)}));
+  if ((rc = c->bt.reserve(bt_units * 4 * (size_t)n_waves))) return rc;
+  if ((rc = c->aux.reserve(aux_units * 4 * (size_t)n_waves))) return rc;
+  if ((rc = c->ops.reserve(ops_units * 4 * (size_t)n_waves))) return rc;
   SW_HIP_TRY(hipMemsetAsync(c->dev_out.p, 0, out_total, s));   // a fresh Java byte[] is zero
   SW_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
   unsigned char* din = c->dev_in.as<unsigned char>();
@@ -206,10 +208,10 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
   a.bt = c->bt.as<uint32_t>();
   a.aux = c->aux.as<int32_t>();
   a.ops = c->ops.as<int32_t>();
+  a.bt_stride = (int64_t)bt_units; a.aux_stride = (int64_t)aux_units; a.ops_stride = (int64_t)ops_units;
   a.text = reinterpret_cast<char*>(dout + o_text);
   a.result = reinterpret_cast<int32_t*>(dout + o_res);
   a.next = c->misc.as<int32_t>();
-  const int n_waves = std::min(n, 256 * 16);
   SW_HIP_TRY(hipEventRecord(c->ev0, s));
   hipLaunchKernelGGL(sw_align_kernel, dim3(n_waves), dim3(64), 0, s, a);
   SW_HIP_TRY(hipEventRecord(c->ev1, s));

@@ -44,10 +44,6 @@ enum { kBtDel = 1, kBtIns = 2, kBtDelExt = 4, kBtInsExt = 8 };
 struct SwPair {
   int64_t ref_off, alt_off;  // into SwArgs::seq
   int32_t nrow, ncol;        // len1 (reference, rows), len2 (alternate, columns)
-  int64_t bt_off;            // 32-bit words: [stripe][step t < ncol + 64][lane]: what lane L stored at step t
-                             // belongs to row block stripe*64 + L, column t - L + 1
-  int64_t aux_off;           // int32 units: last_row[ncol + 1], last_col[nrow + 1], 2 x (carryH, carryF)[ncol + 65]
-  int64_t ops_off;           // int32 units: run-length ops of the walk, [nrow + ncol + 4]
   int64_t text_off;          // bytes: CIGAR text, [cigar_len], zero-filled by the host API
   int32_t cigar_len;
   int32_t rpl;               // rows per lane of this pair's fill: 4 (up to 256 rows per stripe) or 8
@@ -59,9 +55,12 @@ struct SwArgs {
   const int32_t* order;      // pair indices, longest first
   int32_t n_pairs;
   int32_t match, mismatch, open, extend, strategy;
-  uint32_t* bt;
-  int32_t* aux;
-  int32_t* ops;
+  // scratch, one slab per persistent wavefront (sized by the host for the largest pair of the batch):
+  uint32_t* bt;              // back-track words [stripe][step t < ncol + 64][lane]: what lane L stored at step t
+                             // belongs to row block stripe*64 + L, column t - L + 1
+  int32_t* aux;              // last_row[ncol + 1], last_col[nrow + 1], 2 x (carryH, carryF)[ncol + 65]
+  int32_t* ops;              // run-length ops of the walk, [nrow + ncol + 4]
+  int64_t bt_stride, aux_stride, ops_stride;   // slab sizes in elements
   char* text;
   int32_t* result;           // per pair: [0] alignment offset, [1] text bytes written, [2] max_i, [3] max_j
   int32_t* next;
@@ -138,11 +137,11 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
   const uint8_t* alt = a.seq + p.alt_off;
   const bool indel = a.strategy == kSwIndel || a.strategy == kSwLeadingIndel;
   const int32_t open = a.open, extend = a.extend, match = a.match, mismatch = a.mismatch;
-  int32_t* last_row = a.aux + p.aux_off;
+  int32_t* last_row = a.aux + (int64_t)blockIdx.x * a.aux_stride;
   int32_t* last_col = last_row + (ncol + 1);
   int32_t* carry = last_col + (nrow + 1);
   const int cstride = ncol + 65;
-  uint32_t* bt = a.bt + p.bt_off;
+  uint32_t* bt = a.bt + (int64_t)blockIdx.x * a.bt_stride;
   const int n_stripes = (nrow + kStripeRows - 1) / kStripeRows;
   for (int st = 0; st < n_stripes; st++) {
     const int row0 = st * kStripeRows + lane * RPL;       // rows row0+1 .. row0+RPL
@@ -250,7 +249,7 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
 // ---- phase 2: (max_i, max_j) of PairWiseSW.h:207-232.
 __device__ __forceinline__ void sw_find_max(const SwArgs& a, const SwPair& p, int lane, int32_t* out_i, int32_t* out_j) {
   const int nrow = p.nrow, ncol = p.ncol;
-  const int32_t* last_row = a.aux + p.aux_off;
+  const int32_t* last_row = a.aux + (int64_t)blockIdx.x * a.aux_stride;
   const int32_t* last_col = last_row + (ncol + 1);
   const bool use_row = a.strategy == kSwSoftclip || a.strategy == kSwIgnore;
   // global maximum over the candidates
@@ -312,10 +311,10 @@ __device__ __forceinline__ int sw_itoa(char* ptr, int32_t number, bool store) {
 __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int pair_index, int lane, int32_t max_i,
                                          int32_t max_j) {
   const int nrow = p.nrow, ncol = p.ncol;
-  const uint32_t* bt = a.bt + p.bt_off;
+  const uint32_t* bt = a.bt + (int64_t)blockIdx.x * a.bt_stride;
   const int rpl = p.rpl, rshift = rpl == 8 ? 3 : 2;
   const int64_t stripe_words = (int64_t)(ncol + kLanes) * kLanes;
-  int32_t* ops = a.ops + p.ops_off;  // run-length ops in walk order: op << 28 | length
+  int32_t* ops = a.ops + (int64_t)blockIdx.x * a.ops_stride;  // run-length ops in walk order: op << 28 | length
   int n_ops = 0;
   int cur_op = -1;
   int32_t cur_len = 0;

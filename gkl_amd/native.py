@@ -408,8 +408,9 @@ class SwContext:
             self._raise(st)
         return buf.raw[:cigar_len].rstrip(b"\0"), cnt.value, off.value
 
-    def align_batch(self, refs, alts, params, strategy: int, cigar_stride: Optional[int] = None):
-        """Lists of byte strings in, (list of cigar bytes, counts, offsets) out -- one launch for all pairs."""
+    @staticmethod
+    def pack(refs, alts, cigar_stride: Optional[int] = None):
+        """Flat arrays of gklhip_sw_align_batch for lists of byte strings (reusable across calls)."""
         n = len(refs)
         if n != len(alts):
             raise IllegalArgumentException("refs and alts differ in length")
@@ -422,17 +423,27 @@ class SwContext:
         np.cumsum([len(a) for a in alts], out=ao[1:])
         rb = np.frombuffer(b"".join(refs) or b"\0", dtype=np.uint8)
         ab = np.frombuffer(b"".join(alts) or b"\0", dtype=np.uint8)
-        cig = np.zeros(max(n, 1) * cigar_stride, np.uint8)
+        return {"n": n, "ref_off": ro, "alt_off": ao, "refs": rb, "alts": ab, "cigar_stride": int(cigar_stride),
+                "cells": int(sum(len(r) * len(a) for r, a in zip(refs, alts)))}
+
+    def align_packed(self, pk, params, strategy: int):
+        """One gklhip_sw_align_batch call on pack()'s arrays: (cigar byte matrix [n][stride], counts, offsets)."""
+        n, stride = pk["n"], pk["cigar_stride"]
+        cig = np.zeros(max(n, 1) * stride, np.uint8)
         cnt = np.zeros(max(n, 1), np.uint32)
         off = np.zeros(max(n, 1), np.int32)
         p = CSwParams(*[int(v) for v in params])
-        st = self.lib.gklhip_sw_align_batch(self.handle, C.byref(p), int(strategy), n, rb.ctypes.data, ro.ctypes.data,
-                                            ab.ctypes.data, ao.ctypes.data, cig.ctypes.data, int(cigar_stride),
-                                            cnt.ctypes.data, off.ctypes.data)
+        st = self.lib.gklhip_sw_align_batch(self.handle, C.byref(p), int(strategy), n, pk["refs"].ctypes.data,
+                                            pk["ref_off"].ctypes.data, pk["alts"].ctypes.data, pk["alt_off"].ctypes.data,
+                                            cig.ctypes.data, stride, cnt.ctypes.data, off.ctypes.data)
         if st != OK:
             self._raise(st)
-        rows = cig.reshape(max(n, 1), cigar_stride)
-        return [rows[k].tobytes().rstrip(b"\0") for k in range(n)], cnt[:n].copy(), off[:n].copy()
+        return cig.reshape(max(n, 1), stride)[:n], cnt[:n], off[:n]
+
+    def align_batch(self, refs, alts, params, strategy: int, cigar_stride: Optional[int] = None):
+        """Lists of byte strings in, (list of cigar bytes, counts, offsets) out -- one launch for all pairs."""
+        rows, cnt, off = self.align_packed(self.pack(refs, alts, cigar_stride), params, strategy)
+        return [rows[k].tobytes().rstrip(b"\0") for k in range(len(refs))], cnt.copy(), off.copy()
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.gklhip_sw_last_kernel_ms(self.handle))
