@@ -170,8 +170,14 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
     const bool holds_last = last_s >= 0 && last_s < RPL;
     uint32_t* bt_st = bt + (int64_t)st * (ncol + kLanes) * kLanes + lane;  // [t * 64]: one coalesced 256-byte store per step
 
+    // the alternate bases arrive 64 at a time (one coalesced load per 64 steps), then one v_readlane per step
+    uint32_t achunk = 0x100u;
+    auto next_entry = [&](int t) -> uint32_t {
+      if ((t & 63) == 0) achunk = t + lane < ncol ? (uint32_t)alt[t + lane] : 0x100u;
+      return (uint32_t)sw_readlane((int32_t)achunk, t & 63);
+    };
     auto general_step = [&](int t) {
-      const uint32_t entry = t < ncol ? (uint32_t)alt[t] : 0x100u;
+      const uint32_t entry = next_entry(t);
       L.ent = dpp_shr1_keep(entry, L.ent);
       const int j = t - lane + 1;
       const bool act = j >= 1 && j <= ncol && mine;
@@ -218,7 +224,7 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
       int32_t bnd = indel ? open + t * extend : 0;        // H[0][t + 1]
       const int32_t bnd_step = indel ? extend : 0;
       for (; t < steady_end; t++) {
-        L.ent = dpp_shr1_keep((uint32_t)alt[t], L.ent);
+        L.ent = dpp_shr1_keep(next_entry(t), L.ent);
         sw_writelane0(L.in_h, bnd);
         sw_writelane0(L.in_f, kSwLow);
         bnd += bnd_step;
@@ -406,8 +412,13 @@ __global__ __launch_bounds__(64) void sw_align_kernel(SwArgs a) {
     if (p.rpl == 8) sw_fill<8>(a, p, lane);
     else sw_fill<4>(a, p, lane);
     int32_t max_i = 0, max_j = 0;
+#ifndef GKL_SW_ABL   // timing ablations (tools): 1 = fill only, 2 = fill + maximum; results are WRONG when defined
     sw_find_max(a, p, lane, &max_i, &max_j);
     sw_trace(a, p, pi, lane, max_i, max_j);
+#elif GKL_SW_ABL == 2
+    sw_find_max(a, p, lane, &max_i, &max_j);
+    if (lane == 0) a.result[(int64_t)pi * 4 + 2] = max_i + max_j;
+#endif
     __syncthreads();  // one wavefront per block: free, and it keeps the iterations of the persistent loop apart
   }
 }
