@@ -26,6 +26,8 @@
 #include "pairhmm_fwd_kernel.h"
 #include "pairhmm_plan.h"
 #include "pairhmm_tables.h"
+#include "pairhmm_aux_kernels.h"
+#include "pairhmm_host_finalize.h"
 
 using namespace gklhip;
 
@@ -84,320 +86,7 @@ struct PinBuf {
 };
 }  // namespace
 
-// ------------------------------------------------------------------ small kernels
-namespace gklhip {
 
-// stream_src (host plan) -> stream entries: haplotype base codes / separators / idle.
-__global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8_t* __restrict__ hap_bases,
-                                    uint32_t* __restrict__ stream, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t s = src[i];
-  uint32_t e;
-  if (s >= 0) {
-    const uint8_t b = hap_bases[s];  // pairhmm_common.h:57-61: A0 C1 T2 G3 N4, anything else 0
-    e = b == 'C' ? 1u : b == 'T' ? 2u : b == 'G' ? 3u : b == 'N' ? 4u : 0u;
-  } else if (s == -1) {
-    e = kEntIdle;
-  } else {
-    e = kEntSep | (uint32_t)(-2 - s);
-  }
-  stream[i] = e;
-}
-
-// Host finalisation (reference-exact log10f / log10 of the host libm) needs, per pair, either the raw
-// fp32 sum or the raw fp64 sum: one 8-byte word carries both cases -- the double's bits, or
-// 0xFFFFFFFF:float bits (a double whose high word is all ones is a NaN no computation here produces; if
-// one ever does it is replaced by the default NaN, which finalises to NaN all the same).
-constexpr int kModePacked = -2;
-constexpr uint64_t kPackedF32Tag = 0xFFFFFFFF00000000ull;
-
-struct FinalizeArgs {
-  const float* raw32;
-  const double* raw64;
-  double* out;
-  uint8_t* used64;
-  int32_t* list;
-  int32_t* count;
-  int32_t* read_fail;  // [n_reads] number of haplotypes each read must be recomputed against
-  int32_t n_haps;
-  int64_t n;
-  int mode;            // gklhip_finalize (device modes only), -1: no output, kModePacked: `out` = packed raw sums
-  float log10_init_f;  // log10f(2^120), host libm
-  double log10_init32_as_f64;  // log10(2^120) in double
-  double log10_init_d;         // log10(2^1020)
-};
-
-// Precision policy of IntelPairHmm.cc:157-165 on the raw fp32 sums: keep (and
-// finalise) pairs with sum >= 1e-28f, queue the rest for the fp64 kernel.
-__global__ void policy_kernel(FinalizeArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const float v = a.raw32[i];
-  if (v < 1e-28f) {  // NaN compares false and stays fp32, like the reference
-    a.used64[i] = 1;
-    if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[i] = 0;  // "pending": filled in by finalize64_kernel
-    const int k = atomicAdd(a.count, 1);
-    a.list[k] = (int32_t)i;
-    atomicAdd(a.read_fail + (int32_t)(i / a.n_haps), 1);
-  } else {
-    a.used64[i] = 0;
-    if (a.mode == GKLHIP_FINALIZE_DEVICE_F64) {
-      a.out[i] = log10((double)v) - a.log10_init32_as_f64;
-    } else if (a.mode == GKLHIP_FINALIZE_DEVICE_REF32) {
-      a.out[i] = (double)((float)log10((double)v) - a.log10_init_f);
-    } else if (a.mode == kModePacked) {
-      reinterpret_cast<uint64_t*>(a.out)[i] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
-    }
-  }
-}
-
-// log10 of the fp64 sums: all pairs (useDoublePrecision) or the queued ones.
-__global__ void finalize64_kernel(FinalizeArgs a, int use_list) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = use_list ? (int64_t)*a.count : a.n;
-  if (i >= n) return;
-  const int64_t p = use_list ? (int64_t)a.list[i] : i;
-  if (!use_list) a.used64[p] = 1;
-  if (a.mode >= 0) a.out[p] = log10(a.raw64[p]) - a.log10_init_d;
-  if (a.mode == kModePacked) {
-    uint64_t bits = (uint64_t)__double_as_longlong(a.raw64[p]);
-    if ((bits & kPackedF32Tag) == kPackedF32Tag) bits = 0x7FF8000000000000ull;
-    reinterpret_cast<uint64_t*>(a.out)[p] = bits;
-  }
-}
-
-// Packed fp64 fallback, step 2 (device): for every chunk of the second read packing, find the
-// runs of consecutive haplotypes (stream order, never across a stream group) that at least one
-// of its reads must be recomputed against, and queue one wave job per run.
-__global__ void build_jobs_kernel(const LaneSlot* __restrict__ lanes, const int32_t* __restrict__ n_chunks,
-                                  const uint8_t* __restrict__ used64, int n_haps,
-                                  const int32_t* __restrict__ hap_orig, const int32_t* __restrict__ hap_group,
-                                  FwdJob* __restrict__ jobs, int32_t* __restrict__ job_count) {
-  extern __shared__ int32_t smem[];
-  int32_t* s_reads = smem;                                   // [64] distinct reads of the chunk
-  uint8_t* need = reinterpret_cast<uint8_t*>(smem + kLanes + 1);  // [n_haps]
-  const int total = *n_chunks;
-  for (int c = blockIdx.x; c < total; c += gridDim.x) {
-  __syncthreads();
-  if (threadIdx.x == 0) smem[kLanes] = 0;
-  __syncthreads();
-  if (threadIdx.x < kLanes) {
-    const LaneSlot sl = lanes[(int64_t)c * kLanes + threadIdx.x];
-    if (sl.read >= 0 && sl.block == 0) s_reads[atomicAdd(&smem[kLanes], 1)] = sl.read;
-  }
-  __syncthreads();
-  const int nr = smem[kLanes];
-  for (int k = threadIdx.x; k < n_haps; k += blockDim.x) {
-    const int h = hap_orig[k];
-    uint8_t nd = 0;
-    for (int i = 0; i < nr; i++) nd |= used64[(int64_t)s_reads[i] * n_haps + h];
-    need[k] = nd;
-  }
-  __syncthreads();
-  // a needed haplotype starts a run if its predecessor is not needed or lies in another stream group
-  for (int k = threadIdx.x; k < n_haps; k += blockDim.x) {
-    if (!need[k]) continue;
-    if (k > 0 && need[k - 1] && hap_group[k - 1] == hap_group[k]) continue;
-    int e = k + 1;
-    while (e < n_haps && need[e] && hap_group[e] == hap_group[k]) e++;
-    FwdJob j;
-    j.chunk = c; j.hap_begin = k; j.hap_end = e; j.pad_ = 0;
-    jobs[atomicAdd(job_count, 1)] = j;
-  }
-  }  // chunk loop
-}
-
-// Packed fp64 fallback, step 3 (device): order the job list by decreasing length (counting sort on
-// columns / 128, one block), so that the persistent wavefronts of the jobs kernel start the long runs
-// first and the kernel's tail is made of short ones.
-constexpr int kJobClasses = 64;
-__global__ __launch_bounds__(1024) void sort_jobs_kernel(const FwdJob* __restrict__ jobs, const int32_t* __restrict__ job_count,
-                                                         const int32_t* __restrict__ hap_pos,
-                                                         const int32_t* __restrict__ hap_len, FwdJob* __restrict__ sorted) {
-  __shared__ int32_t cnt[kJobClasses], base[kJobClasses];
-  const int n = *job_count;
-  if (threadIdx.x < kJobClasses) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  auto cls_of = [&](const FwdJob& j) {
-    const int cols = hap_pos[j.hap_end - 1] + hap_len[j.hap_end - 1] - hap_pos[j.hap_begin];
-    const int c = cols >> 7;
-    return kJobClasses - 1 - (c < kJobClasses - 1 ? c : kJobClasses - 1);  // class 0 = longest
-  };
-  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&cnt[cls_of(jobs[i])], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int c = 0; c < kJobClasses; c++) { base[c] = acc; acc += cnt[c]; }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const FwdJob j = jobs[i];
-    sorted[atomicAdd(&base[cls_of(j)], 1)] = j;
-  }
-}
-
-// ---- packed fp64 fallback, step 1 (device): order the affected reads by how many haplotypes
-// they failed against (counting sort, most first) and pack them, window by window, into 64-lane
-// chunks with best-fit-decreasing -- the device twin of pack_reads_windowed(), so the pass needs
-// no host round trip.  Reads with similar fallback counts share chunks; in nested patterns (a
-// read underflows against every haplotype shorter than some length) a chunk then needs one
-// contiguous run of the length-sorted haplotype stream.
-constexpr int kPackWindow = 96;
-
-// (reads longer than max_len bases do not fit a chunk: they take the striped long-read path)
-__global__ void fail_hist_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ hist,
-                                 const int64_t* __restrict__ read_off, int max_len) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads && read_fail[r] > 0 && read_off[r + 1] - read_off[r] <= max_len) atomicAdd(hist + read_fail[r], 1);
-}
-
-// one block: bucket start positions for DESCENDING fail count; pos[c] = #reads with count > c
-__global__ void fail_scan_kernel(const int32_t* __restrict__ hist, int n_haps, int32_t* __restrict__ pos,
-                                 int32_t* __restrict__ n_fail_reads) {
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int c = n_haps; c >= 1; c--) { pos[c] = acc; acc += hist[c]; }
-    *n_fail_reads = acc;
-  }
-}
-
-__global__ void fail_scatter_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ pos,
-                                    int32_t* __restrict__ order, const int64_t* __restrict__ read_off, int max_len) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads && read_fail[r] > 0 && read_off[r + 1] - read_off[r] <= max_len)
-    order[atomicAdd(pos + read_fail[r], 1)] = r;
-}
-
-__global__ __launch_bounds__(64) void pack_windows_kernel(const int32_t* __restrict__ order,
-                                                          const int32_t* __restrict__ n_fail_reads,
-                                                          const int64_t* __restrict__ read_off, int rpl,
-                                                          LaneSlot* __restrict__ lanes, int32_t* __restrict__ n_chunks) {
-  // One wavefront per window of <= 96 reads; everything is wave-parallel: rank sort by lanes
-  // needed (descending, stable), then best fit where the 64 lanes each watch up to two bins and
-  // a shuffle reduction picks the fullest bin that still fits.
-  __shared__ int32_t s_read[kPackWindow], s_need[kPackWindow], s_sread[kPackWindow], s_sneed[kPackWindow];
-  __shared__ int32_t s_bin[kPackWindow], s_off[kPackWindow];
-  const int lane = threadIdx.x;
-  const int n = *n_fail_reads;
-  const int w0 = blockIdx.x * kPackWindow;
-  if (w0 >= n) return;
-  const int cnt = min(kPackWindow, n - w0);
-  for (int i = lane; i < cnt; i += kLanes) {
-    const int r = order[w0 + i];
-    s_read[i] = r;
-    s_need[i] = (int)((read_off[r + 1] - read_off[r] + rpl) / rpl);  // blocks_for()
-  }
-  __syncthreads();
-  for (int i = lane; i < cnt; i += kLanes) {
-    const int ni = s_need[i];
-    int rank = 0;
-    for (int j = 0; j < cnt; j++) {
-      const int nj = s_need[j];
-      rank += (nj > ni) || (nj == ni && j < i);
-    }
-    s_sread[rank] = s_read[i];
-    s_sneed[rank] = ni;
-  }
-  __syncthreads();
-  int free0 = 0, free1 = 0;  // free lanes of bins `lane` and `lane + 64` (0 = bin not open)
-  int nb = 0;                // bins opened so far (wave-uniform)
-  for (int i = 0; i < cnt; i++) {
-    const int nn = s_sneed[i];
-    // key = free*256 + bin for bins that fit, smallest free wins (best fit); none -> large
-    int key = 0x7fffffff;
-    if (free0 >= nn) key = free0 * 256 + lane;
-    if (free1 >= nn && free1 * 256 + lane + kLanes < key) key = free1 * 256 + lane + kLanes;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) key = min(key, __shfl_xor(key, d, kLanes));
-    int bin, off;
-    if (key == 0x7fffffff) { bin = nb++; off = 0; }
-    else { bin = key & 255; off = kLanes - (key >> 8); }
-    if (bin == lane) free0 = (key == 0x7fffffff ? kLanes : free0) - nn;
-    if (bin == lane + kLanes) free1 = (key == 0x7fffffff ? kLanes : free1) - nn;
-    if (lane == 0) { s_bin[i] = bin; s_off[i] = off; }
-  }
-  int base = 0;
-  if (lane == 0) base = atomicAdd(n_chunks, nb);
-  base = __shfl(base, 0, kLanes);
-  __syncthreads();
-  LaneSlot idle; idle.read = -1; idle.block = 0;
-  for (int i = lane; i < nb * kLanes; i += kLanes) lanes[(int64_t)base * kLanes + i] = idle;
-  __syncthreads();
-  for (int i = 0; i < cnt; i++)
-    for (int b = lane; b < s_sneed[i]; b += kLanes) {
-      LaneSlot sl; sl.read = s_sread[i]; sl.block = b;
-      lanes[(int64_t)(base + s_bin[i]) * kLanes + s_off[i] + b] = sl;
-    }
-}
-
-}  // namespace gklhip
-
-// ------------------------------------------------------------------ host worker pool
-// Persistent helper threads for the host-side log10 finalisation (spawning threads per call costs more
-// than the work on GATK-sized batches).  parallel_for blocks until every slice is done.
-namespace {
-class WorkerPool {
- public:
-  ~WorkerPool() { stop(); }
-  void parallel_for(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn) {
-    if (threads <= 1 || n < 16384) { fn(0, n); return; }
-    ensure(threads - 1);
-    const int64_t per = (n + threads - 1) / threads;
-    {
-      std::lock_guard<std::mutex> l(mu_);
-      fn_ = &fn; n_ = n; per_ = per; slices_ = threads; next_ = 1; pending_ = threads - 1;
-      gen_++;
-    }
-    cv_.notify_all();
-    fn(0, std::min(n, per));
-    std::unique_lock<std::mutex> l(mu_);
-    done_.wait(l, [&] { return pending_ == 0; });
-    fn_ = nullptr;
-  }
-  void stop() {
-    {
-      std::lock_guard<std::mutex> l(mu_);
-      quit_ = true;
-    }
-    cv_.notify_all();
-    for (auto& t : workers_) t.join();
-    workers_.clear();
-    quit_ = false;
-  }
-
- private:
-  void ensure(int n) {
-    while ((int)workers_.size() < n) workers_.emplace_back([this] { loop(); });
-  }
-  void loop() {
-    uint64_t seen = 0;
-    std::unique_lock<std::mutex> l(mu_);
-    for (;;) {
-      cv_.wait(l, [&] { return quit_ || (gen_ != seen && next_ < slices_); });
-      if (quit_) return;
-      while (next_ < slices_) {
-        const int k = next_++;
-        const int64_t lo = k * per_, hi = std::min(n_, lo + per_);
-        const auto* fn = fn_;
-        l.unlock();
-        if (lo < hi) (*fn)(lo, hi);
-        l.lock();
-        if (--pending_ == 0) done_.notify_all();
-      }
-      seen = gen_;
-    }
-  }
-  std::mutex mu_;
-  std::condition_variable cv_, done_;
-  std::vector<std::thread> workers_;
-  const std::function<void(int64_t, int64_t)>* fn_ = nullptr;
-  int64_t n_ = 0, per_ = 0;
-  int slices_ = 0, next_ = 0, pending_ = 0;
-  uint64_t gen_ = 0;
-  bool quit_ = false;
-};
-}  // namespace
 
 // ------------------------------------------------------------------ context
 struct gklhip_ctx {
@@ -812,73 +501,6 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   }
   return GKLHIP_OK;
 }
-
-// IntelPairHmm.cc:159-165 verbatim in meaning (host libm log10f / log10) over the packed raw sums.
-// phase 1 (`early`): finalise the fp32-tagged words and remember where the others are (their fp64 sums are
-// still being computed); phase 2 (`late`): finalise those from the complete copy.  With pending == nullptr
-// one pass does everything.  Returns the number of pairs that took the fp64 path.
-struct HostFinalizer {
-  float lf = host_tables_f32().log10_initial;
-  double ld = host_tables_f64().log10_initial;
-  std::vector<std::vector<int32_t>> pending;  // per slice
-
-  static inline bool is_f32(uint64_t w) { return (w & kPackedF32Tag) == kPackedF32Tag; }
-  inline double fin32(uint64_t w) const {
-    const uint32_t lo32 = (uint32_t)w;
-    float f;
-    memcpy(&f, &lo32, 4);
-    return (double)(log10f(f) - lf);
-  }
-  inline double fin64(uint64_t w) const {
-    double d;
-    memcpy(&d, &w, 8);
-    return log10(d) - ld;
-  }
-
-  int64_t all(WorkerPool* pool, const uint64_t* packed, double* out, int64_t n, int threads) const {
-    std::atomic<int64_t> n64{0};
-    const std::function<void(int64_t, int64_t)> work = [&](int64_t lo, int64_t hi) {
-      int64_t cnt = 0;
-      for (int64_t i = lo; i < hi; i++) {
-        const uint64_t w = packed[i];
-        if (is_f32(w)) out[i] = fin32(w);
-        else { out[i] = fin64(w); cnt++; }
-      }
-      n64 += cnt;
-    };
-    pool->parallel_for(n, threads, work);
-    return n64.load();
-  }
-  void early(WorkerPool* pool, const uint64_t* packed, double* out, int64_t n, int threads) {
-    const int slices = (threads <= 1 || n < 16384) ? 1 : threads;
-    const int64_t per = (n + slices - 1) / slices;
-    pending.assign((size_t)slices, {});
-    const std::function<void(int64_t, int64_t)> work = [&](int64_t lo, int64_t hi) {
-      std::vector<int32_t>& mine = pending[(size_t)(lo / per)];
-      for (int64_t i = lo; i < hi; i++) {
-        const uint64_t w = packed[i];
-        if (is_f32(w)) out[i] = fin32(w);
-        else mine.push_back((int32_t)i);  // whatever the word holds: the fp64 pass may be writing it right now
-      }
-    };
-    pool->parallel_for(n, threads, work);
-  }
-  int64_t late(WorkerPool* pool, const uint64_t* packed, double* out, int threads) const {
-    int64_t total = 0;
-    for (const auto& v : pending) total += (int64_t)v.size();
-    const std::function<void(int64_t, int64_t)> work = [&](int64_t lo, int64_t hi) {
-      // slice [lo, hi) of the concatenated pending lists
-      int64_t at = 0;
-      for (const auto& v : pending) {
-        const int64_t a = std::max<int64_t>(lo - at, 0), b = std::min<int64_t>(hi - at, (int64_t)v.size());
-        for (int64_t k = a; k < b; k++) out[v[(size_t)k]] = fin64(packed[v[(size_t)k]]);
-        at += (int64_t)v.size();
-      }
-    };
-    pool->parallel_for(total, threads, work);
-    return total;
-  }
-};
 
 }  // namespace
 
