@@ -56,14 +56,30 @@ struct FinalizeArgs {
 // finalise) pairs with sum >= 1e-28f, queue the rest for the fp64 kernel.
 __global__ void policy_kernel(FinalizeArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const float v = a.raw32[i];
-  if (v < 1e-28f) {  // NaN compares false and stays fp32, like the reference
+  const bool in_range = i < a.n;
+  const float v = in_range ? a.raw32[i] : 1.0f;
+  const bool fails = in_range && v < 1e-28f;  // NaN compares false and stays fp32, like the reference
+  // One atomic per wavefront instead of one per pair: ~265 k pairs of the bench batch hit the same counter.
+  const uint64_t mask = __ballot(fails);
+  if (mask) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __builtin_ctzll(mask);
+    const int total = __builtin_popcountll(mask);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(a.count, total);
+    base = __shfl(base, leader, 64);
+    const int32_t read = fails ? (int32_t)(i / a.n_haps) : -1;
+    if (fails) a.list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)i;
+    // r-major pairs: the failing lanes of a wavefront usually belong to one read (n_haps >= 64) or a few
+    const int32_t lead_read = __shfl(read, leader, 64);
+    const uint64_t same = __ballot(fails && read == lead_read);
+    if (lane == leader) atomicAdd(a.read_fail + lead_read, __builtin_popcountll(same));
+    if (fails && read != lead_read) atomicAdd(a.read_fail + read, 1);
+  }
+  if (!in_range) return;
+  if (fails) {
     a.used64[i] = 1;
     if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[i] = 0;  // "pending": filled in by finalize64_kernel
-    const int k = atomicAdd(a.count, 1);
-    a.list[k] = (int32_t)i;
-    atomicAdd(a.read_fail + (int32_t)(i / a.n_haps), 1);
   } else {
     a.used64[i] = 0;
     if (a.mode == GKLHIP_FINALIZE_DEVICE_F64) {
