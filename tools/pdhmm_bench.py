@@ -26,6 +26,13 @@ def main():
         "cross": cross_product(rng, a.reads, a.haps, (80, 151), (150, 300)),
         "distinct": random_pd_batch(rng, a.reads * a.haps, read_len=(80, 151), hap_len=(150, 300)),
     }
+    # the reference's own reads x haplotypes fixture (real GATK PD haplotypes: ~1.5 % of the columns lie in or
+    # next to a deletion, 2 % carry a SNP flag), replicated to fill the chip
+    from gkl_amd.pdhmm_batch import PdhmmBatch
+    from tests.golden_io import load_pdhmm_holders_file
+    reads, haps, _ = load_pdhmm_holders_file()
+    pairs = [(h[0], h[1], r[0], r[1], r[2], r[3], r[4]) for r in reads for h in haps]
+    cases["fixture pdhmm_new x4"] = PdhmmBatch.from_pairs(pairs * 4)
     ctx = native.PdhmmContext()
     for name, b in cases.items():
         ctx.compute(b)
