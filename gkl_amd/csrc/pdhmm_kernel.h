@@ -217,6 +217,34 @@ struct PdJob {
     fetch_above();
   }
 
+  // a column is special when it is entered in state INSIDE_DEL / AFTER_DEL or carries DEL_END
+  static __device__ __forceinline__ bool any_special(uint32_t e) {
+    const bool special = (e & ((3u << 16) | ((uint32_t)kPdDelEnd << 8))) != 0u && (e & kPdIdle) == 0u;
+    return __ballot(special) != 0;
+  }
+
+  // A packed job (no stripes): alternate between runs of plain steps and runs of general steps, each in its own
+  // loop so that neither pays register shuffling for the other at every iteration.
+  __device__ __forceinline__ void run_packed(const uint32_t* __restrict__ ep, int n_steps) {
+    fetch_above();
+    uint32_t cur = ep[0];
+    int t = 0;
+    while (t < n_steps) {
+      while (t < n_steps && !any_special(cur)) {
+        const uint32_t nxt = ep[t + 1];
+        step<true>(cur);
+        cur = nxt;
+        t++;
+      }
+      while (t < n_steps && any_special(cur)) {
+        const uint32_t nxt = ep[t + 1];
+        step<false>(cur);
+        cur = nxt;
+        t++;
+      }
+    }
+  }
+
   // One stripe: `n_steps` steps over the loaded rows; ep[t] is this lane's column entry at step t
   // (the pair's entries shifted by the lane's skew); cin / cout carry the boundary row between
   // stripes (six values per stream position + the column-0 values in slot [6*clen..]).
@@ -248,10 +276,7 @@ struct PdJob {
           if (lane == 0) r[k] = v;
         }
       }
-      // a column is special when it is entered in state INSIDE_DEL / AFTER_DEL or carries DEL_END
-      const bool special = (cur & ((3u << 16) | ((uint32_t)kPdDelEnd << 8))) != 0u && (cur & kPdIdle) == 0u;
-      if (__ballot(special) == 0) step<true>(cur);
-      else step<false>(cur);
+      step<false>(cur);   // striped jobs (reads over 255 bases) keep the general step
       cur = nxt;
       if (cout) {
         const int p = t - (kLanes - 1);
@@ -296,8 +321,7 @@ __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_con
       const double init = init_condition / (double)a.hap_len[p];  // pdhmm.h:867-878 (IEEE division, as on the host)
       job.setup(a, p, sl.block, n_blocks, active, init);
       // block k of a pair sees column j at step j + k
-      job.run(a.entries + (int64_t)p * a.entry_stride + kLanes - sl.block, a.job_steps[j], lane, nullptr, nullptr,
-              a.carry_len);
+      job.run_packed(a.entries + (int64_t)p * a.entry_stride + kLanes - sl.block, a.job_steps[j]);
       if (job.holds_last) a.sums[p] = job.sum;
       continue;
     }
