@@ -146,34 +146,37 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNat
       if (hb[h].empty() || hp[h].size() < hb[h].size()) { throw_java(env, kIAE, "empty haplotype or haplotypePDBases shorter than haplotypeBases"); return; }
       max_h = (int)std::max<size_t>(max_h, hb[h].size());
     }
-    // batches bounded by maxMemoryInMB like JavaData.h:86-101
-    const int64_t per_pair = (int64_t)max_r * 5 + (int64_t)max_h * 2 + 8 + 16;
-    int64_t batch = std::min<int64_t>(total, ((int64_t)g.max_memory_mb * 1024 * 1024) / per_pair);
-    if (batch <= 0) { throw_java(env, kIAE, "Batch size is too small. Please increase the memory limit for PDHMM by using the maxMemoryInMB argument."); return; }
-    std::vector<int8_t> b_hb((size_t)batch * max_h), b_hp((size_t)batch * max_h), b_rb((size_t)batch * max_r),
-        b_rq((size_t)batch * max_r), b_ri((size_t)batch * max_r), b_rd((size_t)batch * max_r), b_rc((size_t)batch * max_r);
-    std::vector<int64_t> hl((size_t)batch), rl((size_t)batch);
-    std::vector<double> out((size_t)batch);
-    for (int64_t start = 0; start < total; start += batch) {
-      const int64_t cnt = std::min(batch, total - start);
-      std::fill(b_hb.begin(), b_hb.end(), 0); std::fill(b_hp.begin(), b_hp.end(), 0);
-      for (auto* v : {&b_rb, &b_rq, &b_ri, &b_rd, &b_rc}) std::fill(v->begin(), v->end(), 0);
-      for (int64_t k = 0; k < cnt; k++) {
-        const int64_t pair = start + k;  // read-major: JavaData.h:190-191
-        const int r = (int)(pair / n_haps), h = (int)(pair % n_haps);
-        const size_t R = rb[r].size(), H = hb[h].size();
-        memcpy(&b_rb[(size_t)k * max_r], rb[r].data(), R); memcpy(&b_rq[(size_t)k * max_r], rq[r].data(), R);
-        memcpy(&b_ri[(size_t)k * max_r], ri[r].data(), R); memcpy(&b_rd[(size_t)k * max_r], rd[r].data(), R);
-        memcpy(&b_rc[(size_t)k * max_r], rc[r].data(), R);
-        memcpy(&b_hb[(size_t)k * max_h], hb[h].data(), H); memcpy(&b_hp[(size_t)k * max_h], hp[h].data(), H);
-        hl[(size_t)k] = (int64_t)H; rl[(size_t)k] = (int64_t)R;
-      }
-      gklhip_pdhmm_batch b = {(int32_t)cnt, max_h, max_r, b_hb.data(), b_hp.data(), b_rb.data(), b_rq.data(),
-                              b_ri.data(), b_rd.data(), b_rc.data(), hl.data(), rl.data()};
-      const int st = gklhip_pdhmm_compute(ctx, &b, out.data());
-      if (st != GKLHIP_OK) { throw_status(env, st); return; }
-      gkljni::SetDoubleArrayRegion(env, likelihoodArray, (jsize)start, (jsize)cnt, out.data());
+    // The reference expands the cross product into padded PAIRS, in batches bounded by maxMemoryInMB
+    // (JavaData.h:86-101,177-242), because computePDHMM takes pairs.  Here every read and every haplotype is
+    // staged once and the device walks the cross product itself; maxMemoryInMB then only has to cover
+    // reads + haplotypes + results, and the same "too small" error is raised when it does not.
+    const int64_t need = (int64_t)n_reads * max_r * 5 + (int64_t)n_haps * max_h * 2 + total * 8;
+    if (need > (int64_t)g.max_memory_mb * 1024 * 1024) {
+      throw_java(env, kIAE, "Batch size is too small. Please increase the memory limit for PDHMM by using the maxMemoryInMB argument.");
+      return;
     }
+    std::vector<int8_t> b_hb((size_t)n_haps * max_h, 0), b_hp((size_t)n_haps * max_h, 0), b_rb((size_t)n_reads * max_r, 0),
+        b_rq((size_t)n_reads * max_r, 0), b_ri((size_t)n_reads * max_r, 0), b_rd((size_t)n_reads * max_r, 0),
+        b_rc((size_t)n_reads * max_r, 0);
+    std::vector<int64_t> hl((size_t)n_haps), rl((size_t)n_reads);
+    for (jsize r = 0; r < n_reads; r++) {
+      const size_t R = rb[r].size();
+      memcpy(&b_rb[(size_t)r * max_r], rb[r].data(), R); memcpy(&b_rq[(size_t)r * max_r], rq[r].data(), R);
+      memcpy(&b_ri[(size_t)r * max_r], ri[r].data(), R); memcpy(&b_rd[(size_t)r * max_r], rd[r].data(), R);
+      memcpy(&b_rc[(size_t)r * max_r], rc[r].data(), R);
+      rl[(size_t)r] = (int64_t)R;
+    }
+    for (jsize h = 0; h < n_haps; h++) {
+      const size_t H = hb[h].size();
+      memcpy(&b_hb[(size_t)h * max_h], hb[h].data(), H); memcpy(&b_hp[(size_t)h * max_h], hp[h].data(), H);
+      hl[(size_t)h] = (int64_t)H;
+    }
+    std::vector<double> out((size_t)total);
+    gklhip_pdhmm_cross x = {n_reads, n_haps, max_h, max_r, b_hb.data(), b_hp.data(), b_rb.data(), b_rq.data(),
+                            b_ri.data(), b_rd.data(), b_rc.data(), hl.data(), rl.data()};
+    const int st = gklhip_pdhmm_compute_cross(ctx, &x, out.data());
+    if (st != GKLHIP_OK) { throw_status(env, st); return; }
+    gkljni::SetDoubleArrayRegion(env, likelihoodArray, 0, (jsize)total, out.data());
   } catch (const std::bad_alloc&) {
     throw_java(env, kOOM, "Memory allocation issue.");
   }

@@ -171,67 +171,116 @@ int gklhip_pdhmm_set_fma_mode(gklhip_pdhmm_ctx* c, int fma_mode) {
 
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* c) { return c ? c->last_ms : 0.f; }
 
-int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, double* out_host) {
-  if (!c) return pd_fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
-  if (!b) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batch is NULL");
-  // IntelPDHMM.java:163-173
-  if (b->batch <= 0) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batchSize must be greater than 0");
-  if (b->max_hap_len <= 0 || b->max_read_len <= 0)
+namespace {
+// Shared by the two entry points.  Paired layout: n_read_items == n_hap_items == n_pairs, cross_haps = 0.
+// Cross layout: n_pairs == n_read_items * n_hap_items, cross_haps = n_hap_items, pair p = (p / n_haps, p % n_haps).
+struct PdProblem {
+  int64_t n_pairs;
+  int32_t n_read_items, n_hap_items, cross_haps, max_hap_len, max_read_len;
+  const int8_t *hap_bases, *hap_pdbases, *read_bases, *read_qual, *read_ins_qual, *read_del_qual, *gcp;
+  const int64_t *hap_lengths, *read_lengths;
+};
+
+int pd_validate(const PdProblem& q, const double* out_host) {
+  if (q.max_hap_len <= 0 || q.max_read_len <= 0)
     return pd_fail(GKLHIP_ERR_INVALID_ARG, "maxHapLength / maxReadLength must be greater than 0");
-  if (!b->hap_bases || !b->hap_pdbases || !b->read_bases || !b->read_qual || !b->read_ins_qual || !b->read_del_qual ||
-      !b->gcp || !b->hap_lengths || !b->read_lengths || !out_host)
+  if (!q.hap_bases || !q.hap_pdbases || !q.read_bases || !q.read_qual || !q.read_ins_qual || !q.read_del_qual ||
+      !q.gcp || !q.hap_lengths || !q.read_lengths || !out_host)
     return pd_fail(GKLHIP_ERR_INVALID_ARG, "Input arrays aren't valid.");
-  for (int i = 0; i < b->batch; i++) {
-    if (b->hap_lengths[i] < 1 || b->hap_lengths[i] > b->max_hap_len)
-      return pd_fail(GKLHIP_ERR_INVALID_ARG, "hap_lengths[%d] = %lld outside 1..%d", i, (long long)b->hap_lengths[i], b->max_hap_len);
-    if (b->read_lengths[i] < 1 || b->read_lengths[i] > b->max_read_len)
-      return pd_fail(GKLHIP_ERR_INVALID_ARG, "read_lengths[%d] = %lld outside 1..%d", i, (long long)b->read_lengths[i], b->max_read_len);
-  }
+  if (q.n_pairs > 0x7fffffffLL) return pd_fail(GKLHIP_ERR_INVALID_ARG, "more than 2^31 pairs");
+  for (int i = 0; i < q.n_hap_items; i++)
+    if (q.hap_lengths[i] < 1 || q.hap_lengths[i] > q.max_hap_len)
+      return pd_fail(GKLHIP_ERR_INVALID_ARG, "hap_lengths[%d] = %lld outside 1..%d", i, (long long)q.hap_lengths[i], q.max_hap_len);
+  for (int i = 0; i < q.n_read_items; i++)
+    if (q.read_lengths[i] < 1 || q.read_lengths[i] > q.max_read_len)
+      return pd_fail(GKLHIP_ERR_INVALID_ARG, "read_lengths[%d] = %lld outside 1..%d", i, (long long)q.read_lengths[i], q.max_read_len);
+  return GKLHIP_OK;
+}
+
+int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   std::lock_guard<std::mutex> lock(c->mu);
   PD_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
-  const size_t n = (size_t)b->batch;
-  const size_t hap_bytes = n * (size_t)b->max_hap_len, read_bytes = n * (size_t)b->max_read_len;
+  const size_t n = (size_t)q.n_pairs;
+  const size_t nh = (size_t)q.n_hap_items, nr = (size_t)q.n_read_items;
+  const size_t hap_bytes = nh * (size_t)q.max_hap_len, read_bytes = nr * (size_t)q.max_read_len;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   const size_t o_hb = 0, o_hp = up(hap_bytes), o_rb = o_hp + up(hap_bytes), o_rq = o_rb + up(read_bytes),
                o_ri = o_rq + up(read_bytes), o_rd = o_ri + up(read_bytes), o_gc = o_rd + up(read_bytes),
-               o_hl = o_gc + up(read_bytes), o_rl = o_hl + up(n * 8), total = o_rl + up(n * 8);
+               o_hl = o_gc + up(read_bytes), o_rl = o_hl + up(nh * 8), total = o_rl + up(nr * 8);
   int rc;
   if ((rc = c->inputs.reserve(total))) return rc;
   unsigned char* d = c->inputs.as<unsigned char>();
-  PD_HIP_TRY(hipMemcpyAsync(d + o_hb, b->hap_bases, hap_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_hp, b->hap_pdbases, hap_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_rb, b->read_bases, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_rq, b->read_qual, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_ri, b->read_ins_qual, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_rd, b->read_del_qual, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_gc, b->gcp, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_hl, b->hap_lengths, n * 8, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_rl, b->read_lengths, n * 8, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_hb, q.hap_bases, hap_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_hp, q.hap_pdbases, hap_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_rb, q.read_bases, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_rq, q.read_qual, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_ri, q.read_ins_qual, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_rd, q.read_del_qual, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_gc, q.gcp, read_bytes, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_hl, q.hap_lengths, nh * 8, hipMemcpyHostToDevice, s));
+  PD_HIP_TRY(hipMemcpyAsync(d + o_rl, q.read_lengths, nr * 8, hipMemcpyHostToDevice, s));
+  const int cross = q.cross_haps;
+  auto read_len_of = [&](size_t p) { return (int)q.read_lengths[cross ? p / (size_t)cross : p]; };
+  auto hap_len_of = [&](size_t p) { return (int)q.hap_lengths[cross ? p % (size_t)cross : p]; };
 
-  // ---- jobs: short pairs, ordered by haplotype length so that wavefront mates finish together, are
-  // packed best-fit into 64-lane chunks; a read that needs more than 64 lanes becomes a striped job ----
-  std::vector<PlanLane> lanes;
+  // ---- jobs ----
+  std::vector<PlanLane> lanes;                 // general packed jobs: [job][64] = {pair, block}
   std::vector<int32_t> job_pair, job_steps;
   std::vector<uint8_t> job_striped;
-  {
+  std::vector<PlanLane> cross_lanes;           // cross layout: [chunk][64] = {read item, block}
+  std::vector<int32_t> hap_order, chunk_steps, chunk_rep;
+  if (cross) {
+    // reads are packed into 64-lane chunks ONCE; every chunk meets every haplotype (longest haplotypes first).
+    std::vector<int64_t> read_off(nr + 1, 0);
+    for (size_t r = 0; r < nr; r++) read_off[r + 1] = read_off[r] + q.read_lengths[r];
+    std::vector<int32_t> shorts;
+    shorts.reserve(nr);
+    for (size_t r = 0; r < nr; r++) {
+      if (blocks_for((int)q.read_lengths[r], kPdRpl) <= kLanes) { shorts.push_back((int32_t)r); continue; }
+      for (size_t h = 0; h < nh; h++) {  // a read over 255 bases: one striped job per haplotype
+        job_pair.push_back((int32_t)(r * nh + h)); job_striped.push_back(1); job_steps.push_back(0);
+      }
+    }
+    const int made = pack_reads_windowed(shorts.data(), (int)shorts.size(), read_off.data(), kPdRpl, 192, &cross_lanes, nullptr);
+    chunk_steps.assign((size_t)made, 0);
+    chunk_rep.assign((size_t)made, 0);
+    for (int k = 0; k < made; k++) {
+      const PlanLane* row = cross_lanes.data() + (size_t)k * kLanes;
+      int32_t rep = -1, top = 0;
+      for (int l = 0; l < kLanes; l++) {
+        if (row[l].read < 0) continue;
+        if (rep < 0) rep = row[l].read;
+        top = std::max(top, row[l].block);
+      }
+      chunk_steps[(size_t)k] = top;
+      chunk_rep[(size_t)k] = rep;
+    }
+    hap_order.resize(nh);
+    for (size_t h = 0; h < nh; h++) hap_order[h] = (int32_t)h;
+    std::stable_sort(hap_order.begin(), hap_order.end(),
+                     [&](int32_t x, int32_t y) { return q.hap_lengths[x] > q.hap_lengths[y]; });
+    lanes.resize(job_pair.size() * kLanes, PlanLane{-1, 0});  // striped jobs do not use their lane rows
+  } else {
+    // short pairs, ordered by haplotype length so that wavefront mates finish together, are packed best-fit
+    // into 64-lane chunks; a read that needs more than 64 lanes becomes a striped job
     std::vector<int64_t> pair_off(n + 1, 0);  // pack_reads_windowed() addresses reads through offsets
-    for (size_t i = 0; i < n; i++) pair_off[i + 1] = pair_off[i] + b->read_lengths[i];
+    for (size_t i = 0; i < n; i++) pair_off[i + 1] = pair_off[i] + read_len_of(i);
     std::vector<int32_t> shorts;
     shorts.reserve(n);
     {  // counting sort by haplotype length, longest first (the big jobs start first)
-      std::vector<int32_t> cnt((size_t)b->max_hap_len + 2, 0);
+      std::vector<int32_t> cnt((size_t)q.max_hap_len + 2, 0);
       size_t n_short = 0;
       for (size_t i = 0; i < n; i++)
-        if (blocks_for((int)b->read_lengths[i], kPdRpl) <= kLanes) { cnt[(size_t)b->hap_lengths[i]]++; n_short++; }
+        if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) { cnt[(size_t)hap_len_of(i)]++; n_short++; }
       int32_t acc = 0;
-      for (int64_t h = b->max_hap_len; h >= 0; h--) { const int32_t c = cnt[(size_t)h]; cnt[(size_t)h] = acc; acc += c; }
+      for (int64_t h = q.max_hap_len; h >= 0; h--) { const int32_t k = cnt[(size_t)h]; cnt[(size_t)h] = acc; acc += k; }
       shorts.resize(n_short);
       for (size_t i = 0; i < n; i++)
-        if (blocks_for((int)b->read_lengths[i], kPdRpl) <= kLanes) shorts[(size_t)cnt[(size_t)b->hap_lengths[i]]++] = (int32_t)i;
+        if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) shorts[(size_t)cnt[(size_t)hap_len_of(i)]++] = (int32_t)i;
     }
     for (size_t i = 0; i < n; i++) {
-      if (blocks_for((int)b->read_lengths[i], kPdRpl) <= kLanes) continue;
+      if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) continue;
       job_pair.push_back((int32_t)i); job_striped.push_back(1); job_steps.push_back(0);
       lanes.resize(lanes.size() + kLanes, PlanLane{-1, 0});  // striped job: its lane row stays unused
     }
@@ -243,27 +292,41 @@ int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, doubl
       for (int l = 0; l < kLanes; l++) {
         if (row[l].read < 0) continue;
         if (rep < 0) rep = row[l].read;
-        steps = std::max(steps, (int32_t)b->hap_lengths[row[l].read] + row[l].block);
+        steps = std::max(steps, (int32_t)hap_len_of((size_t)row[l].read) + row[l].block);
       }
       job_pair.push_back(rep); job_striped.push_back(0); job_steps.push_back(steps);
     }
   }
-  const int n_jobs = (int)job_pair.size();
-  const int entry_stride = (b->max_hap_len + 2 * kLanes + 1 + 63) / 64 * 64;
+  const int n_chunks_cross = (int)chunk_steps.size();
+  const int64_t n_cross_jobs64 = (int64_t)n_chunks_cross * (int64_t)(cross ? nh : 0);
+  if (n_cross_jobs64 + (int64_t)job_pair.size() > 0x7fffffffLL) return pd_fail(GKLHIP_ERR_INVALID_ARG, "too many jobs");
+  const int n_cross_jobs = (int)n_cross_jobs64;
+  const int n_general = (int)job_pair.size();
+  const int n_jobs = n_cross_jobs + n_general;
+  const int entry_stride = (q.max_hap_len + 2 * kLanes + 1 + 63) / 64 * 64;
   const int carry_len = entry_stride;
   const int n_blocks = std::min(n_jobs, 256 * 8);
-  if ((rc = c->entries.reserve(n * (size_t)entry_stride * 4))) return rc;
+  if ((rc = c->entries.reserve(nh * (size_t)entry_stride * 4))) return rc;
   if ((rc = c->sums.reserve(n * 8))) return rc;
   if ((rc = c->misc.reserve(64))) return rc;
   if ((rc = c->carry.reserve((size_t)n_blocks * 2 * (6 * (size_t)carry_len + 64) * 8))) return rc;
-  const size_t o_jl = 0, o_jp = up(lanes.size() * sizeof(PlanLane)), o_jn = o_jp + up((size_t)n_jobs * 4),
-               o_js = o_jn + up((size_t)n_jobs * 4);
-  if ((rc = c->jobs.reserve(o_js + up((size_t)n_jobs)))) return rc;
+  const size_t o_jl = 0, o_jp = up(lanes.size() * sizeof(PlanLane)), o_jn = o_jp + up((size_t)n_general * 4),
+               o_js = o_jn + up((size_t)n_general * 4), o_cl = o_js + up((size_t)n_general),
+               o_ho = o_cl + up(cross_lanes.size() * sizeof(PlanLane)), o_cs = o_ho + up(hap_order.size() * 4),
+               o_cr = o_cs + up(chunk_steps.size() * 4), jobs_total = o_cr + up(chunk_rep.size() * 4);
+  if ((rc = c->jobs.reserve(jobs_total + 256))) return rc;
   unsigned char* dj = c->jobs.as<unsigned char>();
-  PD_HIP_TRY(hipMemcpyAsync(dj + o_jl, lanes.data(), lanes.size() * sizeof(PlanLane), hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(dj + o_jp, job_pair.data(), (size_t)n_jobs * 4, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(dj + o_jn, job_steps.data(), (size_t)n_jobs * 4, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(dj + o_js, job_striped.data(), (size_t)n_jobs, hipMemcpyHostToDevice, s));
+  auto put = [&](size_t off, const void* src, size_t bytes) {
+    return bytes ? hipMemcpyAsync(dj + off, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  PD_HIP_TRY(put(o_jl, lanes.data(), lanes.size() * sizeof(PlanLane)));
+  PD_HIP_TRY(put(o_jp, job_pair.data(), (size_t)n_general * 4));
+  PD_HIP_TRY(put(o_jn, job_steps.data(), (size_t)n_general * 4));
+  PD_HIP_TRY(put(o_js, job_striped.data(), (size_t)n_general));
+  PD_HIP_TRY(put(o_cl, cross_lanes.data(), cross_lanes.size() * sizeof(PlanLane)));
+  PD_HIP_TRY(put(o_ho, hap_order.data(), hap_order.size() * 4));
+  PD_HIP_TRY(put(o_cs, chunk_steps.data(), chunk_steps.size() * 4));
+  PD_HIP_TRY(put(o_cr, chunk_rep.data(), chunk_rep.size() * 4));
   PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
 
   const PdTables& t = pd_tables();
@@ -277,7 +340,8 @@ int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, doubl
   a.gcp = reinterpret_cast<const int8_t*>(d + o_gc);
   a.hap_len = reinterpret_cast<const int64_t*>(d + o_hl);
   a.read_len = reinterpret_cast<const int64_t*>(d + o_rl);
-  a.batch = b->batch; a.max_hap = b->max_hap_len; a.max_read = b->max_read_len;
+  a.batch = (int32_t)n; a.max_hap = q.max_hap_len; a.max_read = q.max_read_len;
+  a.cross_haps = cross; a.n_hap_items = q.n_hap_items;
   a.q2err = c->tables.as<double>();
   a.mm_prob = c->tables.as<double>() + t.q2err.size();
   a.entries = c->entries.as<uint32_t>();
@@ -292,8 +356,13 @@ int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, doubl
   a.job_steps = reinterpret_cast<const int32_t*>(dj + o_jn);
   a.job_striped = dj + o_js;
   a.n_jobs = n_jobs;
+  a.n_cross_jobs = n_cross_jobs; a.n_chunks_cross = std::max(n_chunks_cross, 1);
+  a.cross_lanes = reinterpret_cast<const LaneSlot*>(dj + o_cl);
+  a.hap_order = reinterpret_cast<const int32_t*>(dj + o_ho);
+  a.chunk_steps = reinterpret_cast<const int32_t*>(dj + o_cs);
+  a.chunk_rep = reinterpret_cast<const int32_t*>(dj + o_cr);
 
-  hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, a);
+  hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)((nh + 127) / 128)), dim3(128), 0, s, a);
   PD_HIP_TRY(hipEventRecord(c->ev0, s));
   if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
   else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
@@ -309,6 +378,29 @@ int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, doubl
     return pd_fail(GKLHIP_ERR_INVALID_ARG, "Error while calculating pdhmm. Input arrays aren't valid.");
   for (size_t i = 0; i < n; i++) out_host[i] = std::log10(sums[i]) - t.initial_condition_log10;  // pdhmm.h:846
   return GKLHIP_OK;
+}
+}  // namespace
+
+int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, double* out_host) {
+  if (!c) return pd_fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
+  if (!b) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batch is NULL");
+  // IntelPDHMM.java:163-173
+  if (b->batch <= 0) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batchSize must be greater than 0");
+  PdProblem q{b->batch, b->batch, b->batch, 0, b->max_hap_len, b->max_read_len, b->hap_bases, b->hap_pdbases,
+              b->read_bases, b->read_qual, b->read_ins_qual, b->read_del_qual, b->gcp, b->hap_lengths, b->read_lengths};
+  const int rc = pd_validate(q, out_host);
+  return rc ? rc : pd_run(c, q, out_host);
+}
+
+int gklhip_pdhmm_compute_cross(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_cross* x, double* out_host) {
+  if (!c) return pd_fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
+  if (!x) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batch is NULL");
+  if (x->n_reads <= 0 || x->n_haps <= 0) return pd_fail(GKLHIP_ERR_INVALID_ARG, "no pairs to process");
+  PdProblem q{(int64_t)x->n_reads * x->n_haps, x->n_reads, x->n_haps, x->n_haps, x->max_hap_len, x->max_read_len,
+              x->hap_bases, x->hap_pdbases, x->read_bases, x->read_qual, x->read_ins_qual, x->read_del_qual, x->gcp,
+              x->hap_lengths, x->read_lengths};
+  const int rc = pd_validate(q, out_host);
+  return rc ? rc : pd_run(c, q, out_host);
 }
 
 }  // extern "C"

@@ -43,12 +43,15 @@ struct PdArgs {
   const int8_t* read_ins;
   const int8_t* read_del;
   const int8_t* gcp;
-  const int64_t* hap_len;      // [batch]
-  const int64_t* read_len;
+  const int64_t* hap_len;      // [n_hap_items]
+  const int64_t* read_len;     // [n_read_items]
   int32_t batch, max_hap, max_read;
+  // paired layout (computePDHMM): pair p = read item p x haplotype item p, cross_haps = 0.
+  // cross layout (computeLikelihoods): pair p = read item p / cross_haps x haplotype item p % cross_haps.
+  int32_t cross_haps, n_hap_items;
   const double* q2err;         // [255]  10^(-q/10)
   const double* mm_prob;       // [32640] matchToMatchProb triangle
-  uint32_t* entries;           // [batch * entry_stride] per pair: 64 idle, the column entries, idle to the end
+  uint32_t* entries;           // [n_hap_items * entry_stride] per haplotype item: 64 idle, the column entries, idle to the end
   int32_t entry_stride;        // 64 + max_hap + 64 + 1 (prefetch) rounded up
   double* sums;                // [batch] raw sums (scaled by 2^1020)
   int32_t* status;             // [1] sticky PDHMM_INPUT_DATA_ERROR flag (negative quals)
@@ -62,14 +65,25 @@ struct PdArgs {
   const int32_t* job_pair;
   const int32_t* job_steps;
   const uint8_t* job_striped;
-  int32_t n_jobs;
+  int32_t n_jobs;              // cross jobs first, then the listed ("general") jobs
+  // cross layout: the reads are packed into chunks ONCE (cross_lanes[chunk*64+lane] = {read item, row block}) and
+  // every chunk meets every haplotype: cross job j = (haplotype hap_order[j / n_chunks], chunk j % n_chunks).
+  // Only reads that need more than 64 lanes appear in the general job list (striped).
+  int32_t n_cross_jobs, n_chunks_cross;
+  const LaneSlot* cross_lanes;
+  const int32_t* hap_order;    // haplotype items, longest first
+  const int32_t* chunk_steps;  // per chunk: highest row block in it (steps = hap_len + that)
+  const int32_t* chunk_rep;    // per chunk: a read item of it (for idle lanes)
 };
 
-// One thread per pair: walk the column state machine (pdhmm.h:437-449 -- it depends on the
+__device__ __forceinline__ int pd_read_of(const PdArgs& a, int p) { return a.cross_haps ? p / a.cross_haps : p; }
+__device__ __forceinline__ int pd_hap_of(const PdArgs& a, int p) { return a.cross_haps ? p % a.cross_haps : p; }
+
+// One thread per haplotype item: walk the column state machine (pdhmm.h:437-449 -- it depends on the
 // haplotype only and restarts at NORMAL on every row) and emit one entry per column.
 __global__ void pdhmm_entries_kernel(PdArgs a) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.batch) return;
+  if (p >= a.n_hap_items) return;
   const int H = (int)a.hap_len[p];
   const int8_t* hb = a.hap_bases + (int64_t)p * a.max_hap;
   const int8_t* pd = a.hap_pdbases + (int64_t)p * a.max_hap;
@@ -105,10 +119,11 @@ struct PdJob {
   bool holds_last;
 
   __device__ __forceinline__ void setup(const PdArgs& a, int p, int block, int n_blocks, bool active, double init) {
-    const int R = (int)a.read_len[p];
+    const int ri = pd_read_of(a, p);
+    const int R = (int)a.read_len[ri];
     const int pads = n_blocks * RPL - R;
     const int first = block * RPL - pads;
-    const int64_t ro = (int64_t)p * a.max_read;
+    const int64_t ro = (int64_t)ri * a.max_read;
     holds_last = active && block == n_blocks - 1;
     lmask = (active && block != 0) ? ~0u : 0u;
 #pragma unroll
@@ -312,24 +327,41 @@ __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_con
     if (lane == 0) j = atomicAdd(a.next, 1);
     j = __builtin_amdgcn_readfirstlane(j);
     if (j >= a.n_jobs) break;
+    if (j < a.n_cross_jobs) {
+      const int k = j / a.n_chunks_cross, chunk = j - k * a.n_chunks_cross;
+      const int hi = a.hap_order[k];
+      const LaneSlot sl = a.cross_lanes[(int64_t)chunk * kLanes + lane];
+      const bool active = sl.read >= 0;
+      const int ri = active ? sl.read : a.chunk_rep[chunk];
+      const int p = ri * a.cross_haps + hi;
+      const int H = (int)a.hap_len[hi];
+      const int n_blocks = ((int)a.read_len[ri] + Job::RPL) / Job::RPL;
+      job.setup(a, p, sl.block, n_blocks, active, init_condition / (double)H);
+      job.run_packed(a.entries + (int64_t)hi * a.entry_stride + kLanes - sl.block, H + a.chunk_steps[chunk]);
+      if (job.holds_last) a.sums[p] = job.sum;
+      continue;
+    }
+    j -= a.n_cross_jobs;
     const int rep = a.job_pair[j];
     if (!a.job_striped[j]) {
       const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
       const bool active = sl.read >= 0;
       const int p = active ? sl.read : rep;
-      const int n_blocks = ((int)a.read_len[p] + Job::RPL) / Job::RPL;
-      const double init = init_condition / (double)a.hap_len[p];  // pdhmm.h:867-878 (IEEE division, as on the host)
+      const int hi = pd_hap_of(a, p);
+      const int n_blocks = ((int)a.read_len[pd_read_of(a, p)] + Job::RPL) / Job::RPL;
+      const double init = init_condition / (double)a.hap_len[hi];  // pdhmm.h:867-878 (IEEE division, as on the host)
       job.setup(a, p, sl.block, n_blocks, active, init);
       // block k of a pair sees column j at step j + k
-      job.run_packed(a.entries + (int64_t)p * a.entry_stride + kLanes - sl.block, a.job_steps[j]);
+      job.run_packed(a.entries + (int64_t)hi * a.entry_stride + kLanes - sl.block, a.job_steps[j]);
       if (job.holds_last) a.sums[p] = job.sum;
       continue;
     }
-    const int H = (int)a.hap_len[rep];
+    const int rep_hap = pd_hap_of(a, rep);
+    const int H = (int)a.hap_len[rep_hap];
     const double init = init_condition / (double)H;
-    const uint32_t* ep = a.entries + (int64_t)rep * a.entry_stride + kLanes - lane;  // lane l sees column j at step j + l
+    const uint32_t* ep = a.entries + (int64_t)rep_hap * a.entry_stride + kLanes - lane;  // lane l sees column j at step j + l
     const int n_steps = H + kLanes - 1;
-    const int R = (int)a.read_len[rep];
+    const int R = (int)a.read_len[pd_read_of(a, rep)];
     const int n_blocks = (R + Job::RPL) / Job::RPL;
     const int n_stripes = (n_blocks + kLanes - 1) / kLanes;
     const int first_cnt = n_blocks - kLanes * (n_stripes - 1);

@@ -237,6 +237,13 @@ class CPdhmmBatch(C.Structure):
                 ("gcp", C.c_void_p), ("hap_lengths", C.c_void_p), ("read_lengths", C.c_void_p)]
 
 
+class CPdhmmCross(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_haps", C.c_int32), ("max_hap_len", C.c_int32), ("max_read_len", C.c_int32),
+                ("hap_bases", C.c_void_p), ("hap_pdbases", C.c_void_p), ("read_bases", C.c_void_p),
+                ("read_qual", C.c_void_p), ("read_ins_qual", C.c_void_p), ("read_del_qual", C.c_void_p),
+                ("gcp", C.c_void_p), ("hap_lengths", C.c_void_p), ("read_lengths", C.c_void_p)]
+
+
 _pd_lib = None
 
 
@@ -258,6 +265,8 @@ def load_pdhmm_library(path: Optional[str] = None):
     lib.gklhip_pdhmm_set_fma_mode.restype = C.c_int
     lib.gklhip_pdhmm_compute.argtypes = [C.c_void_p, C.POINTER(CPdhmmBatch), C.c_void_p]
     lib.gklhip_pdhmm_compute.restype = C.c_int
+    lib.gklhip_pdhmm_compute_cross.argtypes = [C.c_void_p, C.POINTER(CPdhmmCross), C.c_void_p]
+    lib.gklhip_pdhmm_compute_cross.restype = C.c_int
     lib.gklhip_pdhmm_done.argtypes = [C.c_void_p]
     lib.gklhip_pdhmm_done.restype = C.c_int
     lib.gklhip_pdhmm_last_kernel_ms.argtypes = [C.c_void_p]
@@ -310,6 +319,23 @@ class PdhmmContext:
                          hl.ctypes.data, rl.ctypes.data)
         out = np.empty(max(b.batch, 0), np.float64)
         st = self.lib.gklhip_pdhmm_compute(self.handle, C.byref(cb), out.ctypes.data)
+        if st != OK:
+            self._raise(st)
+        return out
+
+    def compute_cross(self, reads, haps) -> np.ndarray:
+        """Every read against every haplotype (IntelPDHMM.computeLikelihoods), out[r * n_haps + h].
+        reads: PdhmmBatch-like with the five read arrays [n][max_read_len] + read_lengths (its haplotype side is
+        ignored); haps: PdhmmBatch-like with hap_bases / hap_pdbases [n][max_hap_len] + hap_lengths."""
+        keep = [np.ascontiguousarray(a, np.int8) for a in (haps.hap_bases, haps.hap_pdbases, reads.read_bases,
+                                                           reads.read_qual, reads.read_ins_qual, reads.read_del_qual,
+                                                           reads.gcp)]
+        hl = np.ascontiguousarray(haps.hap_lengths, np.int64)
+        rl = np.ascontiguousarray(reads.read_lengths, np.int64)
+        cb = CPdhmmCross(reads.batch, haps.batch, haps.max_hap_len, reads.max_read_len, *[a.ctypes.data for a in keep],
+                         hl.ctypes.data, rl.ctypes.data)
+        out = np.empty(max(reads.batch * haps.batch, 0), np.float64)
+        st = self.lib.gklhip_pdhmm_compute_cross(self.handle, C.byref(cb), out.ctypes.data)
         if st != OK:
             self._raise(st)
         return out

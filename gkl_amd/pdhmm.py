@@ -74,11 +74,14 @@ class IntelPDHMM:
         if self._ctx is None:
             raise RuntimeException("computeLikelihoods before initialize")
         try:
-            pairs = [(h.haplotypeBases, h.haplotypePDBases, r.readBases, r.readQuals, r.insertionGOP, r.deletionGOP,
-                      r.overallGCP) for r in readDataArray for h in haplotypeDataArray]  # read-major (JavaData.h:190)
-            if not pairs:
+            if len(readDataArray) == 0 or len(haplotypeDataArray) == 0:
                 raise IllegalArgumentException("no pairs to process")
-            likelihoodArray[:] = self._ctx.compute(PdhmmBatch.from_pairs(pairs))
+            one = b"\0"
+            reads = PdhmmBatch.from_pairs([(one, one, r.readBases, r.readQuals, r.insertionGOP, r.deletionGOP,
+                                            r.overallGCP) for r in readDataArray])
+            haps = PdhmmBatch.from_pairs([(h.haplotypeBases, h.haplotypePDBases, one, one, one, one, one)
+                                          for h in haplotypeDataArray])
+            likelihoodArray[:] = self._ctx.compute_cross(reads, haps)  # read-major (JavaData.h:190)
         except OutOfMemoryError:
             raise OutOfMemoryError("Memory allocation failed")
         except IllegalArgumentException:

@@ -41,6 +41,24 @@ typedef struct {
   const int64_t* read_lengths; /* [batch], 1..max_read_len */
 } gklhip_pdhmm_batch;
 
+/* The reads x haplotypes form of IntelPDHMM.computeLikelihoods (IntelPDHMM.java:83-145): every read against every
+ * haplotype, out[r * n_haps + h] (JavaData.h:177-242 builds exactly this cross product as padded PAIRS before calling
+ * computePDHMM; here each read and each haplotype crosses PCIe once). */
+typedef struct {
+  int32_t n_reads, n_haps;
+  int32_t max_hap_len;       /* row stride of the two haplotype arrays */
+  int32_t max_read_len;      /* row stride of the five read arrays */
+  const int8_t* hap_bases;   /* [n_haps][max_hap_len] */
+  const int8_t* hap_pdbases;
+  const int8_t* read_bases;  /* [n_reads][max_read_len] */
+  const int8_t* read_qual;
+  const int8_t* read_ins_qual;
+  const int8_t* read_del_qual;
+  const int8_t* gcp;
+  const int64_t* hap_lengths;  /* [n_haps] */
+  const int64_t* read_lengths; /* [n_reads] */
+} gklhip_pdhmm_cross;
+
 int gklhip_pdhmm_init(int device /* -1 = current */, gklhip_pdhmm_ctx** out_ctx);
 /* 1 (default) = bit-identical to GKL's AVX-512 PDHMM object (avx512_impl.cc: a*b + c*d contracted to
  * fma(c, d, a*b)); 0 = bit-identical to its AVX2 object (avx2_impl.cc: no FMA).  Same switch as
@@ -49,6 +67,8 @@ int gklhip_pdhmm_set_fma_mode(gklhip_pdhmm_ctx* ctx, int fma_mode);
 /* Host buffers in, out_host[batch] = log10 likelihoods. Negative ins/del/gcp quals ->
  * GKLHIP_ERR_INVALID_ARG (PDHMM_INPUT_DATA_ERROR in the reference). */
 int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_batch* batch, double* out_host);
+/* out_host[n_reads * n_haps], read-major. Same arithmetic, errors and tables as gklhip_pdhmm_compute. */
+int gklhip_pdhmm_compute_cross(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_cross* batch, double* out_host);
 /* HIP-event time of the forward kernel of the last call, milliseconds. */
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* ctx);
 int gklhip_pdhmm_done(gklhip_pdhmm_ctx* ctx);

@@ -210,6 +210,29 @@ def test_pdhmm_gpu_cross_product_shares_haplotypes(pd_ctx, pd_oracle, shape):
 
 
 @pytest.mark.gpu
+def test_pdhmm_gpu_cross_entry_point_equals_paired(pd_ctx, pd_oracle):
+    # gklhip_pdhmm_compute_cross walks reads x haplotypes on the device; the paired entry point gets the same
+    # cross product expanded on the host
+    rng = np.random.RandomState(31)
+    reads = random_pd_batch(rng, 37, read_len=(1, 300), hap_len=(1, 2))       # includes reads over 255 bases (striped)
+    haps = random_pd_batch(rng, 11, read_len=(1, 2), hap_len=(1, 260), flag_rate=0.05)
+    got = pd_ctx.compute_cross(reads, haps)
+    pairs = []
+    for r in range(reads.batch):
+        R = int(reads.read_lengths[r])
+        rr = lambda a: a.reshape(reads.batch, reads.max_read_len)[r, :R]  # noqa: E731
+        for h in range(haps.batch):
+            H = int(haps.hap_lengths[h])
+            hh = lambda a: a.reshape(haps.batch, haps.max_hap_len)[h, :H]  # noqa: E731
+            pairs.append((hh(haps.hap_bases), hh(haps.hap_pdbases), rr(reads.read_bases), rr(reads.read_qual),
+                          rr(reads.read_ins_qual), rr(reads.read_del_qual), rr(reads.gcp)))
+    b = PdhmmBatch.from_pairs(pairs)
+    _, vec = pd_oracle.compute(b, semantics=pd_ctx.sem)
+    assert got.tobytes() == vec.tobytes()
+    assert pd_ctx.compute(b).tobytes() == vec.tobytes()
+
+
+@pytest.mark.gpu
 def test_pdhmm_gpu_argument_errors(pd_ctx):
     from gkl_amd import native
     b = random_pd_batch(np.random.RandomState(5), 8)
@@ -266,7 +289,7 @@ def test_pdhmm_jni_flat_and_holder_paths(pd_oracle):
     assert rc == 0, (cls, msg)
     _, vec = pd_oracle.compute(b, semantics=2)
     assert out.tobytes() == vec.tobytes() and np.max(np.abs(out - exp)) <= TOL
-    # holders: 7 reads x 5 haplotypes, read-major cross product, tiny memory budget -> several batches
+    # holders: 7 reads x 5 haplotypes, read-major cross product (staged once each, crossed on the device)
     rng = np.random.RandomState(9)
     src = random_pd_batch(rng, 7, read_len=(20, 60), hap_len=(30, 80))
     haps = random_pd_batch(rng, 5, read_len=(1, 2), hap_len=(30, 80))
