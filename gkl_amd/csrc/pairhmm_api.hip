@@ -227,7 +227,26 @@ constexpr int kTargetCols = 3072;  // columns of a full-size haplotype group (sw
 #define GKL_RPL_F32 8
 #endif
 constexpr int kRplF32 = GKL_RPL_F32;
-int pick_rpl_f32(int forced) { return forced == 4 ? 4 : kRplF32; }
+// fp32 main pass: which kernel.  rows_per_lane of the config: 0 = choose, 8 = the 8-row kernel, 4 = the dual-chunk
+// packed-math kernel (2 x 4 rows), -4 = the single-chunk 4-row kernel.  Choosing: a small batch (one GATK active
+// region) gives the 8-row kernel fewer jobs than the chip has wavefront slots worth filling (< 2 per SIMD), and a
+// lone wavefront issues one instruction per ~6 cycles; 4 rows per lane doubles the chunks and halves the step.
+struct F32Kernel { int rpl; bool dual; };
+F32Kernel pick_f32_kernel(int forced, int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off) {
+  if (forced == 4) return {4, true};
+  if (forced == -4) return {4, false};
+  if (forced == 8) return {kRplF32, false};
+  int64_t blocks = 0;
+  for (int r = 0; r < n_reads; r++) {
+    const int nb = blocks_for((int)(read_off[r + 1] - read_off[r]), kRplF32);
+    if (nb <= kLanes) blocks += nb;
+  }
+  const int64_t chunks = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
+  const int64_t total_cols = hap_off[n_haps] + n_haps;
+  const int64_t groups = std::min<int64_t>(n_haps, std::max<int64_t>((total_cols + kTargetCols - 1) / kTargetCols,
+                                                                      (4096 + chunks - 1) / chunks));
+  return chunks * groups < 2048 ? F32Kernel{4, false} : F32Kernel{kRplF32, false};
+}
 
 // The whole device-side pipeline on stream `s`; `db` holds DEVICE byte arrays, host offsets.
 int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int finalize_mode, hipStream_t s) {
@@ -245,7 +264,8 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   const auto t_plan0 = std::chrono::steady_clock::now();
   Plan& plan = c->plan;
   const int rpl64 = kRplF64;
-  const int rpl_main = use_double ? rpl64 : pick_rpl_f32(c->cfg.rows_per_lane);
+  const F32Kernel f32k = pick_f32_kernel(c->cfg.rows_per_lane, n_reads, n_haps, db->read_off, db->hap_off);
+  const int rpl_main = use_double ? rpl64 : f32k.rpl;
   static const int target_cols_env = [] { const char* v = getenv("GKLHIP_TARGET_COLS"); return v ? atoi(v) : 0; }();
   build_plan(n_reads, n_haps, db->read_off, db->hap_off, rpl_main, target_cols_env > 0 ? target_cols_env : kTargetCols, &plan);
   // Long reads: pseudo-chunks (lane 0 names the read) + one striped job per (read, stream group)
@@ -405,7 +425,8 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.y0 = reinterpret_cast<const float*>(dp + L.y0_32);
     a.raw = c->raw32.as<float>();
     if (n_main_blocks > 0) {
-      if (rpl_main == 4) launch_stream2<4>(a, fma, ((plan.n_chunks + 1) / 2) * (int)plan.groups.size(), s);
+      if (f32k.dual)          launch_stream2<4>(a, fma, ((plan.n_chunks + 1) / 2) * (int)plan.groups.size(), s);
+      else if (rpl_main == 4) launch_stream<float, 4>(a, fma, n_main_blocks, s);
       else               launch_stream<float, kRplF32>(a, fma, n_main_blocks, s);
     }
     if (n_long_main > 0) {

@@ -73,7 +73,8 @@ typedef struct {
                            0 = arithmetic of GKL's AVX objects (separate mul/add) */
   int32_t finalize;     /* gklhip_finalize for gklhip_compute_device; -1 = default */
   int32_t record_events;/* 1 = bracket kernels with HIP events (gklhip_get_stats) */
-  int32_t rows_per_lane;/* 0 = auto (8); 4 = the dual-chunk packed-math fp32 kernel */
+  int32_t rows_per_lane;/* fp32 main kernel: 0 = auto (8 rows per lane; 4 for small batches), 8 = 8-row kernel,
+                           4 = the dual-chunk packed-math kernel, -4 = the single-chunk 4-row kernel */
 } gklhip_config;
 
 /* Flat structure-of-arrays batch. Offsets always live on the host; the byte

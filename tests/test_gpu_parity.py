@@ -140,17 +140,26 @@ def test_hc_batch_policy_and_tolerance(native, ctx32, ctx64, oracle):
     assert np.mean(ref32 == out) > 0.9
 
 
-@pytest.mark.parametrize("rpl", [4, 8])
+@pytest.mark.parametrize("rpl", [4, 8, -4])
 def test_every_fp32_kernel_variant_bit_exact(native, oracle, rpl):
-    """rows_per_lane 4 = dual-chunk packed kernel, 8 = default."""
+    """rows_per_lane 8 = the 8-row kernel (what auto picks for big batches), 4 = dual-chunk packed kernel,
+    -4 = single-chunk 4-row kernel (what auto picks for small batches)."""
     b = make_batch("hc", 150, 12, seed=77)
-    rng = np.random.RandomState(rpl)
+    rng = np.random.RandomState(abs(rpl))
     b2 = random_batch(rng, 30, 7, read_len=(1, 250), hap_len=(1, 90), alphabet=b"ACGTN")
     with native.PairHmmContext(rows_per_lane=rpl) as c:
         assert c.stats()["rows_per_lane"] == 0
         check_against_oracle(c, oracle, b)
-        assert c.stats()["rows_per_lane"] == rpl
+        assert c.stats()["rows_per_lane"] == abs(rpl)
         check_against_oracle(c, oracle, b2)
+
+
+def test_auto_picks_the_kernel_by_batch_size(native, oracle):
+    with native.PairHmmContext() as c:
+        check_against_oracle(c, oracle, make_batch("hc", 100, 10, seed=5))      # one active region
+        assert c.stats()["rows_per_lane"] == 4
+        check_against_oracle(c, oracle, make_batch("hc", 1500, 40, seed=6))     # enough jobs to fill the chip
+        assert c.stats()["rows_per_lane"] == 8
 
 
 @pytest.mark.parametrize("rpl", [0, 4])
