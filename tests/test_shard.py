@@ -80,3 +80,37 @@ def test_world_size_2_gloo_gather_matches_single_process():
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret.get("ok") is True
     assert ret.get("ok_pipelined") is True
+
+
+def _gpu_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gkl_amd import native
+        batch = make_batch("hc", 301, 9, seed=11)
+        with native.PairHmmContext() as ctx:
+            def local(shard):
+                out = np.empty(shard.n_pairs)
+                ctx.compute(shard, out)
+                return out
+            full = compute_sharded(batch, local, device="cpu")
+        if rank == 0:
+            from oracle.oracle import Oracle
+            ret["ok_gpu"] = bool(full is not None and full.tobytes() == Oracle().batch(batch, n_threads=4).tobytes())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_world_size_2_shards_on_the_gpu_match_the_oracle():
+    # two ranks share the one GPU of the test box (the driver's multi-GPU run gives each rank its own): every rank
+    # runs the HIP path on its read range, rank 0 gathers (gloo here, RCCL in bench.py) and compares bit for bit
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gpu_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get("ok_gpu") is True
