@@ -255,3 +255,18 @@ def test_sw_jni_and_mirror_paths(sw_oracle):
     assert sw.align(ref, ref, SWParameters(IntelSmithWaterman.MAXIMUM_SW_MATCH_VALUE, -5, -10, -10),
                     SWOverhangStrategy.IGNORE).cigar == f"{n}M"
     sw.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_sw_gpu_maximum_sequence_length(sw_ctx, sw_oracle):
+    # maxSequenceFullAlignmentTest (SmithWatermanUnitTest.java:207-229, disabled in the reference): 32 767 x 32 767 with
+    # the largest match value; 64 stripes of 512 rows, ~1.07e9 cells in one wavefront
+    n = 32 * 1024 - 1
+    rng = np.random.RandomState(99)
+    ref = bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+    got = sw_ctx.align(ref, ref, (64 * 1024, -5, -10, -10), IGNORE)
+    assert got == (f"{n}M".encode(), len(f"{n}M"), 0)
+    alt = mutate(rng, ref[1000:31000], 0.01)
+    exp = sw_oracle.align(ref, alt, PARAM_SETS[0], SOFTCLIP)[1:]
+    assert sw_ctx.align(ref, alt, PARAM_SETS[0], SOFTCLIP) == exp
