@@ -193,7 +193,10 @@ def main():
                          "frac": round(achieved / (PEAK_FP32_VECTOR_TFLOPS / 2 if a.double else PEAK_FP32_VECTOR_TFLOPS), 4),
                          "traffic": traffic, "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(k_ms, 3),
                          "kernel_gcups": round(batch.cells / k_ms / 1e6, 1),
-                         "note": "vector-FMA bound recurrence (no MFMA / not HBM bound); peak = fp32 vector = fp32 MFMA dense peak"},
+                         "note": "vector-FMA bound recurrence (no MFMA / not HBM bound); peak = fp32 vector = fp32 MFMA dense "
+                                 "peak, reachable only by packed FMA-only code. The recurrence needs 4 mul + 4 fma per cell "
+                                 "(1.5 flop per instruction) and a SIMD retires one plain VALU op per ~2.7 cycles (measured), "
+                                 "so its issue-bound ceiling is ~7 TCUPS = 0.53 of peak (DESIGN.md section 3)"},
             "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(float(np.mean(ms_fb)), 3),
                            "device_total": round(float(np.mean(ms_dev)), 3)},
             "plan": {"chunks": st["n_chunks"], "hap_groups": st["n_hap_groups"], "rows_per_lane": st["rows_per_lane"],
