@@ -112,7 +112,14 @@ struct gklhip_ctx {
   hipStream_t copy_stream = nullptr;  // early D2H of the fp32 results while the fp64 pass runs
   hipEvent_t policy_done = nullptr, early_copy_done = nullptr;
   // events
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // events: kEventRing sets of 6 (call start, main begin/end, fallback begin/end, call end); record_events == 1 uses
+  // set 0 and synchronises every call, record_events == 2 rotates through the ring and never synchronises
+  // (gklhip_get_step_times reads a set later)
+  static constexpr int kEventRing = 64;
+  hipEvent_t ev_ring[kEventRing][6] = {};
+  hipEvent_t* ev = ev_ring[0];
+  int64_t calls = 0;
+  bool ring_double[kEventRing] = {};
   // last call
   gklhip_stats stats;
   int64_t last_pairs = 0;
@@ -345,6 +352,12 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   if (!use_double) HIP_TRY(hipMemsetAsync(c->read_fail.p, 0, (size_t)n_reads * 4, s));
 
   const bool ev = c->cfg.record_events != 0;
+  const bool deferred = c->cfg.record_events == 2;
+  if (ev) {
+    c->ev = c->ev_ring[deferred ? c->calls % gklhip_ctx::kEventRing : 0];
+    c->ring_double[deferred ? c->calls % gklhip_ctx::kEventRing : 0] = use_double;
+    c->calls++;
+  }
   if (ev) HIP_TRY(hipEventRecord(c->ev[0], s));
 
   // ---- haplotype streams ----
@@ -507,7 +520,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   c->last_stream = s;
   c->have_last = true;
 
-  if (ev) {
+  if (ev && !deferred) {
     HIP_TRY(hipEventSynchronize(c->ev[5]));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); st.ms_fwd_main = ms;
@@ -588,8 +601,12 @@ int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
       hipEventCreateWithFlags(&c->early_copy_done, hipEventDisableTiming) != hipSuccess)
     return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
   if (hipEventRecord(c->stage_free, c->stream) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventRecord failed"));
-  for (auto& e : c->ev)
-    if (hipEventCreate(&e) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  {
+    const int sets = c->cfg.record_events == 2 ? gklhip_ctx::kEventRing : 1;
+    for (int k = 0; k < sets; k++)
+      for (auto& e : c->ev_ring[k])
+        if (hipEventCreate(&e) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  }
   if ((rc = upload_tables(c, host_tables_f32(), &c->tab32, &c->dt32))) return bail(rc);
   if ((rc = upload_tables(c, host_tables_f64(), &c->tab64, &c->dt64))) return bail(rc);
   *out_ctx = c;
@@ -610,7 +627,8 @@ int gklhip_done(gklhip_ctx* c) {
   if (c->policy_done) (void)hipEventDestroy(c->policy_done);
   if (c->early_copy_done) (void)hipEventDestroy(c->early_copy_done);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
-  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& set : c->ev_ring)
+    for (auto& e : set) if (e) (void)hipEventDestroy(e);
   if (c->stage_free) (void)hipEventDestroy(c->stage_free);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -702,6 +720,24 @@ void* gklhip_host_alloc(size_t bytes) {
 
 void gklhip_host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+
+int gklhip_get_step_times(gklhip_ctx* c, int32_t steps_back, float* ms_main, float* ms_fallback, float* ms_total) {
+  if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (c->cfg.record_events != 2) return fail(GKLHIP_ERR_INVALID_ARG, "context was not created with record_events = 2");
+  if (steps_back < 0 || steps_back >= gklhip_ctx::kEventRing || steps_back >= c->calls)
+    return fail(GKLHIP_ERR_INVALID_ARG, "steps_back %d outside the %d recorded calls", steps_back,
+                (int)std::min<int64_t>(c->calls, gklhip_ctx::kEventRing));
+  HIP_TRY(hipSetDevice(c->device));
+  const int slot = (int)((c->calls - 1 - steps_back) % gklhip_ctx::kEventRing);
+  hipEvent_t* e = c->ev_ring[slot];
+  HIP_TRY(hipEventSynchronize(e[5]));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e[1], e[2])); if (ms_main) *ms_main = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, e[3], e[4])); if (ms_fallback) *ms_fallback = c->ring_double[slot] ? 0.f : ms;
+  HIP_TRY(hipEventElapsedTime(&ms, e[0], e[5])); if (ms_total) *ms_total = ms;
+  return GKLHIP_OK;
 }
 
 int gklhip_get_stats(gklhip_ctx* c, gklhip_stats* out) {

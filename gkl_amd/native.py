@@ -82,6 +82,9 @@ def load_library(path: Optional[str] = None):
     lib.gklhip_compute_device.argtypes = [C.c_void_p, C.POINTER(CBatch), C.c_void_p, C.c_void_p]
     lib.gklhip_compute_device.restype = C.c_int
     lib.gklhip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    lib.gklhip_get_step_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                          C.POINTER(C.c_float)]
+    lib.gklhip_get_step_times.restype = C.c_int
     lib.gklhip_get_stats.restype = C.c_int
     lib.gklhip_get_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gklhip_get_raw.restype = C.c_int
@@ -207,6 +210,14 @@ class PairHmmContext:
         if st != OK:
             _raise(self.lib, st)
         return out
+
+    def step_times(self, steps_back: int = 0):
+        """record_events=2 contexts: (ms_main, ms_fallback, ms_total_device) of the call `steps_back` calls ago."""
+        a, b, t = C.c_float(0), C.c_float(0), C.c_float(0)
+        st = self.lib.gklhip_get_step_times(self.handle, int(steps_back), C.byref(a), C.byref(b), C.byref(t))
+        if st != OK:
+            _raise(self.lib, st)
+        return a.value, b.value, t.value
 
     def stats(self) -> dict:
         s = Stats()

@@ -72,7 +72,9 @@ typedef struct {
   int32_t fma_mode;     /* 1 = arithmetic of GKL's AVX-512 objects (gcc-contracted FMA; default),
                            0 = arithmetic of GKL's AVX objects (separate mul/add) */
   int32_t finalize;     /* gklhip_finalize for gklhip_compute_device; -1 = default */
-  int32_t record_events;/* 1 = bracket kernels with HIP events (gklhip_get_stats) */
+  int32_t record_events;/* 1 = bracket kernels with HIP events and synchronise every call (gklhip_get_stats);
+                           2 = record into a ring of 64 event sets WITHOUT synchronising: calls pipeline, the
+                               times are read afterwards with gklhip_get_step_times */
   int32_t rows_per_lane;/* fp32 main kernel: 0 = auto (8 rows per lane; 4 for small batches), 8 = 8-row kernel,
                            4 = the dual-chunk packed-math kernel, -4 = the single-chunk 4-row kernel */
 } gklhip_config;
@@ -133,6 +135,10 @@ int gklhip_compute_device(gklhip_ctx* ctx, const gklhip_batch* dev_batch, double
 
 /* Introspection (tests, bench). */
 int gklhip_get_stats(gklhip_ctx* ctx, gklhip_stats* out);
+
+/* record_events == 2: HIP-event times (ms) of the call `steps_back` calls ago (0 = the last one; at most 63):
+ * main forward kernel, fp64 fallback kernel, whole device pipeline.  Waits for that call to finish. */
+int gklhip_get_step_times(gklhip_ctx* ctx, int32_t steps_back, float* ms_main, float* ms_fallback, float* ms_total);
 /* Raw sums of the last call, copied to host arrays of n_pairs entries (any may be NULL).
  * raw64 is meaningful where used64 != 0. Synchronises the stream. */
 int gklhip_get_raw(gklhip_ctx* ctx, float* raw32, double* raw64, uint8_t* used64);

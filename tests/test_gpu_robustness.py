@@ -83,3 +83,26 @@ def test_two_contexts_do_not_interfere(native, oracle):
         o1b = c1.compute(b1)
     assert np.array_equal(bits(o1a), bits(o1b)) and np.array_equal(bits(o1a), bits(oracle.batch(b1, n_threads=8)))
     assert np.array_equal(bits(o2), bits(oracle.batch(b2, use_double=True, n_threads=8)))
+
+
+def test_deferred_event_ring_reports_each_pipelined_call(native, oracle):
+    # record_events=2: no call synchronises; gklhip_get_step_times reads the HIP-event times afterwards
+    import torch
+    from gkl_amd.errors import IllegalArgumentException
+    b = make_batch("hc", 400, 16, seed=21)
+    db = native.DeviceBatch.upload(b)
+    outs = [torch.empty(b.n_pairs, dtype=torch.float64, device="cuda") for _ in range(5)]
+    with native.PairHmmContext(record_events=2) as c:
+        for o in outs:
+            c.compute_device(db, o)
+        times = [c.step_times(k) for k in range(5)]
+        with pytest.raises(IllegalArgumentException):
+            c.step_times(5)
+    assert all(t[0] > 0 and t[2] >= t[0] + t[1] - 1e-3 for t in times)
+    ref = outs[0].cpu().numpy()
+    assert all(np.array_equal(o.cpu().numpy(), ref) for o in outs[1:])
+    exp = oracle.batch(b, use_double=True, n_threads=4)
+    assert np.max(np.abs(ref - exp) / np.abs(exp)) < 1e-5   # device finalisation: tolerance of the north star
+    with native.PairHmmContext(record_events=1) as c:
+        with pytest.raises(IllegalArgumentException):
+            c.step_times(0)
