@@ -453,7 +453,13 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa);
-    if (finalize_mode == kModePacked) HIP_TRY(hipEventRecord(c->policy_done, s));
+    HIP_TRY(hipEventRecord(c->policy_done, s));
+    const bool side_finalize = finalize_mode == GKLHIP_FINALIZE_DEVICE_F64 || finalize_mode == GKLHIP_FINALIZE_DEVICE_REF32;
+    if (side_finalize) {
+      HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->policy_done, 0));
+      hipLaunchKernelGGL(finalize32_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, c->copy_stream, fa);
+      HIP_TRY(hipEventRecord(c->early_copy_done, c->copy_stream));
+    }
     // ---- fp64 recomputation of the underflowed pairs ----
     FwdArgs<double> d{};
     fill_common(d);
@@ -512,6 +518,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
+    if (side_finalize) HIP_TRY(hipStreamWaitEvent(s, c->early_copy_done, 0));  // join the side stream
   }
   if (ev) HIP_TRY(hipEventRecord(c->ev[5], s));
   HIP_TRY(hipGetLastError());

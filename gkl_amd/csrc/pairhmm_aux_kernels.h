@@ -82,14 +82,19 @@ __global__ void policy_kernel(FinalizeArgs a) {
     if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[i] = 0;  // "pending": filled in by finalize64_kernel
   } else {
     a.used64[i] = 0;
-    if (a.mode == GKLHIP_FINALIZE_DEVICE_F64) {
-      a.out[i] = log10((double)v) - a.log10_init32_as_f64;
-    } else if (a.mode == GKLHIP_FINALIZE_DEVICE_REF32) {
-      a.out[i] = (double)((float)log10((double)v) - a.log10_init_f);
-    } else if (a.mode == kModePacked) {
-      reinterpret_cast<uint64_t*>(a.out)[i] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
-    }
+    // the device log10 of the kept pairs is finalize32_kernel's job: it runs beside the fp64 pass
+    if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[i] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
   }
+}
+
+// log10 of the fp32 sums the policy kept (device finalisation modes).  Launched on the context's side stream
+// right after policy_kernel, so its ~1.3 M double-precision log10 overlap the planning kernels and the fp64 pass.
+__global__ void finalize32_kernel(FinalizeArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n || a.used64[i]) return;
+  const float v = a.raw32[i];
+  if (a.mode == GKLHIP_FINALIZE_DEVICE_F64) a.out[i] = log10((double)v) - a.log10_init32_as_f64;
+  else if (a.mode == GKLHIP_FINALIZE_DEVICE_REF32) a.out[i] = (double)((float)log10((double)v) - a.log10_init_f);
 }
 
 // log10 of the fp64 sums: all pairs (useDoublePrecision) or the queued ones.
