@@ -348,8 +348,13 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   if ((rc = c->counters.reserve(64))) return rc;
   if ((rc = c->read_fail.reserve((size_t)n_reads * 4))) return rc;
   if ((rc = c->stream_buf.reserve(plan.stream_src.size() * 4))) return rc;
-  HIP_TRY(hipMemsetAsync(c->counters.p, 0, 64, s));
-  if (!use_double) HIP_TRY(hipMemsetAsync(c->read_fail.p, 0, (size_t)n_reads * 4, s));
+  const int n_hist = use_double ? 0 : 2 * (n_haps + 2);
+  if (!use_double && (rc = c->fail_hist.reserve((size_t)n_hist * 4))) return rc;
+  {
+    const int n_clear = std::max({16, use_double ? 0 : n_reads, n_hist});
+    hipLaunchKernelGGL(clear3_kernel, dim3((unsigned)((n_clear + 255) / 256)), dim3(256), 0, s, c->counters.as<int32_t>(), 16,
+                       c->read_fail.as<int32_t>(), use_double ? 0 : n_reads, c->fail_hist.as<int32_t>(), n_hist);
+  }
 
   const bool ev = c->cfg.record_events != 0;
   const bool deferred = c->cfg.record_events == 2;
@@ -452,7 +457,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
       else               launch_long<float, kRplF32>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa);
+    hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + kPolicyBlock - 1) / kPolicyBlock)), dim3(kPolicyBlock), 0, s, fa);
     HIP_TRY(hipEventRecord(c->policy_done, s));
     const bool side_finalize = finalize_mode == GKLHIP_FINALIZE_DEVICE_F64 || finalize_mode == GKLHIP_FINALIZE_DEVICE_REF32;
     if (side_finalize) {
@@ -471,7 +476,6 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     // pack them into chunks, queue one job per (chunk, needed haplotype run), then let persistent
     // wavefronts stream those jobs -- same WaveJob template as the main pass, T = double.
     const size_t n_groups = plan.groups.size();
-    if ((rc = c->fail_hist.reserve((size_t)(2 * (n_haps + 2)) * 4))) return rc;
     if ((rc = c->fail_order.reserve((size_t)n_reads * 4))) return rc;
     if ((rc = c->lanes2.reserve((size_t)n_reads * kLanes * sizeof(LaneSlot)))) return rc;
     const size_t max_jobs = (size_t)n_reads * ((size_t)(n_haps + 1) / 2 + n_groups);
@@ -479,7 +483,6 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     int32_t* hist = c->fail_hist.as<int32_t>();
     int32_t* pos = hist + (n_haps + 2);
     int32_t* cnts = c->counters.as<int32_t>();  // [0] pairs [2] jobs [3] next job [4] fail reads [5] chunks
-    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(2 * (n_haps + 2)) * 4, s));
     const unsigned rb = (unsigned)((n_reads + 255) / 256);
     hipLaunchKernelGGL(fail_hist_kernel, dim3(rb), dim3(256), 0, s, c->read_fail.as<int32_t>(), n_reads, hist,
                        b.read_off, kLanes * rpl64 - 1);

@@ -11,6 +11,15 @@
 
 namespace gklhip {
 
+// Zeroes the three small per-call arrays (counters, per-read fail counts, fail histogram) in one launch; three
+// hipMemsetAsync blits cost a barrier bubble of ~50 us per step between back-to-back batches.
+__global__ void clear3_kernel(int32_t* a, int na, int32_t* b, int nb, int32_t* c, int nc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < na) a[i] = 0;
+  if (i < nb) b[i] = 0;
+  if (i < nc) c[i] = 0;
+}
+
 // stream_src (host plan) -> stream entries: haplotype base codes / separators / idle.
 __global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8_t* __restrict__ hap_bases,
                                     uint32_t* __restrict__ stream, int n) {
@@ -54,22 +63,30 @@ struct FinalizeArgs {
 
 // Precision policy of IntelPairHmm.cc:157-165 on the raw fp32 sums: keep (and
 // finalise) pairs with sum >= 1e-28f, queue the rest for the fp64 kernel.
-__global__ void policy_kernel(FinalizeArgs a) {
+constexpr int kPolicyBlock = 1024;
+__global__ __launch_bounds__(kPolicyBlock) void policy_kernel(FinalizeArgs a) {
+  __shared__ int32_t wave_cnt[kPolicyBlock / 64], wave_base[kPolicyBlock / 64];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < a.n;
   const float v = in_range ? a.raw32[i] : 1.0f;
   const bool fails = in_range && v < 1e-28f;  // NaN compares false and stays fp32, like the reference
-  // One atomic per wavefront instead of one per pair: ~265 k pairs of the bench batch hit the same counter.
+  // One atomic per BLOCK on the queue counter: atomics on a single address retire one per ~7 ns at the L2, and
+  // one per wavefront (20 k of them for the bench batch) made this kernel take 150 us.
+  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
   const uint64_t mask = __ballot(fails);
+  if (lane == 0) wave_cnt[wave] = __builtin_popcountll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < kPolicyBlock / 64; w++) { wave_base[w] = total; total += wave_cnt[w]; }
+    const int base = total ? atomicAdd(a.count, total) : 0;
+    for (int w = 0; w < kPolicyBlock / 64; w++) wave_base[w] += base;
+  }
+  __syncthreads();
   if (mask) {
-    const int lane = (int)(threadIdx.x & 63u);
     const int leader = __builtin_ctzll(mask);
-    const int total = __builtin_popcountll(mask);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(a.count, total);
-    base = __shfl(base, leader, 64);
     const int32_t read = fails ? (int32_t)(i / a.n_haps) : -1;
-    if (fails) a.list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)i;
+    if (fails) a.list[wave_base[wave] + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)i;
     // r-major pairs: the failing lanes of a wavefront usually belong to one read (n_haps >= 64) or a few
     const int32_t lead_read = __shfl(read, leader, 64);
     const uint64_t same = __ballot(fails && read == lead_read);
