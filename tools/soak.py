@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Dev tool: 20 s of GATK-sized calls through the host-buffer C ABI checked bit for bit against the oracle, then 300
+back-to-back bench-sized batches on the device-resident path (no synchronisation in between)."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gkl_amd import native
 from gkl_amd.synth import make_batch
