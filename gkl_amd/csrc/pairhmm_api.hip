@@ -104,7 +104,7 @@ struct gklhip_ctx {
   hipEvent_t stage_free = nullptr;  // previous call's uploads have left the staging buffer
   // per-call device scratch
   DevBuf raw32, raw64, used64, list, counters, stream_buf, read_off_dev, out_dev;
-  DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist;
+  DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist, hap_flags;
   // host-API device copies of the batch, packed results (device + pinned), finalisation workers
   DevBuf batch_dev, res_dev;
   PinBuf res_pin, res_pin2;
@@ -367,9 +367,11 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
 
   // ---- haplotype streams ----
   const int n_stream = (int)plan.stream_src.size();
+  if ((rc = c->hap_flags.reserve((size_t)n_haps))) return rc;
   hipLaunchKernelGGL(build_stream_kernel, dim3((n_stream + 255) / 256), dim3(256), 0, s,
                      reinterpret_cast<const int32_t*>(dp + L.stream_src), db->hap_bases,
-                     c->stream_buf.as<uint32_t>(), n_stream);
+                     c->stream_buf.as<uint32_t>(), n_stream, reinterpret_cast<const int32_t*>(dp + L.hap_len),
+                     c->hap_flags.as<uint8_t>());
 
   DevBatch b;
   b.read_bases = db->read_bases; b.read_quals = db->read_quals; b.ins = db->ins_gop;
@@ -384,6 +386,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos);
     a.hap_orig = reinterpret_cast<const int32_t*>(dp + L.hap_orig);
     a.hap_sidx = reinterpret_cast<const int32_t*>(dp + L.hap_sidx);
+    a.hap_has_n = c->hap_flags.as<uint8_t>();
     a.groups = reinterpret_cast<const HapGroup*>(dp + L.groups);
     a.n_groups = (int)plan.groups.size();
     a.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.lanes);
@@ -629,7 +632,7 @@ int gklhip_done(gklhip_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev, &c->raw32, &c->raw64, &c->used64, &c->list,
                     &c->counters, &c->stream_buf, &c->read_off_dev, &c->out_dev, &c->batch_dev, &c->read_fail,
-                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->res_dev})
+                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->res_dev, &c->hap_flags})
     b->release();
   c->stage.release();
   c->res_pin.release();

@@ -21,8 +21,11 @@ __global__ void clear3_kernel(int32_t* a, int na, int32_t* b, int nb, int32_t* c
 }
 
 // stream_src (host plan) -> stream entries: haplotype base codes / separators / idle.
+// The thread of a separator also scans its haplotype for 'N' (hap_has_n: the fp64 kernels route such haplotypes
+// through the general step, see WaveJob::kCodes).
 __global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8_t* __restrict__ hap_bases,
-                                    uint32_t* __restrict__ stream, int n) {
+                                    uint32_t* __restrict__ stream, int n, const int32_t* __restrict__ hap_len,
+                                    uint8_t* __restrict__ hap_has_n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t s = src[i];
@@ -33,7 +36,11 @@ __global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8
   } else if (s == -1) {
     e = kEntIdle;
   } else {
-    e = kEntSep | (uint32_t)(-2 - s);
+    const int k = -2 - s;  // stream-order haplotype whose columns are the hap_len[k] entries before this one
+    e = kEntSep | (uint32_t)k;
+    uint8_t any = 0;
+    for (int j = 1; j <= hap_len[k]; j++) any |= hap_bases[src[i - j]] == 'N';
+    hap_has_n[k] = any;
   }
   stream[i] = e;
 }

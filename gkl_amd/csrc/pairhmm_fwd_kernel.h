@@ -83,6 +83,7 @@ struct FwdArgs {
   const int32_t* hap_orig;  // [n_haps] stream order -> caller's hap index
   const int32_t* hap_sidx;  // [n_haps] caller's hap index -> stream order
   const T* y0;              // [n_haps] stream order: INITIAL_CONSTANT / (T)haplen (host-computed)
+  const uint8_t* hap_has_n; // [n_haps] stream order: the haplotype contains an 'N' (set by build_stream_kernel)
   const HapGroup* groups;
   int32_t n_groups;
   const LaneSlot* chunk_lanes;  // [n_chunks * 64]
@@ -199,7 +200,13 @@ struct WaveJob {
   static constexpr int kPerVec = kVecBytes / (int)sizeof(T);        // rows per 16-byte LDS vector
   static constexpr int kPlanes = RPL / kPerVec;                      // 16-byte vectors per lane per code
   static constexpr int kRowBytes = kPlanes * kLanes * kVecBytes;     // one base code, all rows
-  static constexpr int kLdsBytes = 5 * kRowBytes;  // codes A C T G N; idle columns are handled in step_any
+  // Prior table: one plane per haplotype base code.  fp32 keeps five (A C T G N = 10 KB, 4 wavefronts per SIMD
+  // either way).  fp64 keeps four: 5 x 3 KB would let only 10 blocks share a CU's LDS (2.5 per SIMD), 4 x 3 KB
+  // lets 13 (3 per SIMD, what the 152-160 VGPRs allow) -- measured 4 % on the fp64 pass.  A haplotype 'N'
+  // matches every read base, so its prior is the row's OWN plane; such columns are rare and take the general
+  // step, which gathers them row by row (haplotypes containing an N never enter the unrolled loop).
+  static constexpr int kCodes = sizeof(T) == 8 ? 4 : 5;
+  static constexpr int kLdsBytes = kCodes * kRowBytes;  // idle columns are handled in step_any
   static_assert(RPL % kPerVec == 0, "RPL must fill whole 16-byte vectors");
   using Vec = T __attribute__((ext_vector_type(kPerVec)));
 
@@ -213,6 +220,7 @@ struct WaveJob {
   uint32_t lmask;     // 0 if this lane starts a read / is idle
   int32_t out_read;   // read whose LAST row is this lane's bottom row, else -1
   int32_t padb_slot;  // slot of the Y0-holding pad row in this lane, else -1
+  uint32_t own_codes; // kCodes == 4: 2 bits per row, the plane holding the row's match prior (its own base)
   unsigned char* lds; // this wave's prior table
 
   // Load one lane's rows: transition probabilities in registers, priors in LDS.
@@ -265,9 +273,12 @@ struct WaveJob {
         code[s] = -1;
       }
     }
-    // prior table: [base code 0..5][plane][lane][kPerVec rows]
+    own_codes = 0;
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
+    for (int s = 0; s < RPL; s++) own_codes |= (uint32_t)((code[s] >= 0 && code[s] < 4) ? code[s] : 0) << (2 * s);
+    // prior table: [base code][plane][lane][kPerVec rows]
+#pragma unroll
+    for (int c = 0; c < kCodes; c++) {
 #pragma unroll
       for (int pl = 0; pl < kPlanes; pl++) {
         Vec v;
@@ -312,6 +323,16 @@ struct WaveJob {
       for (int k = 0; k < kPerVec; k++) pr[pl * kPerVec + k] = v[k];
     }
   }
+  // kCodes == 4, haplotype base 'N': row s takes its prior from the plane of its own base (a read-base 'N' row
+  // and pad rows hold the same value in every plane).
+  __device__ __forceinline__ void load_priors_n(int lane, T* pr) const {
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+      const uint32_t c = (own_codes >> (2 * s)) & 3u;
+      pr[s] = *reinterpret_cast<const T*>(lds + c * (uint32_t)kRowBytes + (s / kPerVec) * (kLanes * kVecBytes) +
+                                          (uint32_t)lane * kVecBytes + (s % kPerVec) * sizeof(T));
+    }
+  }
 
   // One anti-diagonal step of the recurrence for this lane's RPL rows.
   __device__ __forceinline__ void advance(const T* pr, T* nM, T* nX, T* nY) const {
@@ -353,8 +374,15 @@ struct WaveJob {
     ent = dpp_shr1_keep(entry, ent);
     const bool sep = (int32_t)ent < 0;
     const bool off = sep || ent == kEntIdle;  // no haplotype base in this column: prior 0
+    const bool is_n = kCodes == 4 && ent == 4u;
     T pr[RPL], nM[RPL], nX[RPL], nY[RPL];
-    load_priors(off ? 0u : ent, lane, pr);
+    load_priors((off || is_n) ? 0u : ent, lane, pr);
+    if (kCodes == 4 && __ballot(is_n) != 0) {
+      T pn[RPL];
+      load_priors_n(lane, pn);
+#pragma unroll
+      for (int s = 0; s < RPL; s++) pr[s] = is_n ? pn[s] : pr[s];
+    }
 #pragma unroll
     for (int s = 0; s < RPL; s++) pr[s] = off ? T(0) : pr[s];
     advance(pr, nM, nX, nY);
@@ -388,6 +416,7 @@ struct WaveJob {
     int fast_from = kLanes - 1;  // the fill: lanes still idle until t = 63
     for (int k = hap_begin; k < hap_end; k++) {
       const int sep_at = a.hap_pos[k] - sb + a.hap_len[k];  // stream-relative separator position
+      if (kCodes == 4 && a.hap_has_n[k]) fast_from = sep_at;  // an 'N' somewhere in it: general steps throughout
       const int slow_end = fast_from < sep_at ? fast_from : sep_at;
       run_any(a, sp, t, slow_end, lane, hap_begin, hap_end);
       for (; t + U <= sep_at; t += U) {
