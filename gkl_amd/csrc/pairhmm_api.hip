@@ -350,10 +350,13 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   if ((rc = c->stream_buf.reserve(plan.stream_src.size() * 4))) return rc;
   const int n_hist = use_double ? 0 : 2 * (n_haps + 2);
   if (!use_double && (rc = c->fail_hist.reserve((size_t)n_hist * 4))) return rc;
+  const int n_flag_words = (n_haps + 3) / 4;
+  if ((rc = c->hap_flags.reserve((size_t)n_flag_words * 4))) return rc;
   {
-    const int n_clear = std::max({16, use_double ? 0 : n_reads, n_hist});
-    hipLaunchKernelGGL(clear3_kernel, dim3((unsigned)((n_clear + 255) / 256)), dim3(256), 0, s, c->counters.as<int32_t>(), 16,
-                       c->read_fail.as<int32_t>(), use_double ? 0 : n_reads, c->fail_hist.as<int32_t>(), n_hist);
+    const int n_clear = std::max({16, use_double ? 0 : n_reads, n_hist, n_flag_words});
+    hipLaunchKernelGGL(clear_kernel, dim3((unsigned)((n_clear + 255) / 256)), dim3(256), 0, s, c->counters.as<int32_t>(), 16,
+                       c->read_fail.as<int32_t>(), use_double ? 0 : n_reads, c->fail_hist.as<int32_t>(), n_hist,
+                       c->hap_flags.as<int32_t>(), n_flag_words);
   }
 
   const bool ev = c->cfg.record_events != 0;
@@ -367,10 +370,9 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
 
   // ---- haplotype streams ----
   const int n_stream = (int)plan.stream_src.size();
-  if ((rc = c->hap_flags.reserve((size_t)n_haps))) return rc;
   hipLaunchKernelGGL(build_stream_kernel, dim3((n_stream + 255) / 256), dim3(256), 0, s,
                      reinterpret_cast<const int32_t*>(dp + L.stream_src), db->hap_bases,
-                     c->stream_buf.as<uint32_t>(), n_stream, reinterpret_cast<const int32_t*>(dp + L.hap_len),
+                     c->stream_buf.as<uint32_t>(), n_stream, reinterpret_cast<const int32_t*>(dp + L.hap_pos), n_haps,
                      c->hap_flags.as<uint8_t>());
 
   DevBatch b;

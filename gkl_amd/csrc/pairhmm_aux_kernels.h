@@ -11,21 +11,22 @@
 
 namespace gklhip {
 
-// Zeroes the three small per-call arrays (counters, per-read fail counts, fail histogram) in one launch; three
+// Zeroes the small per-call arrays (counters, per-read fail counts, fail histogram, haplotype flags) in one launch;
 // hipMemsetAsync blits cost a barrier bubble of ~50 us per step between back-to-back batches.
-__global__ void clear3_kernel(int32_t* a, int na, int32_t* b, int nb, int32_t* c, int nc) {
+__global__ void clear_kernel(int32_t* a, int na, int32_t* b, int nb, int32_t* c, int nc, int32_t* d, int nd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < na) a[i] = 0;
   if (i < nb) b[i] = 0;
   if (i < nc) c[i] = 0;
+  if (i < nd) d[i] = 0;
 }
 
 // stream_src (host plan) -> stream entries: haplotype base codes / separators / idle.
-// The thread of a separator also scans its haplotype for 'N' (hap_has_n: the fp64 kernels route such haplotypes
-// through the general step, see WaveJob::kCodes).
+// A thread that meets an 'N' also flags its haplotype (hap_has_n, zeroed beforehand: the fp64 kernels route such
+// haplotypes through the general step, see WaveJob::kCodes); it finds the haplotype by bisecting hap_pos.
 __global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8_t* __restrict__ hap_bases,
-                                    uint32_t* __restrict__ stream, int n, const int32_t* __restrict__ hap_len,
-                                    uint8_t* __restrict__ hap_has_n) {
+                                    uint32_t* __restrict__ stream, int n, const int32_t* __restrict__ hap_pos,
+                                    int n_haps, uint8_t* __restrict__ hap_has_n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t s = src[i];
@@ -33,14 +34,18 @@ __global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8
   if (s >= 0) {
     const uint8_t b = hap_bases[s];  // pairhmm_common.h:57-61: A0 C1 T2 G3 N4, anything else 0
     e = b == 'C' ? 1u : b == 'T' ? 2u : b == 'G' ? 3u : b == 'N' ? 4u : 0u;
+    if (b == 'N') {
+      int lo = 0, hi = n_haps - 1;  // largest stream-order haplotype whose first column is at or before i
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (hap_pos[mid] <= i) lo = mid; else hi = mid - 1;
+      }
+      hap_has_n[lo] = 1;
+    }
   } else if (s == -1) {
     e = kEntIdle;
   } else {
-    const int k = -2 - s;  // stream-order haplotype whose columns are the hap_len[k] entries before this one
-    e = kEntSep | (uint32_t)k;
-    uint8_t any = 0;
-    for (int j = 1; j <= hap_len[k]; j++) any |= hap_bases[src[i - j]] == 'N';
-    hap_has_n[k] = any;
+    e = kEntSep | (uint32_t)(-2 - s);
   }
   stream[i] = e;
 }
