@@ -99,9 +99,14 @@ struct gklhip_ctx {
   DevTables<float> dt32;
   DevTables<double> dt64;
   // per-call plan uploads (pinned staging -> device)
-  PinBuf stage;
-  DevBuf plan_dev;
-  hipEvent_t stage_free = nullptr;  // previous call's uploads have left the staging buffer
+  // Two slots alternate from call to call: the plan of call k+1 is staged and uploaded (own stream) while the
+  // kernels of call k still read theirs -- back-to-back batches then never wait for the 1.7 MB plan block.
+  PinBuf stage_slot[2];
+  DevBuf plan_dev_slot[2];
+  hipEvent_t stage_free_slot[2] = {nullptr, nullptr};   // the slot's upload has left the staging buffer
+  hipEvent_t plan_unused_slot[2] = {nullptr, nullptr};  // the last call that used the slot's device copy has finished
+  hipStream_t upload_stream = nullptr;
+  int plan_slot = 0;
   // per-call device scratch
   DevBuf raw32, raw64, used64, list, counters, stream_buf, read_off_dev, out_dev;
   DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist, hap_flags;
@@ -302,10 +307,14 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
 
   // ---- stage + upload plan ----
   int rc;
-  HIP_TRY(hipEventSynchronize(c->stage_free));
-  if ((rc = c->stage.reserve(L.total))) return rc;
-  if ((rc = c->plan_dev.reserve(L.total))) return rc;
-  unsigned char* hs = c->stage.as<unsigned char>();
+  const int slot = c->plan_slot ^= 1;
+  PinBuf& stage = c->stage_slot[slot];
+  DevBuf& plan_dev = c->plan_dev_slot[slot];
+  HIP_TRY(hipEventSynchronize(c->stage_free_slot[slot]));
+  if (L.total > stage.cap || L.total > plan_dev.cap) HIP_TRY(hipEventSynchronize(c->plan_unused_slot[slot]));  // about to reallocate
+  if ((rc = stage.reserve(L.total))) return rc;
+  if ((rc = plan_dev.reserve(L.total))) return rc;
+  unsigned char* hs = stage.as<unsigned char>();
   memcpy(hs + L.lanes, plan.lanes.data(), plan.lanes.size() * sizeof(PlanLane));
   memcpy(hs + L.groups, plan.groups.data(), plan.groups.size() * sizeof(PlanGroup));
   memcpy(hs + L.hap_len, plan.hap_len.data(), (size_t)n_haps * 4);
@@ -332,9 +341,11 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     int32_t lc[4] = {(int32_t)long_jobs.size(), n_long_main, n_long64, 0};
     memcpy(hs + L.long_count, lc, sizeof lc);
   }
-  unsigned char* dp = c->plan_dev.as<unsigned char>();
-  HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipEventRecord(c->stage_free, s));
+  unsigned char* dp = plan_dev.as<unsigned char>();
+  HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->plan_unused_slot[slot], 0));  // readers of the old contents are done
+  HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, c->upload_stream));
+  HIP_TRY(hipEventRecord(c->stage_free_slot[slot], c->upload_stream));
+  HIP_TRY(hipStreamWaitEvent(s, c->stage_free_slot[slot], 0));                    // kernels below read the new plan
   if (getenv("GKLHIP_TIMING"))
     fprintf(stderr, "[gklhip] host plan + staging: %.3f ms (%d chunks, %zu stream entries, %zu plan bytes)\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count(),
@@ -531,6 +542,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   if (ev) HIP_TRY(hipEventRecord(c->ev[5], s));
   HIP_TRY(hipGetLastError());
 
+  HIP_TRY(hipEventRecord(c->plan_unused_slot[slot], s));
   c->last_pairs = n_pairs;
   c->last_stream = s;
   c->have_last = true;
@@ -610,12 +622,18 @@ int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
   int rc = GKLHIP_OK;
   auto bail = [&](int status) { gklhip_done(c); return status; };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
-  if (hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  for (int k = 0; k < 2; k++)
+    if (hipEventCreateWithFlags(&c->stage_free_slot[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->plan_unused_slot[k], hipEventDisableTiming) != hipSuccess)
+      return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
   if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
   if (hipEventCreateWithFlags(&c->policy_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->early_copy_done, hipEventDisableTiming) != hipSuccess)
     return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
-  if (hipEventRecord(c->stage_free, c->stream) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventRecord failed"));
+  for (int k = 0; k < 2; k++)
+    if (hipEventRecord(c->stage_free_slot[k], c->stream) != hipSuccess || hipEventRecord(c->plan_unused_slot[k], c->stream) != hipSuccess)
+      return bail(fail(GKLHIP_ERR_HIP, "hipEventRecord failed"));
   {
     const int sets = c->cfg.record_events == 2 ? gklhip_ctx::kEventRing : 1;
     for (int k = 0; k < sets; k++)
@@ -632,11 +650,12 @@ int gklhip_done(gklhip_ctx* c) {
   if (!c) return GKLHIP_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev, &c->raw32, &c->raw64, &c->used64, &c->list,
+  for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev_slot[0], &c->plan_dev_slot[1], &c->raw32, &c->raw64, &c->used64, &c->list,
                     &c->counters, &c->stream_buf, &c->read_off_dev, &c->out_dev, &c->batch_dev, &c->read_fail,
                     &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->res_dev, &c->hap_flags})
     b->release();
-  c->stage.release();
+  c->stage_slot[0].release();
+  c->stage_slot[1].release();
   c->res_pin.release();
   c->res_pin2.release();
   if (c->policy_done) (void)hipEventDestroy(c->policy_done);
@@ -644,7 +663,11 @@ int gklhip_done(gklhip_ctx* c) {
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   for (auto& set : c->ev_ring)
     for (auto& e : set) if (e) (void)hipEventDestroy(e);
-  if (c->stage_free) (void)hipEventDestroy(c->stage_free);
+  for (int k = 0; k < 2; k++) {
+    if (c->stage_free_slot[k]) (void)hipEventDestroy(c->stage_free_slot[k]);
+    if (c->plan_unused_slot[k]) (void)hipEventDestroy(c->plan_unused_slot[k]);
+  }
+  if (c->upload_stream) { (void)hipStreamSynchronize(c->upload_stream); (void)hipStreamDestroy(c->upload_stream); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return GKLHIP_OK;
