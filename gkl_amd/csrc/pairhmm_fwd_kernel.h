@@ -26,9 +26,10 @@
 //     transition probabilities, so a read boundary inside the array costs no
 //     instructions; lanes that start a read zero their incoming values with a
 //     per-lane AND mask (isolates pairs from each other, NaN/Inf included).
-//   * The match/mismatch prior is a 5 x rows table in LDS indexed by the
-//     haplotype base code of the lane's current column: one ds_read_b128 per
-//     four rows replaces a compare+select per cell.
+//   * The match/mismatch prior is a table in LDS (5 base codes x rows in fp32,
+//     4 in fp64 where an 'N' column is gathered from the rows' own planes) indexed
+//     by the haplotype base code of the lane's current column: one ds_read_b128
+//     per four rows replaces a compare+select per cell.
 //   * No MFMA: this is a recurrence, not a contraction.  The roofline is the fp32
 //     (fp64) vector FMA rate; HBM traffic is ~1 KB per pair.
 #pragma once
