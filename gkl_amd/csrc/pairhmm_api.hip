@@ -112,7 +112,7 @@ struct gklhip_ctx {
   DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist, hap_flags;
   // host-API device copies of the batch, packed results (device + pinned), finalisation workers
   DevBuf batch_dev, res_dev;
-  PinBuf res_pin, res_pin2;
+  PinBuf res_pin, res_pin2, batch_stage;
   WorkerPool workers;
   hipStream_t copy_stream = nullptr;  // early D2H of the fp32 results while the fp64 pass runs
   hipEvent_t policy_done = nullptr, early_copy_done = nullptr;
@@ -234,6 +234,7 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 #define GKL_RPL_F64 6
 #endif
 constexpr int kRplF64 = GKL_RPL_F64;
+constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size stage their inputs in one block
 constexpr int kTargetCols = 3072;  // columns of a full-size haplotype group (sweep 1024..8000: flat optimum 2048..4096)
 #ifndef GKL_RPL_F32
 #define GKL_RPL_F32 8
@@ -342,10 +343,17 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     memcpy(hs + L.long_count, lc, sizeof lc);
   }
   unsigned char* dp = plan_dev.as<unsigned char>();
-  HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->plan_unused_slot[slot], 0));  // readers of the old contents are done
-  HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, c->upload_stream));
-  HIP_TRY(hipEventRecord(c->stage_free_slot[slot], c->upload_stream));
-  HIP_TRY(hipStreamWaitEvent(s, c->stage_free_slot[slot], 0));                    // kernels below read the new plan
+  if (L.total >= (256u << 10)) {
+    HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->plan_unused_slot[slot], 0));  // readers of the old contents are done
+    HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, c->upload_stream));
+    HIP_TRY(hipEventRecord(c->stage_free_slot[slot], c->upload_stream));
+    HIP_TRY(hipStreamWaitEvent(s, c->stage_free_slot[slot], 0));                    // kernels below read the new plan
+  } else {
+    // a small plan (GATK-sized call): the cross-stream hand-off would cost more than the copy
+    HIP_TRY(hipStreamWaitEvent(s, c->plan_unused_slot[slot], 0));
+    HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(c->stage_free_slot[slot], s));
+  }
   if (getenv("GKLHIP_TIMING"))
     fprintf(stderr, "[gklhip] host plan + staging: %.3f ms (%d chunks, %zu stream entries, %zu plan bytes)\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count(),
@@ -658,6 +666,7 @@ int gklhip_done(gklhip_ctx* c) {
   c->stage_slot[1].release();
   c->res_pin.release();
   c->res_pin2.release();
+  c->batch_stage.release();
   if (c->policy_done) (void)hipEventDestroy(c->policy_done);
   if (c->early_copy_done) (void)hipEventDestroy(c->early_copy_done);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
@@ -703,8 +712,20 @@ int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
   if ((rc = c->batch_dev.reserve(5 * stride + align_up(hl)))) return rc;
   unsigned char* d = c->batch_dev.as<unsigned char>();
   const uint8_t* srcs[5] = {hb->read_bases, hb->read_quals, hb->ins_gop, hb->del_gop, hb->gcp};
-  for (int i = 0; i < 5; i++) HIP_TRY(hipMemcpyAsync(d + i * stride, srcs[i], rl, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d + 5 * stride, hb->hap_bases, hl, hipMemcpyHostToDevice, s));
+  const size_t all_bytes = 5 * stride + align_up(hl);
+  if (all_bytes <= kSmallBatchBytes) {
+    // a GATK-sized call: gather the six arrays in one pinned block and pay ONE copy launch instead of six
+    // (each costs the host ~6 us; the block is tiny).  The previous call has completed (this entry point
+    // synchronises before it returns), so the block is free.
+    if ((rc = c->batch_stage.reserve(all_bytes))) return rc;
+    unsigned char* hs = c->batch_stage.as<unsigned char>();
+    for (int i = 0; i < 5; i++) memcpy(hs + i * stride, srcs[i], rl);
+    memcpy(hs + 5 * stride, hb->hap_bases, hl);
+    HIP_TRY(hipMemcpyAsync(d, hs, all_bytes, hipMemcpyHostToDevice, s));
+  } else {
+    for (int i = 0; i < 5; i++) HIP_TRY(hipMemcpyAsync(d + i * stride, srcs[i], rl, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + 5 * stride, hb->hap_bases, hl, hipMemcpyHostToDevice, s));
+  }
   gklhip_batch db = *hb;
   db.read_bases = d; db.read_quals = d + stride; db.ins_gop = d + 2 * stride;
   db.del_gop = d + 3 * stride; db.gcp = d + 4 * stride; db.hap_bases = d + 5 * stride;
