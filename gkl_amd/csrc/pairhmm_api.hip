@@ -107,6 +107,11 @@ struct gklhip_ctx {
   hipEvent_t plan_unused_slot[2] = {nullptr, nullptr};  // the last call that used the slot's device copy has finished
   hipStream_t upload_stream = nullptr;
   int plan_slot = 0;
+  // small host-buffer calls: after the policy kernel the packed results and the fallback count come back at once;
+  // a call without underflowed pairs (the usual GATK region) then skips the whole fp64 stage
+  bool peek_after_policy = false;   // in: set by gklhip_compute
+  bool fallback_skipped = false;    // out
+  PinBuf peek_count;
   // per-call device scratch
   DevBuf raw32, raw64, used64, list, counters, stream_buf, read_off_dev, out_dev;
   DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist, hap_flags;
@@ -234,6 +239,7 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 #define GKL_RPL_F64 6
 #endif
 constexpr int kRplF64 = GKL_RPL_F64;
+constexpr int64_t kPeekPairs = 65536;          // host-buffer calls up to this many pairs look at the fallback count before the fp64 stage
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size stage their inputs in one block
 constexpr int kTargetCols = 3072;  // columns of a full-size haplotype group (sweep 1024..8000: flat optimum 2048..4096)
 #ifndef GKL_RPL_F32
@@ -269,6 +275,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   memset(&st, 0, sizeof st);
   st.n_pairs = n_pairs;
   c->have_last = false;
+  c->fallback_skipped = false;
   if (n_pairs == 0) return GKLHIP_OK;
   const bool use_double = c->cfg.use_double != 0;
   const int fma = c->cfg.fma_mode != 0;
@@ -489,6 +496,17 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
       hipLaunchKernelGGL(finalize32_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, c->copy_stream, fa);
       HIP_TRY(hipEventRecord(c->early_copy_done, c->copy_stream));
     }
+    if (c->peek_after_policy) {
+      if ((rc = c->peek_count.reserve(64))) return rc;
+      HIP_TRY(hipMemcpyAsync(c->res_pin.p, out_dev, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(c->peek_count.p, c->counters.p, 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (*c->peek_count.as<int32_t>() == 0) {
+        c->fallback_skipped = true;
+        if (ev) { HIP_TRY(hipEventRecord(c->ev[3], s)); HIP_TRY(hipEventRecord(c->ev[4], s)); }
+      }
+    }
+    if (!c->fallback_skipped) {
     // ---- fp64 recomputation of the underflowed pairs ----
     FwdArgs<double> d{};
     fill_common(d);
@@ -545,6 +563,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
+    }  // !fallback_skipped
     if (side_finalize) HIP_TRY(hipStreamWaitEvent(s, c->early_copy_done, 0));  // join the side stream
   }
   if (ev) HIP_TRY(hipEventRecord(c->ev[5], s));
@@ -667,6 +686,7 @@ int gklhip_done(gklhip_ctx* c) {
   c->res_pin.release();
   c->res_pin2.release();
   c->batch_stage.release();
+  c->peek_count.release();
   if (c->policy_done) (void)hipEventDestroy(c->policy_done);
   if (c->early_copy_done) (void)hipEventDestroy(c->early_copy_done);
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
@@ -753,6 +773,23 @@ int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
     HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+    return GKLHIP_OK;
+  }
+  if (n_pairs <= kPeekPairs) {
+    // GATK-sized call: one D2H after the policy kernel; no underflowed pair (the usual case) = done
+    c->peek_after_policy = true;
+    rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s);
+    c->peek_after_policy = false;
+    if (rc) return rc;
+    if (c->fallback_skipped) {
+      c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+      return GKLHIP_OK;
+    }
+    fin.early(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);  // overlaps the fp64 pass
+    if ((rc = c->res_pin2.reserve(bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->res_pin2.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->stats.n_fallback = fin.late(&c->workers, c->res_pin2.as<uint64_t>(), out_host, threads);
     return GKLHIP_OK;
   }
   if ((rc = c->res_pin2.reserve(bytes))) return rc;
