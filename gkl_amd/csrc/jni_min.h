@@ -13,7 +13,7 @@
 // DeleteLocalRef 23, GetFieldID 94, GetObjectField 95, GetArrayLength 171,
 // GetObjectArrayElement 173, GetByteArrayRegion 200, SetDoubleArrayRegion 214,
 // ExceptionCheck 228; the PDHMM shim adds NewDoubleArray 182 and GetLongArrayRegion 204, the
-// Smith-Waterman shim SetByteArrayRegion 208.
+// Smith-Waterman shim SetByteArrayRegion 208 and SetIntArrayRegion 211.
 #pragma once
 #include <stdint.h>
 
@@ -39,6 +39,7 @@ typedef jarray jobjectArray;
 typedef jarray jbyteArray;
 typedef jarray jdoubleArray;
 typedef jarray jlongArray;
+typedef jarray jintArray;
 struct _jfieldID;
 typedef struct _jfieldID* jfieldID;
 
@@ -63,6 +64,7 @@ enum {
   kJniSlotGetByteArrayRegion = 200,
   kJniSlotGetLongArrayRegion = 204,
   kJniSlotSetByteArrayRegion = 208,
+  kJniSlotSetIntArrayRegion = 211,
   kJniSlotSetDoubleArrayRegion = 214,
   kJniSlotExceptionCheck = 228,
   kJniSlotCount = 235  // JNI 9+: GetModule is 233, IsVirtualThread (21) is 234
@@ -116,6 +118,9 @@ inline void GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize start, jsize len, 
 }
 inline void SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, const jbyte* buf) {
   fn<void (*)(JNIEnv*, jbyteArray, jsize, jsize, const jbyte*)>(e, kJniSlotSetByteArrayRegion)(e, a, start, len, buf);
+}
+inline void SetIntArrayRegion(JNIEnv* e, jintArray a, jsize start, jsize len, const jint* buf) {
+  fn<void (*)(JNIEnv*, jintArray, jsize, jsize, const jint*)>(e, kJniSlotSetIntArrayRegion)(e, a, start, len, buf);
 }
 inline void SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
   fn<void (*)(JNIEnv*, jdoubleArray, jsize, jsize, const jdouble*)>(e, kJniSlotSetDoubleArrayRegion)(e, a, start, len, buf);

@@ -25,6 +25,8 @@ inline jboolean ExceptionCheck(JNIEnv* e) { return e->ExceptionCheck(); }
 inline jsize GetArrayLength(JNIEnv* e, jarray a) { return e->GetArrayLength(a); }
 inline void GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, jbyte* b) { e->GetByteArrayRegion(a, s, l, b); }
 inline void SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, const jbyte* b) { e->SetByteArrayRegion(a, s, l, b); }
+inline void GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize s, jsize l, jlong* b) { e->GetLongArrayRegion(a, s, l, b); }
+inline void SetIntArrayRegion(JNIEnv* e, jintArray a, jsize s, jsize l, const jint* b) { e->SetIntArrayRegion(a, s, l, b); }
 }  // namespace gkljni
 #endif
 
@@ -89,6 +91,52 @@ JNIEXPORT jint JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_align
     if (st != GKLHIP_OK) { throw_status(env, st); return -1; }
     if (cigar_len > 0) gkljni::SetByteArrayRegion(env, cigar, 0, cigar_len, g.cigar.data());
     return offset;
+  } catch (const std::bad_alloc&) {
+    throw_java(env, kOOM, "Memory allocation issue");
+    return -1;
+  }
+}
+
+JNIEXPORT jint JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_alignBatchNative(
+    JNIEnv* env, jclass, jbyteArray refs, jlongArray refOffsets, jbyteArray alts, jlongArray altOffsets,
+    jbyteArray cigars, jint cigarStride, jintArray offsets, jint match, jint mismatch, jint open, jint extend,
+    jbyte strategy) {
+  if (!refs || !refOffsets || !alts || !altOffsets || !cigars || !offsets) { throw_java(env, kIAE, "Arrays aren't valid."); return -1; }
+  std::lock_guard<std::mutex> lock(g.mu);
+  if (!g.ctx) { throw_java(env, kRTE, "GKL-HIP Smith-Waterman: alignBatchNative before initNative"); return -1; }
+  try {
+    const jsize n = gkljni::GetArrayLength(env, refOffsets) - 1;
+    if (n < 0 || gkljni::GetArrayLength(env, altOffsets) != n + 1 || gkljni::GetArrayLength(env, offsets) < n ||
+        cigarStride <= 0 || (int64_t)gkljni::GetArrayLength(env, cigars) < (int64_t)n * cigarStride) {
+      throw_java(env, kIAE, "Arrays aren't valid.");
+      return -1;
+    }
+    if (n == 0) return 0;
+    std::vector<int64_t> ro((size_t)n + 1), ao((size_t)n + 1);
+    gkljni::GetLongArrayRegion(env, refOffsets, 0, n + 1, reinterpret_cast<jlong*>(ro.data()));
+    gkljni::GetLongArrayRegion(env, altOffsets, 0, n + 1, reinterpret_cast<jlong*>(ao.data()));
+    if (gkljni::ExceptionCheck(env)) return -1;
+    const jsize ref_bytes = gkljni::GetArrayLength(env, refs), alt_bytes = gkljni::GetArrayLength(env, alts);
+    if (ro[0] != 0 || ao[0] != 0 || ro[(size_t)n] > ref_bytes || ao[(size_t)n] > alt_bytes) {
+      throw_java(env, kIAE, "Arrays aren't valid.");
+      return -1;
+    }
+    g.ref.resize((size_t)ro[(size_t)n]);
+    g.alt.resize((size_t)ao[(size_t)n]);
+    g.cigar.assign((size_t)n * (size_t)cigarStride, 0);
+    if (!g.ref.empty()) gkljni::GetByteArrayRegion(env, refs, 0, (jsize)g.ref.size(), g.ref.data());
+    if (!g.alt.empty()) gkljni::GetByteArrayRegion(env, alts, 0, (jsize)g.alt.size(), g.alt.data());
+    if (gkljni::ExceptionCheck(env)) return -1;
+    gklhip_sw_params prm{match, mismatch, open, extend};
+    std::vector<uint32_t> counts((size_t)n);
+    std::vector<int32_t> offs((size_t)n);
+    const int st = gklhip_sw_align_batch(g.ctx, &prm, (int32_t)strategy, n, reinterpret_cast<const uint8_t*>(g.ref.data()),
+                                         ro.data(), reinterpret_cast<const uint8_t*>(g.alt.data()), ao.data(),
+                                         reinterpret_cast<char*>(g.cigar.data()), cigarStride, counts.data(), offs.data());
+    if (st != GKLHIP_OK) { throw_status(env, st); return -1; }
+    gkljni::SetByteArrayRegion(env, cigars, 0, (jsize)g.cigar.size(), g.cigar.data());
+    gkljni::SetIntArrayRegion(env, offsets, 0, n, reinterpret_cast<const jint*>(offs.data()));
+    return n;
   } catch (const std::bad_alloc&) {
     throw_java(env, kOOM, "Memory allocation issue");
     return -1;

@@ -30,6 +30,18 @@ JNIEXPORT jint JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_align
     JNIEnv* env, jclass cls, jbyteArray ref, jbyteArray alt, jbyteArray cigar, jint match, jint mismatch, jint open,
     jint extend, jbyte strategy);
 
+/* NOT in the reference: the batch entry point a caller has to adopt for the GPU to pay off.
+ *   private native static int alignBatchNative(byte[] refs, long[] refOffsets, byte[] alts, long[] altOffsets,
+ *                                              byte[] cigars, int cigarStride, int[] offsets,
+ *                                              int match, int mismatch, int open, int extend, byte strategy)
+ * n = refOffsets.length - 1 pairs; pair k aligns refs[refOffsets[k] .. refOffsets[k+1]) against
+ * alts[altOffsets[k] .. altOffsets[k+1]); its CIGAR text goes to cigars[k * cigarStride ..] (zero padded, like
+ * alignNative's array), its alignment offset to offsets[k].  Returns n, or -1 after throwing. */
+JNIEXPORT jint JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_alignBatchNative(
+    JNIEnv* env, jclass cls, jbyteArray refs, jlongArray refOffsets, jbyteArray alts, jlongArray altOffsets,
+    jbyteArray cigars, jint cigarStride, jintArray offsets, jint match, jint mismatch, jint open, jint extend,
+    jbyte strategy);
+
 /* private native static void doneNative()   (IntelSmithWaterman.cc:130-132) */
 JNIEXPORT void JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_doneNative(JNIEnv* env, jclass cls);
 

@@ -132,3 +132,32 @@ def run_sw(ref, alt, params, strategy, cigar_len=None, flags=0, iters=1):
                             int(params[1]), int(params[2]), int(params[3]), int(strategy), int(flags), int(iters), out,
                             C.byref(off), ec, em, C.byref(wall))
     return rc, out.raw[:cigar_len].rstrip(b"\0"), off.value, ec.value.decode(), em.value.decode(), wall.value
+
+
+def run_sw_batch(refs, alts, params, strategy, stride=None):
+    """initNative -> alignBatchNative -> doneNative.  Returns (rc, returned, [cigar bytes], offsets, class, message)."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    build()
+    lib = C.CDLL(SO)
+    n = len(refs)
+    refs, alts = [bytes(r) for r in refs], [bytes(a) for a in alts]
+    if stride is None:
+        stride = 2 * max(max(len(r), len(a)) for r, a in zip(refs, alts))
+    ro = np.zeros(n + 1, np.int64)
+    ao = np.zeros(n + 1, np.int64)
+    np.cumsum([len(r) for r in refs], out=ro[1:])
+    np.cumsum([len(a) for a in alts], out=ao[1:])
+    rb, ab = b"".join(refs), b"".join(alts)
+    cig = np.zeros(n * stride, np.uint8)
+    off = np.zeros(n, np.int32)
+    ret = C.c_int(0)
+    ec, em = C.create_string_buffer(256), C.create_string_buffer(512)
+    lib.mockjni_run_sw_batch.restype = C.c_int
+    rc = lib.mockjni_run_sw_batch(SW_JNI_LIB.encode(), n, rb, ro.ctypes.data_as(C.c_void_p), ab, ao.ctypes.data_as(C.c_void_p),
+                                  int(stride), int(params[0]), int(params[1]), int(params[2]), int(params[3]), int(strategy),
+                                  cig.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.byref(ret), ec, em)
+    rows = cig.reshape(n, stride)
+    return rc, ret.value, [rows[k].tobytes().rstrip(b"\0") for k in range(n)], off, ec.value.decode(), em.value.decode()

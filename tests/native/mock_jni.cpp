@@ -27,12 +27,13 @@
 namespace {
 
 struct Obj {
-  enum Kind { CLASS, BYTES, DOUBLES, LONGS, OBJARRAY, HOLDER } kind;
+  enum Kind { CLASS, BYTES, DOUBLES, LONGS, INTS, OBJARRAY, HOLDER } kind;
   std::string name;                      // CLASS
   std::set<std::string> class_fields;    // CLASS
   std::vector<int8_t> bytes;             // BYTES
   std::vector<double> doubles;           // DOUBLES
   std::vector<int64_t> longs;            // LONGS
+  std::vector<int32_t> ints;             // INTS
   std::vector<Obj*> elems;               // OBJARRAY
   std::map<std::string, Obj*> fields;    // HOLDER (value may be nullptr)
 };
@@ -88,7 +89,7 @@ jobject m_GetObjectField(JNIEnv* e, jobject o, jfieldID f) {
 jsize m_GetArrayLength(JNIEnv*, jarray a) {
   Obj* o = O(a);
   return (jsize)(o->kind == Obj::BYTES ? o->bytes.size() : o->kind == Obj::DOUBLES ? o->doubles.size()
-                 : o->kind == Obj::LONGS ? o->longs.size() : o->elems.size());
+                 : o->kind == Obj::LONGS ? o->longs.size() : o->kind == Obj::INTS ? o->ints.size() : o->elems.size());
 }
 jobject m_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) {
   Obj* o = O(a);
@@ -111,6 +112,14 @@ void m_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, const
     return;
   }
   memcpy(o->bytes.data() + start, buf, (size_t)len);
+}
+void m_SetIntArrayRegion(JNIEnv* e, jintArray a, jsize start, jsize len, const jint* buf) {
+  Obj* o = O(a);
+  if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->ints.size()) {
+    M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "int region");
+    return;
+  }
+  memcpy(o->ints.data() + start, buf, sizeof(int32_t) * (size_t)len);
 }
 void m_SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
   Obj* o = O(a);
@@ -157,6 +166,7 @@ void install_table(Mock& m) {
   m.table.slot[kJniSlotGetObjectArrayElement] = (void*)&m_GetObjectArrayElement;
   m.table.slot[kJniSlotGetByteArrayRegion] = (void*)&m_GetByteArrayRegion;
   m.table.slot[kJniSlotSetByteArrayRegion] = (void*)&m_SetByteArrayRegion;
+  m.table.slot[kJniSlotSetIntArrayRegion] = (void*)&m_SetIntArrayRegion;
   m.table.slot[kJniSlotSetDoubleArrayRegion] = (void*)&m_SetDoubleArrayRegion;
   m.table.slot[kJniSlotNewDoubleArray] = (void*)&m_NewDoubleArray;
   m.table.slot[kJniSlotGetLongArrayRegion] = (void*)&m_GetLongArrayRegion;
@@ -455,6 +465,49 @@ int mockjni_run_sw(const char* lib_path, const uint8_t* ref, int ref_len, const 
   if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   f_done(env, nullptr);
   memcpy(cigar_out, jcig->bytes.data(), (size_t)cigar_len);
+  if (m.pending) {
+    snprintf(exc_class, 256, "%s", m.exc_class.c_str());
+    snprintf(exc_msg, 512, "%s", m.exc_msg.c_str());
+  }
+  return rc_;
+}
+
+
+typedef jint (*sw_batch_fn)(JNIEnv*, jclass, jbyteArray, jlongArray, jbyteArray, jlongArray, jbyteArray, jint, jintArray, jint,
+                            jint, jint, jint, jbyte);
+// initNative -> alignBatchNative -> doneNative.  cigars_out[n * stride], offsets_out[n].  Return codes as mockjni_run_sw.
+int mockjni_run_sw_batch(const char* lib_path, int n, const uint8_t* refs, const int64_t* ref_off, const uint8_t* alts,
+                         const int64_t* alt_off, int stride, int match, int mismatch, int open, int extend, int strategy,
+                         uint8_t* cigars_out, int32_t* offsets_out, int* returned, char* exc_class, char* exc_msg) {
+  exc_class[0] = exc_msg[0] = 0;
+  void* h = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { snprintf(exc_msg, 512, "dlopen: %s", dlerror()); return -1; }
+  sw_init_fn f_init = (sw_init_fn)dlsym(h, "Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_initNative");
+  sw_batch_fn f_batch = (sw_batch_fn)dlsym(h, "Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_alignBatchNative");
+  sw_done_fn f_done = (sw_done_fn)dlsym(h, "Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_doneNative");
+  if (!f_init || !f_batch || !f_done) { snprintf(exc_msg, 512, "missing JNI symbol"); return -1; }
+  Mock m;
+  install_table(m);
+  JNIEnv* env = &m.env;
+  Obj* jrefs = bytes_obj(m, refs, ref_off[n]);
+  Obj* jalts = bytes_obj(m, alts, alt_off[n]);
+  Obj* jro = m.make(Obj::LONGS); jro->longs.assign(ref_off, ref_off + n + 1);
+  Obj* jao = m.make(Obj::LONGS); jao->longs.assign(alt_off, alt_off + n + 1);
+  Obj* jcig = m.make(Obj::BYTES); jcig->bytes.assign((size_t)n * stride, 0);
+  Obj* joff = m.make(Obj::INTS); joff->ints.assign((size_t)n, -777);
+  int rc_ = 0;
+  f_init(env, nullptr);
+  if (m.pending) rc_ = 1;
+  if (rc_ == 0) {
+    *returned = f_batch(env, nullptr, reinterpret_cast<jbyteArray>(jrefs), reinterpret_cast<jlongArray>(jro),
+                        reinterpret_cast<jbyteArray>(jalts), reinterpret_cast<jlongArray>(jao),
+                        reinterpret_cast<jbyteArray>(jcig), stride, reinterpret_cast<jintArray>(joff), match, mismatch,
+                        open, extend, (jbyte)strategy);
+    if (m.pending) rc_ = 2;
+  }
+  f_done(env, nullptr);
+  memcpy(cigars_out, jcig->bytes.data(), (size_t)n * stride);
+  memcpy(offsets_out, joff->ints.data(), sizeof(int32_t) * (size_t)n);
   if (m.pending) {
     snprintf(exc_class, 256, "%s", m.exc_class.c_str());
     snprintf(exc_msg, 512, "%s", m.exc_msg.c_str());

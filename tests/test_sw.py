@@ -203,6 +203,22 @@ def test_sw_jni_exports_and_errors_without_a_call():
     assert rc == 2 and cls == "java/lang/IllegalArgumentException" and msg == "Arrays aren't valid."
 
 
+@pytest.mark.gpu
+def test_sw_jni_batch_entry_point(sw_oracle):
+    # alignBatchNative (not in the reference: the entry point a batching caller binds, include/gkl_sw_jni.h)
+    from tests import mockjni
+    rng = np.random.RandomState(44)
+    pairs = random_pairs(rng, 150, lengths=(1, 9, 40, 130, 257, 300, 520))
+    refs, alts = [r for r, _ in pairs], [a for _, a in pairs]
+    for strategy in STRATEGIES:
+        rc, ret, cigs, offs, cls, msg = mockjni.run_sw_batch(refs, alts, PARAM_SETS[0], strategy)
+        assert rc == 0 and ret == len(pairs), (cls, msg)
+        stride = 2 * max(max(len(r), len(a)) for r, a in pairs)
+        for k, (r, a) in enumerate(pairs):
+            _, ecig, _, eoff = sw_oracle.align(r, a, PARAM_SETS[0], strategy, cigar_len=stride)
+            assert (cigs[k], int(offs[k])) == (ecig, eoff), (k, strategy)
+
+
 def test_sw_mirror_argument_validation():
     # SmithWatermanUnitTest.java:33-166: null -> NPE; too long / match too large / empty -> IAE, before any native call
     from gkl_amd.errors import IllegalArgumentException, NullPointerException
