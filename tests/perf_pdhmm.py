@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev tool: PDHMM forward kernel throughput on (a) a reads x haplotypes cross product -- the batches
+"""Measurement script (lives under tests/ because it times / checks against oracle/, which only tests may use): PDHMM forward kernel throughput on (a) a reads x haplotypes cross product -- the batches
 IntelPDHMM.computeLikelihoods builds -- and (b) pairs with all-distinct haplotypes (the reference's
 test-data shape), with the reference's AVX-512/AVX2 kernel timed on one host thread beside it."""
 import argparse

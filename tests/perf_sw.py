@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev tool: Smith-Waterman throughput (batch C ABI) and per-call latency (single-pair C ABI = what alignNative
+"""Measurement script (lives under tests/ because it times / checks against oracle/, which only tests may use): Smith-Waterman throughput (batch C ABI) and per-call latency (single-pair C ABI = what alignNative
 pays) on GATK-shaped inputs, with the reference's own AVX2 / AVX-512 objects timed on one host core beside it."""
 import argparse
 import os
@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     from gkl_amd import native
-    from oracle.sw import SOFTCLIP
+    SOFTCLIP = native.SW_SOFTCLIP
     params = (200, -150, -260, -11)
     rng = np.random.RandomState(3)
     shapes = {"haplotype-to-reference (ref 300-600, alt 250-600)": ((300, 600), (250, 600)),

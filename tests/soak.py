@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev tool: 20 s of GATK-sized calls through the host-buffer C ABI checked bit for bit against the oracle, then 300
+"""Measurement script (lives under tests/ because it times / checks against oracle/, which only tests may use): 20 s of GATK-sized calls through the host-buffer C ABI checked bit for bit against the oracle, then 300
 back-to-back bench-sized batches on the device-resident path (no synchronisation in between)."""
 import sys, time
 import os
