@@ -27,6 +27,7 @@
 
 #include "../../include/gkl_hip_pairhmm.h"
 #include "../../include/gkl_pairhmm_jni.h"
+#include "jni_onload.h"
 
 #ifdef GKL_USE_SYSTEM_JNI
 namespace gkljni {

@@ -14,6 +14,7 @@
 #include "../../include/gkl_hip_pairhmm.h"
 #include "../../include/gkl_hip_pdhmm.h"
 #include "../../include/gkl_pdhmm_jni.h"
+#include "jni_onload.h"
 
 #ifdef GKL_USE_SYSTEM_JNI
 namespace gkljni {

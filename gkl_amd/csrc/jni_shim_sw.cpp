@@ -15,6 +15,7 @@
 #include "../../include/gkl_hip_pairhmm.h"
 #include "../../include/gkl_hip_sw.h"
 #include "../../include/gkl_sw_jni.h"
+#include "jni_onload.h"
 
 #ifdef GKL_USE_SYSTEM_JNI
 namespace gkljni {

@@ -44,6 +44,14 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
 /* native void doneNative()  -- replaces IntelPairHmm.cc:189-192; releases the device context. */
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv* env, jobject obj);
 
+/* Device probe run by the JVM at System.load (not in the reference): JNI_VERSION_1_8 when a gfx950 device is usable,
+ * JNI_ERR otherwise -- load() then returns false and the caller falls back, as it does on a CPU without AVX.
+ * GKL_HIP_LOAD_WITHOUT_DEVICE=1 disables the probe.  (gkl_amd/csrc/jni_onload.h) */
+#ifndef GKL_USE_SYSTEM_JNI
+struct JavaVM_;
+#endif
+JNIEXPORT jint JNICALL JNI_OnLoad(struct JavaVM_* vm, void* reserved);
+
 #ifdef __cplusplus
 }
 #endif

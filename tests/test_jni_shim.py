@@ -115,6 +115,22 @@ def test_jni_concurrent_callers_get_their_own_slot(oracle, n_threads, slots, mon
     assert out.tobytes() == oracle.batch(b, n_threads=8).tobytes()
 
 
+def test_jni_onload_probes_for_a_device(monkeypatch):
+    # JNI_OnLoad (not in the reference): JNI_ERR without a usable gfx950 device, so that System.load fails and
+    # NativeLibraryLoader.load() returns false (GATK then falls back); JNI_VERSION_1_8 with one, or when forced
+    import ctypes as C
+    import torch
+    have_gpu = torch.cuda.is_available()
+    for name in ("libgkl_pairhmm.so", "libgkl_pdhmm.so", "libgkl_smithwaterman.so"):
+        lib = C.CDLL(os.path.join(os.path.dirname(mockjni.JNI_LIB), name))
+        lib.JNI_OnLoad.restype = C.c_int
+        lib.JNI_OnLoad.argtypes = [C.c_void_p, C.c_void_p]
+        monkeypatch.delenv("GKL_HIP_LOAD_WITHOUT_DEVICE", raising=False)
+        assert lib.JNI_OnLoad(None, None) == (0x00010008 if have_gpu else -1), name
+        monkeypatch.setenv("GKL_HIP_LOAD_WITHOUT_DEVICE", "1")
+        assert lib.JNI_OnLoad(None, None) == 0x00010008
+
+
 def test_utils_library_gates_on_the_gpu():
     """libgkl_utils.so replacement: IntelPairHmm.load() asks isAvxSupported() first
     (IntelPairHmm.java:66-75); here that answers "is a gfx950 device usable"."""
