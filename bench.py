@@ -55,7 +55,18 @@ def cpu_baseline(batch, budget_s=6.0):
     t0 = time.time()
     run(sample, threads)
     dt = time.time() - t0
+    one = batch.read_slice(0, min(batch.n_reads, 96))      # also the single-thread rate
+    t1 = time.time()
+    run(one, 1)
+    one_thread = one.cells / max(time.time() - t1, 1e-4) / 1e9
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {"value": round(sample.cells / dt / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": kind,
+            "one_thread_gcups": round(one_thread, 3), "cpu_model": model,
             "isa": isa, "sample": f"first {n} reads x {batch.n_haps} haps of the same batch "
             f"({sample.cells:.3e} cells, {dt:.2f} s, fp32+fp64-fallback policy, OpenMP dynamic,1)",
             "likelihoods_per_s": round(sample.n_pairs / dt, 1)}
