@@ -17,7 +17,8 @@ Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the fp32
 kernel): 12 FLOP per cell x cells per launch / its HIP-event duration,
 against the 157.3 TFLOP/s fp32 vector peak (no MFMA applies to a recurrence).
 `cpu_baseline` times the reference's own AVX-512/AVX kernels (oracle/_ref, OpenMP dynamic,1
-like IntelPairHmm.cc:151-154) on a bounded sample of the same workload on the host cores.
+like IntelPairHmm.cc:151-154) on a bounded sample of the same workload on the host cores this
+process may use (cgroup quota respected; `cores` = threads actually used).
 """
 import argparse
 import json
@@ -45,7 +46,17 @@ def cpu_baseline(batch, budget_s=6.0):
         eng = Oracle()
         kind, run = "port", lambda b, t: eng.batch(b, n_threads=t)
         isa = "scalar"
-    threads = max(1, min(eng.max_threads(), os.cpu_count() or 1))
+    # threads = the CPUs this process may really use: the cgroup quota when there is one (the GPU boxes expose 256
+    # hardware threads but grant 16 CPUs; more threads than that only get throttled)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(eng.max_threads(), avail, quota or avail))
     probe = batch.read_slice(0, min(batch.n_reads, 2 * threads))
     t0 = time.time()
     run(probe, threads)
@@ -66,7 +77,8 @@ def cpu_baseline(batch, budget_s=6.0):
     except OSError:
         pass
     return {"value": round(sample.cells / dt / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": kind,
-            "one_thread_gcups": round(one_thread, 3), "cpu_model": model,
+            "one_thread_gcups": round(one_thread, 3), "cpu_model": model, "host_hw_threads": os.cpu_count(),
+            "cgroup_cpu_quota": quota,
             "isa": isa, "sample": f"first {n} reads x {batch.n_haps} haps of the same batch "
             f"({sample.cells:.3e} cells, {dt:.2f} s, fp32+fp64-fallback policy, OpenMP dynamic,1)",
             "likelihoods_per_s": round(sample.n_pairs / dt, 1)}
