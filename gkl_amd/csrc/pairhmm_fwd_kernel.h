@@ -316,7 +316,8 @@ struct WaveJob {
   }
 
   __device__ __forceinline__ void load_priors(uint32_t code, int lane, T* pr) const {
-    const unsigned char* p = lds + code * (uint32_t)kRowBytes + (uint32_t)lane * kVecBytes;
+    // 24-bit multiply: kRowBytes is 3072 in fp64 and a plain v_mul_lo_u32 issues at quarter rate
+    const unsigned char* p = lds + __umul24(code, (uint32_t)kRowBytes) + (uint32_t)lane * kVecBytes;
 #pragma unroll
     for (int pl = 0; pl < kPlanes; pl++) {
       const Vec v = *reinterpret_cast<const Vec*>(p + pl * (kLanes * kVecBytes));
@@ -369,8 +370,13 @@ struct WaveJob {
   // emit the result, return to the column-0 state of the next one).  Branch-free except for
   // the result store: M and X clear themselves on a prior-0 column (see mul_prior; fp64
   // selects explicitly), Y and the running sums are selected.
+  // `k_cur` (wave-uniform): the haplotype whose separator is travelling through the array during this
+  // step, with its output column `orig_cur` and the next haplotype's Y0 `y0_next` already in scalar
+  // registers (the caller loads them once per haplotype) -- so the lane on the separator stores its result
+  // and restarts without waiting for two dependent global loads.  Any other separator (haplotypes
+  // shorter than the array, the striped long-read path) takes the loads.
   __device__ __forceinline__ void step_any(const FwdArgs<T>& a, uint32_t entry, int lane,
-                                           int hap_begin, int hap_end) {
+                                           int hap_begin, int hap_end, int k_cur, int orig_cur, T y0_next) {
     constexpr bool kSelfClearing = sizeof(T) == 4;
     ent = dpp_shr1_keep(entry, ent);
     const bool sep = (int32_t)ent < 0;
@@ -389,11 +395,16 @@ struct WaveJob {
     advance(pr, nM, nX, nY);
     const T tM = sM + nM[RPL - 1], tX = sX + nX[RPL - 1];  // on a separator both addends are 0
     T y0n = T(0);
-    if (sep) {
+    if (GKL_ABL != 6 && sep) {
       const int k = (int)(ent & 0x7fffffffu);
-      const bool mine = (k >= hap_begin) && (k < hap_end);
-      if (mine && out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
-      if (mine && k + 1 < hap_end) y0n = a.y0[k + 1];
+      if (k == k_cur) {  // k_cur is always inside [hap_begin, hap_end)
+        if (out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + orig_cur] = sM + sX;
+        y0n = y0_next;
+      } else {
+        const bool mine = (k >= hap_begin) && (k < hap_end);
+        if (mine && out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
+        if (mine && k + 1 < hap_end) y0n = a.y0[k + 1];
+      }
     }
 #pragma unroll
     for (int s = 0; s < RPL; s++) {
@@ -415,11 +426,13 @@ struct WaveJob {
     reset_state(a.y0[hap_begin]);
     int t = 0;
     int fast_from = kLanes - 1;  // the fill: lanes still idle until t = 63
+    int k_cur = -1, orig_cur = 0;  // the separator in flight (none during the fill)
+    T y0_next = T(0);
     for (int k = hap_begin; k < hap_end; k++) {
       const int sep_at = a.hap_pos[k] - sb + a.hap_len[k];  // stream-relative separator position
       if (kCodes == 4 && a.hap_has_n[k]) fast_from = sep_at;  // an 'N' somewhere in it: general steps throughout
       const int slow_end = fast_from < sep_at ? fast_from : sep_at;
-      run_any(a, sp, t, slow_end, lane, hap_begin, hap_end);
+      run_any(a, sp, t, slow_end, lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
       for (; t + U <= sep_at; t += U) {
         uint32_t e[U];
 #pragma unroll
@@ -429,25 +442,28 @@ struct WaveJob {
       }
       if (t >= fast_from)
         for (; t < sep_at; t++) step_fast(sp[t], lane);  // < U leftover columns, still all in-haplotype
-      run_any(a, sp, t, sep_at, lane, hap_begin, hap_end);
+      run_any(a, sp, t, sep_at, lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
       fast_from = sep_at + kLanes;
+      k_cur = k;  // from stream position sep_at on, lanes meet this haplotype's separator
+      orig_cur = a.hap_orig[k];
+      y0_next = k + 1 < hap_end ? a.y0[k + 1] : T(0);
     }
-    run_any(a, sp, t, fast_from, lane, hap_begin, hap_end);  // drain
+    run_any(a, sp, t, fast_from, lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);  // drain
   }
 
   // General steps for stream positions [t, end): four at a time so the stream entries come from
   // one scalar load issued ahead of use and the state needs no loop-carried register copies.
   __device__ __forceinline__ void run_any(const FwdArgs<T>& a, const uint32_t* __restrict__ sp, int& t, int end,
-                                          int lane, int hap_begin, int hap_end) {
+                                          int lane, int hap_begin, int hap_end, int k_cur, int orig_cur, T y0_next) {
     constexpr int V = 4;
     for (; t + V <= end; t += V) {
       uint32_t e[V];
 #pragma unroll
       for (int u = 0; u < V; u++) e[u] = sp[t + u];
 #pragma unroll
-      for (int u = 0; u < V; u++) step_any(a, e[u], lane, hap_begin, hap_end);
+      for (int u = 0; u < V; u++) { if (GKL_ABL == 5) step_fast(e[u] & 3u, lane); else step_any(a, e[u], lane, hap_begin, hap_end, k_cur, orig_cur, y0_next); }
     }
-    for (; t < end; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
+    for (; t < end; t++) { if (GKL_ABL == 5) step_fast(sp[t] & 3u, lane); else step_any(a, sp[t], lane, hap_begin, hap_end, k_cur, orig_cur, y0_next); }
   }
 
   // One 64-lane STRIPE of a read that is longer than a chunk (the reference's stripe loop with
@@ -475,7 +491,7 @@ struct WaveJob {
         const T vM = read_lane(ciM, t & 63), vX = read_lane(ciX, t & 63), vY = read_lane(ciY, t & 63);
         if (lane == 0) { rM = vM; rX = vX; rY = vY; }
       }
-      step_any(a, sp[t], lane, hap_begin, hap_end);
+      step_any(a, sp[t], lane, hap_begin, hap_end, -1, 0, T(0));
       if (cout) {
         const int p = t - (kLanes - 1);  // stream position lane 63 has just finished
         if (p >= 0) {
@@ -719,7 +735,7 @@ struct WaveJob2 {
 // ---- kernels -------------------------------------------------------------------
 // Main pass: block (one wavefront) = (chunk of packed reads) x (haplotype group).
 template <typename T, int RPL, bool FMA>
-__global__ __launch_bounds__(64) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 3 : 4))) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
   using Job = WaveJob<T, RPL, FMA>;
   __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
@@ -759,7 +775,7 @@ __global__ __launch_bounds__(64) void pairhmm_fwd_stream2_kernel(FwdArgs<float> 
 // jobs built on the device from the fallback flags; chunks come from a second read packing
 // that groups reads with similar fallback patterns.
 template <typename T, int RPL, bool FMA>
-__global__ __launch_bounds__(64) void pairhmm_fwd_jobs_kernel(FwdArgs<T> a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 3 : 4))) void pairhmm_fwd_jobs_kernel(FwdArgs<T> a) {
   using Job = WaveJob<T, RPL, FMA>;
   __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
