@@ -217,15 +217,19 @@ def main():
                        "fallback_fraction": round(st["n_fallback"] / batch.n_pairs, 4),
                        "parallelism": f"read-range shard x{world}, gather to rank 0 overlapped with the next step" if world > 1 else "single GPU",
                        "finalize": "device log10 in double"},
-            "roofline": {"bound": "valu-fp64" if a.double else "valu-fp32", "kernel": "pairhmm_fwd_stream_kernel",
+            # "mfma" = the compute roofline of the bench contract, priced at the dense MFMA peak of the dtype (which
+            # for fp32/fp64 equals the vector peak); the kernel itself is vector-ALU code, see `note`
+            "roofline": {"bound": "mfma", "limiter": "valu-fp64 issue" if a.double else "valu-fp32 issue",
+                         "kernel": "pairhmm_fwd_stream_kernel",
                          "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_VECTOR_TFLOPS / 2 if a.double else PEAK_FP32_VECTOR_TFLOPS,
                          "unit": "TFLOP/s",
                          "frac": round(achieved / (PEAK_FP32_VECTOR_TFLOPS / 2 if a.double else PEAK_FP32_VECTOR_TFLOPS), 4),
                          "traffic": traffic, "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(k_ms, 3),
                          "kernel_gcups": round(batch.cells / k_ms / 1e6, 1),
-                         "note": "vector-FMA bound recurrence (no MFMA / not HBM bound); peak = fp32 vector = fp32 MFMA dense "
-                                 "peak, reachable only by packed FMA-only code. The recurrence needs 4 mul + 4 fma per cell "
+                         "note": "compute-bound recurrence priced at the dense fp32 (fp64 with --double) MFMA peak = the vector "
+                                 "peak; it has no contraction, so it runs on the vector ALUs and issues no MFMA; that peak is "
+                                 "reachable only by packed FMA-only code. The recurrence needs 4 mul + 4 fma per cell "
                                  "(1.5 flop per instruction) and a SIMD retires one plain VALU op per ~2.7 cycles (measured), "
                                  "so its issue-bound ceiling is ~7 TCUPS = 0.53 of peak (DESIGN.md section 3)"},
             "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(float(np.mean(ms_fb)), 3),

@@ -86,8 +86,6 @@ struct PinBuf {
 };
 }  // namespace
 
-
-
 // ------------------------------------------------------------------ context
 struct gklhip_ctx {
   gklhip_config cfg;
@@ -121,7 +119,6 @@ struct gklhip_ctx {
   WorkerPool workers;
   hipStream_t copy_stream = nullptr;  // early D2H of the fp32 results while the fp64 pass runs
   hipEvent_t policy_done = nullptr, early_copy_done = nullptr;
-  // events
   // events: kEventRing sets of 6 (call start, main begin/end, fallback begin/end, call end); record_events == 1 uses
   // set 0 and synchronises every call, record_events == 2 rotates through the ring and never synchronises
   // (gklhip_get_step_times reads a set later)
@@ -233,7 +230,7 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 }
 
 // Rows per lane.  fp32 main pass: 8 (one chunk per wavefront; 4 = the dual-chunk packed-math
-// kernel, opt-in).  fp64 passes: 4.  A read of length R needs R+1 rows; reads that exceed
+// kernel, opt-in).  fp64 passes: 6.  A read of length R needs R+1 rows; reads that exceed
 // 64*RPL rows go to the striped long-read kernel of the same RPL.
 #ifndef GKL_RPL_F64
 #define GKL_RPL_F64 6
