@@ -238,7 +238,7 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 constexpr int kRplF64 = GKL_RPL_F64;
 constexpr int64_t kPeekPairs = 65536;          // host-buffer calls up to this many pairs look at the fallback count before the fp64 stage
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size stage their inputs in one block
-constexpr int kTargetCols = 3072;  // columns of a full-size haplotype group (sweep 1024..8000: flat optimum 2048..4096)
+constexpr int kTargetCols = 2048;  // columns of a full-size haplotype group (sweep 1024..4096: flat within 2 %, optimum 1800..2600)
 #ifndef GKL_RPL_F32
 #define GKL_RPL_F32 8
 #endif

@@ -222,18 +222,39 @@ struct WaveJob {
   int32_t out_read;   // read whose LAST row is this lane's bottom row, else -1
   int32_t padb_slot;  // slot of the Y0-holding pad row in this lane, else -1
   uint32_t own_codes; // kCodes == 4: 2 bits per row, the plane holding the row's match prior (its own base)
+  uint32_t direct;    // ~0: this lane takes the step's stream entry itself (first lane of a read, idle lane), 0: from the lane above
+  int32_t skew_max;   // wave-uniform: the largest skew of a lane = how many steps an entry travels through the array
   unsigned char* lds; // this wave's prior table
 
   // Load one lane's rows: transition probabilities in registers, priors in LDS.
   // Read layout inside a chunk: n_blocks = ceil((R+1)/RPL) lanes, p = n_blocks*RPL-R
   // pad rows first (p-1 all-zero rows, then the Y0 row), then the R real rows, so the
   // read's last row is always the bottom row of its last lane.
-  __device__ __forceinline__ void setup(const FwdArgs<T>& a, int lane, LaneSlot slot) {
+  //
+  // Skew: the lanes of ONE read must see column j one step after the lane above (systolic hand-off), but
+  // different reads of a chunk are independent, so every read starts its own skew at 0: its first lane takes
+  // the step's stream entry directly, lane b of the read sees it b steps later.  An entry (a separator in
+  // particular) therefore leaves the array after `skew_max` = (largest lane count of a read in the chunk) - 1
+  // steps instead of 63: shorter fill/drain per job and a shorter general-step window behind each separator.
+  // `full_skew` (the striped long-read path, whose carry logic counts on lane L = skew L) keeps 0..63.
+  __device__ __forceinline__ void setup(const FwdArgs<T>& a, int lane, LaneSlot slot, bool full_skew = false) {
     int R = 0, first = 0;
     int64_t roff = 0;
     out_read = -1;
     padb_slot = -1;
     lmask = 0u;
+    {
+      const bool takes = full_skew ? lane == 0 : (lane == 0 || slot.read < 0 || slot.block == 0);
+      direct = takes ? ~0u : 0u;
+      asm("" : "+v"(direct));  // opaque bit mask: as a bool the compiler makes shift_entry a v_mov + v_cndmask on top of the DPP
+      int m = full_skew ? kLanes - 1 : (slot.read >= 0 ? slot.block : 0);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(m, off, kLanes);
+        m = o > m ? o : m;
+      }
+      skew_max = __builtin_amdgcn_readfirstlane(m);
+    }
     if (slot.read >= 0) {
       roff = a.b.read_off[slot.read];
       R = (int)(a.b.read_off[slot.read + 1] - roff);
@@ -349,10 +370,20 @@ struct WaveJob {
     for (int s = 1; s < RPL; s++) nX[s] = mul_add2<FMA>(nX[s - 1], pXX[s], nM[s - 1], pMX[s]);
   }
 
+  // This step's entry of the lane: the scalar `entry` for lanes that start a skew, else the lane above's
+  // previous one (v_and_b32_dpp + v_and_or_b32).
+  __device__ __forceinline__ void shift_entry(uint32_t entry) {
+    uint32_t above;  // (lane above's entry) & ~direct; written as asm because the compiler leaves this AND outside the
+                     // DPP move (three instructions); s_nop 1 = the wait states a DPP read needs after a VALU write
+    asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=v"(above) : "v"(ent), "v"(~direct));
+    ent = (entry & direct) | above;
+  }
+
   // Fast step: every lane is inside a haplotype (entry = base code 0..4).
   __device__ __forceinline__ void step_fast(uint32_t entry, int lane) {
     if (GKL_ABL == 4) ent = entry; else
-    ent = dpp_shr1_keep(entry, ent);
+    shift_entry(entry);
     T pr[RPL], nM[RPL], nX[RPL], nY[RPL];
     if (GKL_ABL == 2) { for (int s = 0; s < RPL; s++) pr[s] = pMM[s]; } else
     load_priors(ent, lane, pr);
@@ -378,7 +409,7 @@ struct WaveJob {
   __device__ __forceinline__ void step_any(const FwdArgs<T>& a, uint32_t entry, int lane,
                                            int hap_begin, int hap_end, int k_cur, int orig_cur, T y0_next) {
     constexpr bool kSelfClearing = sizeof(T) == 4;
-    ent = dpp_shr1_keep(entry, ent);
+    shift_entry(entry);
     const bool sep = (int32_t)ent < 0;
     const bool off = sep || ent == kEntIdle;  // no haplotype base in this column: prior 0
     const bool is_n = kCodes == 4 && ent == 4u;
@@ -425,7 +456,7 @@ struct WaveJob {
     const uint32_t* __restrict__ sp = a.stream + sb;
     reset_state(a.y0[hap_begin]);
     int t = 0;
-    int fast_from = kLanes - 1;  // the fill: lanes still idle until t = 63
+    int fast_from = skew_max;  // the fill: the most skewed lane is idle until t = skew_max
     int k_cur = -1, orig_cur = 0;  // the separator in flight (none during the fill)
     T y0_next = T(0);
     for (int k = hap_begin; k < hap_end; k++) {
@@ -443,7 +474,7 @@ struct WaveJob {
       if (t >= fast_from)
         for (; t < sep_at; t++) step_fast(sp[t], lane);  // < U leftover columns, still all in-haplotype
       run_any(a, sp, t, sep_at, lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
-      fast_from = sep_at + kLanes;
+      fast_from = sep_at + skew_max + 1;
       k_cur = k;  // from stream position sep_at on, lanes meet this haplotype's separator
       orig_cur = a.hap_orig[k];
       y0_next = k + 1 < hap_end ? a.y0[k + 1] : T(0);
@@ -833,7 +864,7 @@ __global__ __launch_bounds__(64) void pairhmm_fwd_long_kernel(FwdArgs<T> a, T* c
         slot.block = first_cnt + (st - 1) * kLanes + lane;
       }
       __syncthreads();
-      job.setup(a, lane, slot);
+      job.setup(a, lane, slot, /*full_skew=*/true);
       __syncthreads();
       const T* cin = st > 0 ? my + (int64_t)((st + 1) & 1) * cstride : nullptr;
       T* cout = st + 1 < n_stripes ? my + (int64_t)(st & 1) * cstride : nullptr;
