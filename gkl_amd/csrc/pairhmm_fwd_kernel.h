@@ -471,8 +471,20 @@ struct WaveJob {
 #pragma unroll
         for (int u = 0; u < U; u++) step_fast(e[u], lane);
       }
-      if (t >= fast_from)
-        for (; t < sep_at; t++) step_fast(sp[t], lane);  // < U leftover columns, still all in-haplotype
+      // < U leftover columns, still all in-haplotype.  fp32: they join the general steps below (unrolled by four with
+      // the entries prefetched: measured 1.3 % faster than single fast steps that each wait for their scalar load);
+      // fp64, whose general step is far more expensive: one unrolled block of four fast steps, then single ones.
+      if (sizeof(T) == 8 && t >= fast_from) {
+        if (t + 4 <= sep_at) {
+          uint32_t e[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) e[u] = sp[t + u];
+#pragma unroll
+          for (int u = 0; u < 4; u++) step_fast(e[u], lane);
+          t += 4;
+        }
+        for (; t < sep_at; t++) step_fast(sp[t], lane);
+      }
       run_any(a, sp, t, sep_at, lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
       fast_from = sep_at + skew_max + 1;
       k_cur = k;  // from stream position sep_at on, lanes meet this haplotype's separator
