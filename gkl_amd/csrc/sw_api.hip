@@ -149,7 +149,14 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
     p.alt_off = (int64_t)up(ref_bytes) + alt_off[k];
     p.nrow = (int32_t)rl;
     p.ncol = (int32_t)al;
-    p.rpl = rl > 4 * kLanes ? 8 : 4;   // 4 rows per lane while the reference fits one 256-row stripe, else 8
+    {
+      // Rows per lane.  A step costs the wavefront ~30 + 20 * rpl instructions whatever the number of lanes in use and a
+      // stripe takes ncol + lanes - 1 steps, so the cheapest fill uses ALL 64 lanes with as few rows each as possible:
+      // as many stripes as 8 rows per lane would need, the rows spread evenly over them.
+      const int64_t n_stripes = (rl + 8 * kLanes - 1) / (8 * kLanes);
+      const int64_t per_stripe = (rl + n_stripes - 1) / n_stripes;
+      p.rpl = (int32_t)std::max<int64_t>(1, (per_stripe + kLanes - 1) / kLanes);
+    }
     {
       const size_t stripe_rows = (size_t)kLanes * (size_t)p.rpl;
       bt_units = std::max(bt_units, (((size_t)rl + stripe_rows - 1) / stripe_rows) * ((size_t)al + kLanes) * kLanes);
@@ -190,7 +197,8 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
   // budget (default 8 GiB of the 288) caps the wavefront count when a batch holds very long sequences
   const size_t slab_bytes = (bt_units + aux_units + ops_units) * 4;
   const size_t budget = (size_t)8 << 30;
-  const int n_waves = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n, (size_t)256 * 16, budget / std::max<size_t>(slab_bytes, 1)}));
+  static const size_t waves_per_cu = [] { const char* v = getenv("GKLHIP_SW_WAVES_PER_CU"); return v ? (size_t)atoi(v) : (size_t)kSwWavesPerSimd * 4; }();
+  const int n_waves = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n, (size_t)256 * waves_per_cu, budget / std::max<size_t>(slab_bytes, 1)}));
   if ((rc = c->bt.reserve(bt_units * 4 * (size_t)n_waves))) return rc;
   if ((rc = c->aux.reserve(aux_units * 4 * (size_t)n_waves))) return rc;
   if ((rc = c->ops.reserve(ops_units * 4 * (size_t)n_waves))) return rc;

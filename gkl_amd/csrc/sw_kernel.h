@@ -23,8 +23,9 @@
 //   * maximum: H of the last row / last column goes to two small arrays; the order-dependent tie rule only
 //     ever matters among candidates equal to the global maximum, so a wave-parallel max is followed by an
 //     in-order pass over those candidates (ballot + scalar loop);
-//   * trace: the walker is wave-uniform (scalar registers); the wavefront prefetches a 16-row x 32-column
-//     tile of back-track nibbles per global load and walks inside it with v_readlane.
+//   * trace: the walker is wave-uniform (scalar registers) and advances a RUN per iteration: one gather of
+//     back-track words looks 32 cells up the diagonal, 16 up the column and 16 along the row, a ballot tells
+//     how far the current state (matches / deletion extension / insertion extension) carries.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,7 +47,8 @@ struct SwPair {
   int32_t nrow, ncol;        // len1 (reference, rows), len2 (alternate, columns)
   int64_t text_off;          // bytes: CIGAR text, [cigar_len], zero-filled by the host API
   int32_t cigar_len;
-  int32_t rpl;               // rows per lane of this pair's fill: 4 (up to 256 rows per stripe) or 8
+  int32_t rpl;               // rows per lane of this pair's fill, 1..8: the smallest that holds the reference in as few
+                             // 64-lane stripes as 8 rows per lane would need (chosen by the host, sw_api.hip)
 };
 
 struct SwArgs {
@@ -162,6 +164,8 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
       L.hl[s] = indel ? open + (i - 1) * extend : 0;       // H[i][0], PairWiseSW.h:194-203
       L.e[s] = kSwLow;                                     // :205
     }
+#pragma unroll
+    for (int s = 0; s < RPL; s++) asm volatile("" :: "v"(L.x[s]));  // wait for the base loads before the step loops, not in them
     L.hd = (row0 == 0 || !indel) ? 0 : open + (row0 - 1) * extend;  // H[row0][0]
     L.in_h = 0; L.in_f = kSwLow; L.out_h = 0; L.out_f = kSwLow;
     L.ent = 0x100u;
@@ -173,7 +177,12 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
     // the alternate bases arrive 64 at a time (one coalesced load per 64 steps), then one v_readlane per step
     uint32_t achunk = 0x100u;
     auto next_entry = [&](int t) -> uint32_t {
-      if ((t & 63) == 0) achunk = t + lane < ncol ? (uint32_t)alt[t + lane] : 0x100u;
+      if ((t & 63) == 0) {
+        achunk = t + lane < ncol ? (uint32_t)alt[t + lane] : 0x100u;
+        // consume the load HERE: otherwise its s_waitcnt vmcnt(0) lands in front of the v_readlane of every step and
+        // each step also waits for the previous step's back-track store (loads and stores share vmcnt on gfx9)
+        asm volatile("" :: "v"(achunk));
+      }
       return (uint32_t)sw_readlane((int32_t)achunk, t & 63);
     };
     auto general_step = [&](int t) {
@@ -186,6 +195,7 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
           const int c = t + 1 + lane;
           ci_h = c <= ncol ? cin_h[c] : 0;
           ci_f = c <= ncol ? cin_f[c] : kSwLow;
+          asm volatile("" :: "v"(ci_h), "v"(ci_f));  // same: wait for the carry loads once per 64 steps, not per step
         }
         const int32_t vh = sw_readlane(ci_h, t & 63), vf = sw_readlane(ci_f, t & 63);
         if (lane == 0) { L.in_h = vh; L.in_f = vf; }
@@ -248,7 +258,10 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
       }
     }
     for (; t < n_steps; t++) general_step(t);
-    __threadfence();  // carry rows, last_row/last_col and the back-track are read back by this wavefront
+    // carry rows, last_row/last_col and the back-track are read back by THIS wavefront only: workgroup scope (wait
+    // for the stores) is all it takes.  A device-scope __threadfence() is `buffer_wbl2 sc1` + `buffer_inv sc1` on
+    // gfx950 -- a write-back and invalidate of the XCD's whole L2, twice per pair and wavefront.
+    __threadfence_block();
   }
 }
 
@@ -318,7 +331,7 @@ __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int p
                                          int32_t max_j) {
   const int nrow = p.nrow, ncol = p.ncol;
   const uint32_t* bt = a.bt + (int64_t)blockIdx.x * a.bt_stride;
-  const int rpl = p.rpl, rshift = rpl == 8 ? 3 : 2;
+  const int rpl = p.rpl;
   const int64_t stripe_words = (int64_t)(ncol + kLanes) * kLanes;
   int32_t* ops = a.ops + (int64_t)blockIdx.x * a.ops_stride;  // run-length ops in walk order: op << 28 | length
   int n_ops = 0;
@@ -334,33 +347,59 @@ __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int p
   else if (a.strategy == kSwLeadingIndel) { i = max_i; j = ncol; }
   else { i = max_i; j = max_j; }
   if (j < ncol) push(kSwSoftclip, ncol - j);
+  // The walk, one RUN per iteration instead of one cell.  The wavefront looks ahead along the three directions the
+  // walker can take from (i, j) -- 32 cells up the diagonal, 16 up the column, 16 along the row -- with ONE gather
+  // of back-track words (every lane fetches the word of its own cell), then a ballot tells how far the current
+  // state carries: a run of plain matches in state 0, a run of extension flags inside an insertion / deletion.
+  // Cell by cell this is the reference's loop (:295-395): a cell is consumed only if the one before it left the
+  // walker in the state the run assumes, and i, j > 0 is part of a cell being there at all.
+  const uint64_t magic = (1ull << 32) / (uint64_t)rpl + 1u;  // (x * magic) >> 32 == x / rpl for x < 2^27 (rpl <= 8)
   int state = 0;
-  int budget = nrow + ncol + 2;  // every step consumes a row or a column: a hard bound, whatever the memory holds
+  int budget = nrow + ncol + 2;  // every cell consumes a row or a column: a hard bound, whatever the memory holds
   while (i > 0 && j > 0 && budget > 0) {
-    // tile: 4 row blocks x 16 columns of back-track words ending at the walker's block / column
-    const int b0 = (i - 1) >> rshift, c0 = j - 1;
-    const int tb = b0 - (lane >> 4), tc = c0 - (lane & 15);
-    uint32_t tile = 0;
-    if (tb >= 0 && tc >= 0)  // block tb = stripe tb / 64, lane tb % 64, stored at step tc + lane
-      tile = bt[(int64_t)(tb >> 6) * stripe_words + (int64_t)(tc + (tb & 63)) * kLanes + (tb & 63)];
-    while (i > 0 && j > 0 && budget > 0) {
-      const int b = (i - 1) >> rshift, c = j - 1;
-      if (b0 - b > 3 || c0 - c > 15) break;
-      budget--;
-      const uint32_t w = (uint32_t)sw_readlane((int32_t)tile, ((b0 - b) << 4) | (c0 - c));
-      const int nib = (int)((w >> (4 * (rpl - 1 - ((i - 1) & (rpl - 1))))) & 0xfu);
-      // the reference's encoding (smithwaterman_common.h:44-48): direction in bits 0-1, extensions in bits 2-3
-      const int btr = ((nib & kBtDel) ? kSwDelete : (nib & kBtIns) ? kSwInsert : kSwMatch) |
-                      ((nib & kBtInsExt) ? kSwInsertExt : 0) | ((nib & kBtDelExt) ? kSwDeleteExt : 0);
-      if (state == kSwInsertExt) { j--; cur_len++; state = btr & kSwInsertExt; }
-      else if (state == kSwDeleteExt) { i--; cur_len++; state = btr & kSwDeleteExt; }
-      else {
-        const int dir = btr & 3;
-        if (dir == kSwMatch) { i--; j--; push(kSwMatch, 1); state = 0; }
-        else if (dir == kSwInsert) { j--; push(kSwInsert, 1); state = btr & kSwInsertExt; }
-        else { i--; push(kSwDelete, 1); state = btr & kSwDeleteExt; }
-      }
+    const int k = lane < 32 ? lane : (lane - 32) & 15;
+    const int ci = lane < 48 ? i - k : i;              // lanes 0-31 diagonal, 32-47 up (k = 0: the current cell), 48-63 left
+    const int cj = (lane < 32 || lane >= 48) ? j - k : j;
+    const bool there = ci > 0 && cj > 0;
+    uint32_t nib = 0;
+    if (there) {
+      const uint32_t x = (uint32_t)(ci - 1);
+      const uint32_t tb = (uint32_t)(((uint64_t)x * magic) >> 32), slot = x - tb * (uint32_t)rpl, tc = (uint32_t)(cj - 1);
+      // row block tb = stripe tb / 64, lane tb % 64, stored at step tc + lane
+      const uint32_t w = bt[(int64_t)(tb >> 6) * stripe_words + (int64_t)(tc + (tb & 63u)) * kLanes + (tb & 63u)];
+      nib = (w >> (4u * ((uint32_t)rpl - 1u - slot))) & 0xfu;
     }
+    int n;  // cells consumed by this iteration (>= 1)
+    if (state == 0) {
+      const uint32_t plain = (uint32_t)__ballot(there && (nib & (kBtDel | kBtIns)) == 0);  // low half: the diagonal
+      n = plain == 0xffffffffu ? 32 : __builtin_ctz(~plain);   // leading plain matches
+      if (n > 0) {
+        n = n < budget ? n : budget;
+        push(kSwMatch, n);
+        i -= n; j -= n;
+      } else {  // the current cell opens a deletion or an insertion (deletion wins, smithwaterman_common.h:44-48)
+        const uint32_t nib0 = (uint32_t)sw_readlane((int32_t)nib, 0);
+        n = 1;
+        if (nib0 & kBtDel) { i--; push(kSwDelete, 1); state = (nib0 & kBtDelExt) ? kSwDeleteExt : 0; }
+        else { j--; push(kSwInsert, 1); state = (nib0 & kBtInsExt) ? kSwInsertExt : 0; }
+      }
+    } else {
+      // inside a deletion (walking up, lanes 32-47) or an insertion (walking left, lanes 48-63): every cell is
+      // consumed; the first one without the extension flag ends the run and returns to state 0
+      const bool del = state == kSwDeleteExt;
+      const uint64_t bal = __ballot(there && (nib & (del ? kBtDelExt : kBtInsExt)) != 0);
+      const uint64_t thr = __ballot(there);
+      const uint32_t ext = (uint32_t)(bal >> (del ? 32 : 48)) & 0xffffu, have = (uint32_t)(thr >> (del ? 32 : 48)) & 0xffffu;
+      const int lead = __builtin_ctz(~ext | 0x10000u);          // leading cells that keep the state (0..16)
+      const int cells = __builtin_ctz(~have | 0x10000u);        // cells that exist (>= 1)
+      n = lead + 1 <= cells ? lead + 1 : cells;                 // + the cell that clears the flag, if it is there
+      if (n > 16) n = 16;
+      if (n > lead) state = 0;
+      n = n < budget ? n : budget;
+      cur_len += n;
+      if (del) i -= n; else j -= n;
+    }
+    budget -= n;
   }
   int32_t offset;
   if (a.strategy == kSwSoftclip) {
@@ -375,7 +414,7 @@ __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int p
     offset = 0;
   }
   if (cur_op >= 0) { if (lane == 0) ops[n_ops] = (int32_t)(((uint32_t)cur_op << 28) | ((uint32_t)cur_len & 0xffffu)); n_ops++; }
-  __threadfence();
+  __threadfence_block();  // ops[] is read back by this wavefront
   // text, last operation first (:417-449); lengths are int16 in the reference.  Executed by the whole
   // wavefront with lane 0 storing: a lane-0-only region at the end of the persistent loop invites the compiler
   // to thread it into the next iteration's lane-0 atomic, which tears the wavefront apart (observed: hang).
@@ -400,7 +439,11 @@ __device__ __forceinline__ void sw_trace(const SwArgs& a, const SwPair& p, int p
   }
 }
 
-__global__ __launch_bounds__(64) void sw_align_kernel(SwArgs a) {
+#ifndef GKL_SW_WAVES
+#define GKL_SW_WAVES 4
+#endif
+constexpr int kSwWavesPerSimd = GKL_SW_WAVES;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GKL_SW_WAVES))) void sw_align_kernel(SwArgs a) {
   const int lane = threadIdx.x;
   for (;;) {
     int k = 0;
@@ -409,8 +452,16 @@ __global__ __launch_bounds__(64) void sw_align_kernel(SwArgs a) {
     if (k >= a.n_pairs) break;
     const int pi = a.order[k];
     const SwPair p = a.pairs[pi];
-    if (p.rpl == 8) sw_fill<8>(a, p, lane);
-    else sw_fill<4>(a, p, lane);
+    switch (p.rpl) {
+      case 1: sw_fill<1>(a, p, lane); break;
+      case 2: sw_fill<2>(a, p, lane); break;
+      case 3: sw_fill<3>(a, p, lane); break;
+      case 4: sw_fill<4>(a, p, lane); break;
+      case 5: sw_fill<5>(a, p, lane); break;
+      case 6: sw_fill<6>(a, p, lane); break;
+      case 7: sw_fill<7>(a, p, lane); break;
+      default: sw_fill<8>(a, p, lane); break;
+    }
     int32_t max_i = 0, max_j = 0;
 #ifndef GKL_SW_ABL   // timing ablations (tools): 1 = fill only, 2 = fill + maximum; results are WRONG when defined
     sw_find_max(a, p, lane, &max_i, &max_j);
