@@ -41,6 +41,10 @@ namespace gklhip {
 constexpr uint32_t kEntIdle = 5u;           // stream entry: idle column (prior 0, no LDS row)
 constexpr uint32_t kEntSep = 0x80000000u;   // stream entry: separator | stream-order hap index
 constexpr int kLanes = 64;
+// The haplotype stream is written by an earlier kernel and only read here: reading it through the constant address
+// space lets every (wave-uniform) entry load be a scalar s_load, also in the job-list kernel whose atomics make the
+// compiler treat plain global memory as clobbered (there the entries came through global_load_dwordx4 + vmcnt waits).
+typedef const uint32_t __attribute__((address_space(4))) StreamWord;
 
 template <typename T>
 struct DevTables {
@@ -453,7 +457,7 @@ struct WaveJob {
   __device__ __forceinline__ void run(const FwdArgs<T>& a, int lane, int hap_begin, int hap_end) {
     constexpr int U = 8;
     const int sb = a.hap_pos[hap_begin];
-    const uint32_t* __restrict__ sp = a.stream + sb;
+    StreamWord* sp = (StreamWord*)(a.stream + sb);
     reset_state(a.y0[hap_begin]);
     int t = 0;
     int fast_from = skew_max;  // the fill: the most skewed lane is idle until t = skew_max
@@ -496,7 +500,7 @@ struct WaveJob {
 
   // General steps for stream positions [t, end): four at a time so the stream entries come from
   // one scalar load issued ahead of use and the state needs no loop-carried register copies.
-  __device__ __forceinline__ void run_any(const FwdArgs<T>& a, const uint32_t* __restrict__ sp, int& t, int end,
+  __device__ __forceinline__ void run_any(const FwdArgs<T>& a, StreamWord* sp, int& t, int end,
                                           int lane, int hap_begin, int hap_end, int k_cur, int orig_cur, T y0_next) {
     constexpr int V = 4;
     for (; t + V <= end; t += V) {
