@@ -166,12 +166,22 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
     p.text_off = (int64_t)k * cigar_stride;
     p.cigar_len = cigar_stride;
   }
-  // longest pairs first: the persistent wavefronts finish together
+  // longest pairs first: the persistent wavefronts finish together.  A counting sort on the cell count (4096 classes
+  // up to the largest pair, stable within a class) -- the comparison sort it replaces took 2-3 ms for 32 k pairs.
   std::vector<int32_t> order((size_t)n);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-    return (int64_t)pairs[(size_t)x].nrow * pairs[(size_t)x].ncol > (int64_t)pairs[(size_t)y].nrow * pairs[(size_t)y].ncol;
-  });
+  {
+    int64_t max_cells = 1;
+    for (int32_t k = 0; k < n; k++) max_cells = std::max(max_cells, (int64_t)pairs[(size_t)k].nrow * pairs[(size_t)k].ncol);
+    constexpr int kClasses = 4096;
+    const auto cls = [&](int32_t k) {
+      const int64_t cells = (int64_t)pairs[(size_t)k].nrow * pairs[(size_t)k].ncol;
+      return (int)(kClasses - 1 - (int64_t)((__int128)cells * (kClasses - 1) / max_cells));   // 0 = largest
+    };
+    std::vector<int32_t> start(kClasses + 1, 0);
+    for (int32_t k = 0; k < n; k++) start[(size_t)cls(k) + 1]++;
+    for (int q = 0; q < kClasses; q++) start[(size_t)q + 1] += start[(size_t)q];
+    for (int32_t k = 0; k < n; k++) order[(size_t)start[(size_t)cls(k)]++] = k;
+  }
 
   std::lock_guard<std::mutex> lock(c->mu);
   SW_HIP_TRY(hipSetDevice(c->device));
@@ -183,11 +193,13 @@ int gklhip_sw_align_batch(gklhip_sw_ctx* c, const gklhip_sw_params* prm, int32_t
   if ((rc = c->stage_in.reserve(in_total))) return rc;
   if ((rc = c->dev_in.reserve(in_total))) return rc;
   unsigned char* hs = c->stage_in.as<unsigned char>();
+  // staged in two parts so the DMA of the references runs while the host still copies the rest
   memcpy(hs + o_ref, refs, ref_bytes);
+  SW_HIP_TRY(hipMemcpyAsync(c->dev_in.p, hs, o_alt, hipMemcpyHostToDevice, s));
   memcpy(hs + o_alt, alts, alt_bytes);
   memcpy(hs + o_pairs, pairs.data(), (size_t)n * sizeof(SwPair));
   memcpy(hs + o_order, order.data(), (size_t)n * 4);
-  SW_HIP_TRY(hipMemcpyAsync(c->dev_in.p, hs, in_total, hipMemcpyHostToDevice, s));
+  SW_HIP_TRY(hipMemcpyAsync(c->dev_in.as<unsigned char>() + o_alt, hs + o_alt, in_total - o_alt, hipMemcpyHostToDevice, s));
   // ---- device scratch and outputs ----
   const size_t text_bytes = (size_t)n * (size_t)cigar_stride;
   const size_t o_text = 0, o_res = up(text_bytes), out_total = o_res + up((size_t)n * 16);

@@ -203,7 +203,10 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
         L.in_h = indel ? open + (j - 1) * extend : 0;       // H[0][j]
         L.in_f = kSwLow;                                    // F[0][j], :204
       }
-      const uint32_t word = L.template step<false>(open, extend, match, mismatch, act);
+      // lanes outside their column range sit the step out (EXEC mask) instead of computing it and selecting the
+      // old state back: the guarded step costs the wavefront what a steady one does
+      uint32_t word = 0;
+      if (act) word = L.template step<true>(open, extend, match, mismatch, true);
       bt_st[(int64_t)t * kLanes] = word;   // unconditionally: slots outside the matrix are never read
       if (act) {
         if (holds_last) {
