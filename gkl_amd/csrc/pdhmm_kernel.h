@@ -229,7 +229,16 @@ struct PdJob {
     for (int k = 0; k < 6; k++) d[k] = r[k];
     const double add = nmm[RPL - 1] + nim[RPL - 1];  // finalSum += M + I, ascending columns (:839-846)
     sum = off ? sum : sum + add;
-    fetch_above();
+    if (kPlain) {
+      // every lane took a plain step, so the lane above's new branch values are its OLD match/insertion/deletion
+      // values -- exactly what this lane received last time (now d[0..2]): three register moves replace six DPP moves
+      r[0] = recv_above(mm[RPL - 1], lmask);
+      r[1] = recv_above(im[RPL - 1], lmask);
+      r[2] = recv_above(dm[RPL - 1], lmask);
+      r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+    } else {
+      fetch_above();
+    }
   }
 
   // a column is special when it is entered in state INSIDE_DEL / AFTER_DEL or carries DEL_END
