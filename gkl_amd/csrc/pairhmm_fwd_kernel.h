@@ -438,7 +438,12 @@ struct WaveJob {
       } else {
         const bool mine = (k >= hap_begin) && (k < hap_end);
         if (mine && out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
-        if (mine && k + 1 < hap_end) y0n = a.y0[k + 1];
+        if (mine && k + 1 < hap_end) {
+          y0n = a.y0[k + 1];
+          // consume the load inside this (rare) branch: left pending, its s_waitcnt vmcnt(0) lands behind the join and
+          // EVERY general step then also waits for the previous step's result store (loads and stores share vmcnt)
+          asm volatile("" :: "v"(y0n));
+        }
       }
     }
 #pragma unroll
