@@ -362,7 +362,7 @@ int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   a.chunk_steps = reinterpret_cast<const int32_t*>(dj + o_cs);
   a.chunk_rep = reinterpret_cast<const int32_t*>(dj + o_cr);
 
-  hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)((nh + 127) / 128)), dim3(128), 0, s, a);
+  hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)nh), dim3(kLanes), 0, s, a);   // one wavefront per haplotype item
   PD_HIP_TRY(hipEventRecord(c->ev0, s));
   if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
   else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);

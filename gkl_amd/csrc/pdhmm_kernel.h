@@ -79,26 +79,44 @@ struct PdArgs {
 __device__ __forceinline__ int pd_read_of(const PdArgs& a, int p) { return a.cross_haps ? p / a.cross_haps : p; }
 __device__ __forceinline__ int pd_hap_of(const PdArgs& a, int p) { return a.cross_haps ? p % a.cross_haps : p; }
 
-// One thread per haplotype item: walk the column state machine (pdhmm.h:437-449 -- it depends on the
-// haplotype only and restarts at NORMAL on every row) and emit one entry per column.
-__global__ void pdhmm_entries_kernel(PdArgs a) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per haplotype item: the column state machine (pdhmm.h:437-449 -- it depends on the haplotype only
+// and restarts at NORMAL on every row) as a wave-parallel scan, one entry per column, coalesced stores.
+// A column without DEL_START / DEL_END leaves INSIDE_DEL alone and turns AFTER_DEL into NORMAL; DEL_START sets
+// INSIDE_DEL, DEL_END (which wins when both are set) sets AFTER_DEL.  So the state a column is ENTERED in depends
+// only on the nearest flagged column k before it: none -> NORMAL; DEL_END at k -> AFTER_DEL if k is the previous
+// column, else NORMAL; DEL_START only -> INSIDE_DEL.  "Nearest flagged column before j" is an exclusive prefix
+// maximum of (2 * k + is_end) over the columns.
+__global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x;
   if (p >= a.n_hap_items) return;
   const int H = (int)a.hap_len[p];
   const int8_t* hb = a.hap_bases + (int64_t)p * a.max_hap;
   const int8_t* pd = a.hap_pdbases + (int64_t)p * a.max_hap;
   uint32_t* e = a.entries + (int64_t)p * a.entry_stride;
-  for (int j = 0; j < kLanes; j++) e[j] = kPdIdle;
+  e[lane] = kPdIdle;
   e += kLanes;
-  int state = 0;
-  for (int j = 0; j < H; j++) {
-    const uint32_t flags = (uint32_t)pd[j] & 0x7fu;
-    e[j] = ((uint32_t)hb[j] & 0xffu) | (flags << 8) | ((uint32_t)state << 16);
-    if (state == 2) state = 0;
-    if (flags & kPdDelStart) state = 1;
-    if (flags & kPdDelEnd) state = 2;
+  int carry = -1;  // key of the last flagged column of the tiles before this one
+  for (int base = 0; base < H; base += kLanes) {
+    const int j = base + lane;
+    const bool valid = j < H;
+    const uint32_t flags = valid ? ((uint32_t)pd[j] & 0x7fu) : 0u;
+    const bool flagged = (flags & (kPdDelStart | kPdDelEnd)) != 0u;
+    int incl = flagged ? 2 * j + ((flags & kPdDelEnd) ? 1 : 0) : -1;
+#pragma unroll
+    for (int d = 1; d < kLanes; d <<= 1) {
+      const int o = __shfl_up(incl, d, kLanes);
+      if (lane >= d && o > incl) incl = o;
+    }
+    int excl = __shfl_up(incl, 1, kLanes);
+    if (lane == 0) excl = -1;
+    if (carry > excl) excl = carry;
+    const uint32_t state = excl < 0 ? 0u : ((excl & 1) ? ((excl >> 1) == j - 1 ? 2u : 0u) : 1u);
+    if (valid) e[j] = ((uint32_t)hb[j] & 0xffu) | (flags << 8) | (state << 16);
+    const int last = __shfl(incl, kLanes - 1, kLanes);
+    if (last > carry) carry = last;
   }
-  for (int j = H; j < a.entry_stride - kLanes; j++) e[j] = kPdIdle;
+  for (int j = H + lane; j < a.entry_stride - kLanes; j += kLanes) e[j] = kPdIdle;
 }
 
 __device__ __forceinline__ double pd_max(double x, double y) { return x > y ? x : y; }  // _mm256_max_pd on finite values

@@ -18,7 +18,9 @@ def main():
     ap.add_argument("--reads", type=int, default=600)
     ap.add_argument("--haps", type=int, default=20)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--json", default=None, help="write a bench-style JSON summary of the fixture case here")
     a = ap.parse_args()
+    import json
     from gkl_amd import native
     from tests.test_pdhmm import cross_product, random_pd_batch
     rng = np.random.RandomState(7)
@@ -51,6 +53,18 @@ def main():
           f"kernel {best_k:.3f} ms = {cc / best_k / 1e6:.1f} GCUPS   host-to-host {best_w * 1e3:.2f} ms = "
           f"{cc / best_w / 1e9:.1f} GCUPS", flush=True)
     ctx0.close()
+    summary = {"metric": "pdhmm_gcups", "unit": "GCUPS", "dtype": "f64", "data": "the reference's own fixture pdhmm_new.txt",
+               "config": {"workload": f"IntelPDHMM.computeLikelihoods: {cross_reads.batch} reads x {cross_haps.batch} PD haplotypes "
+                                      f"(the fixture's 276 reads x4), cross entry point", "cells": cc},
+               "kernel_ms": round(best_k, 4), "kernel_gcups": round(cc / best_k / 1e6, 1),
+               "host_to_host_ms": round(best_w * 1e3, 3), "value": round(cc / best_w / 1e9, 1),
+               # 12 flop per cell: M = prior * fma(.., fma(.., mul)) = 6, D = fma + mul = 3, I = fma + mul = 3 (pdhmm.h:427-443)
+               "roofline": {"bound": "mfma", "limiter": "valu-fp64 issue", "kernel": "pdhmm_fwd_kernel", "flop_per_cell": 12,
+                            "achieved": round(12 * cc / best_k / 1e9, 2), "peak": 78.6, "unit": "TFLOP/s",
+                            "frac": round(12 * cc / best_k / 1e9 / 78.6, 4), "traffic": None,
+                            "note": "fp64 vector recurrence (no contraction for MFMA), priced at the dense fp64 MFMA peak = "
+                                    "fp64 vector peak; 2 wavefronts per SIMD (235 VGPRs), most of the step is selects and "
+                                    "moves around 32 fp64 operations (DESIGN.md section 8)"}}
     for name, b in cases.items():
         ctx.compute(b)
         best_k, best_w = 1e9, 1e9
@@ -70,9 +84,17 @@ def main():
             ref.compute(sub, engine=2 if ref.simd_width(2) >= 8 else 1, threads=1)
             dt = time.perf_counter() - t0
             line += f"   reference 1 thread {sub.cells / dt / 1e9:.2f} GCUPS"
+            if name.startswith("fixture"):
+                summary["cpu_baseline"] = {"value": round(sub.cells / dt / 1e9, 3), "unit": "GCUPS", "cores": 1, "kind": "reference",
+                                           "sample": f"first {sub.batch} pairs of the same fixture, GKL's own "
+                                                     f"{'AVX-512' if ref.simd_width(2) >= 8 else 'AVX2'} kernel, one thread"}
         except Exception as e:  # noqa: BLE001
             line += f"   (reference unavailable: {e})"
         print(line, flush=True)
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(summary, f)
+            f.write("\n")
 
 
 if __name__ == "__main__":

@@ -29,7 +29,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--json", default=None, help="write a bench-style JSON summary of the first shape here")
     a = ap.parse_args()
+    import json
+    summary = None
     from gkl_amd import native
     SOFTCLIP = native.SW_SOFTCLIP
     params = (200, -150, -260, -11)
@@ -78,6 +81,30 @@ def main():
             line += (f" | reference ({'AVX-512' if eng == 2 else 'AVX2'}, 1 thread) {cpu * 1e6:.0f} us/call = "
                      f"{sub_cells / (cpu * len(sub)) / 1e9:.2f} GCUPS")
         print(line, flush=True)
+        if summary is None:
+            # 20 integer VALU operations per cell (5 add, 5 max, compare+select for the score, 2 per back-track bit);
+            # peak = one 32-bit integer operation per lane and clock: 256 CU x 64 lanes x 2.4 GHz
+            peak = 256 * 64 * 2.4e9 / 1e12
+            summary = {"metric": "smithwaterman_gcups", "unit": "GCUPS", "dtype": "int32", "data": "synthetic",
+                       "config": {"workload": f"{len(pairs)} pairs, {name}, GATK parameters 200/-150/-260/-11, SOFTCLIP, "
+                                              f"batch entry point gklhip_sw_align_batch", "cells": cells},
+                       "kernel_ms": round(best_k, 4), "kernel_gcups": round(cells / best_k / 1e6, 1),
+                       "host_to_host_ms": round(best_w * 1e3, 3), "value": round(cells / best_w / 1e9, 1),
+                       "single_pair_call_us": round(one * 1e6, 1),
+                       "roofline": {"bound": "mfma", "limiter": "valu-int32 issue", "kernel": "sw_align_kernel",
+                                    "ops_per_cell": 20, "achieved": round(20 * cells / best_k / 1e9, 2), "peak": round(peak, 1),
+                                    "unit": "Tiop/s", "frac": round(20 * cells / best_k / 1e9 / peak, 4), "traffic": None,
+                                    "note": "integer recurrence on the vector ALUs (nothing for MFMA, 0.5-1 B/cell of HBM "
+                                            "traffic); peak = one int32 op per lane per clock"}}
+            if ref_eng is not None:
+                summary["cpu_baseline"] = {"value": round(sub_cells / (cpu * len(sub)) / 1e9, 3), "unit": "GCUPS", "cores": 1,
+                                           "kind": "reference", "us_per_call": round(cpu * 1e6, 1),
+                                           "sample": f"first {len(sub)} pairs of the same batch, GKL's own "
+                                                     f"{'AVX-512' if eng == 2 else 'AVX2'} object, one thread, one call per pair"}
+    if a.json and summary is not None:
+        with open(a.json, "w") as f:
+            json.dump(summary, f)
+            f.write("\n")
 
 
 if __name__ == "__main__":
