@@ -232,7 +232,8 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
       // single stripe (every pair up to 64*RPL rows): ramp-up with guards, then a steady phase in which every
       // lane is inside its column range -- no selects, lane 0's boundary value from a scalar register -- then
       // the drain with guards again.
-      const int steady_end = ncol;                       // steps [lanes_used - 1, ncol) have all lanes active
+      const int steady_end = ncol - 1;                   // steps [lanes_used - 1, ncol) have all lanes active; the last of
+                                                         // them (lane 0 on column ncol: last_col) is left to the guarded step
       for (; t < lanes_used - 1 && t < n_steps; t++) general_step(t);
       int32_t bnd = indel ? open + t * extend : 0;        // H[0][t + 1]
       const int32_t bnd_step = indel ? extend : 0;
@@ -249,11 +250,6 @@ __device__ __forceinline__ void sw_fill(const SwArgs& a, const SwPair& p, int la
 #pragma unroll
             for (int s = 1; s < RPL; s++) h_last = s == last_s ? L.hl[s] : h_last;
             last_row[t - lane + 1] = h_last;
-          }
-          if (t - lane + 1 == ncol) {
-#pragma unroll
-            for (int s = 0; s < RPL; s++)
-              if (row0 + 1 + s <= nrow) last_col[row0 + 1 + s] = L.hl[s];
           }
         }
         L.in_h = (int32_t)dpp_shr1_zero((uint32_t)L.out_h);
