@@ -303,7 +303,7 @@ int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const int n_cross_jobs = (int)n_cross_jobs64;
   const int n_general = (int)job_pair.size();
   const int n_jobs = n_cross_jobs + n_general;
-  const int entry_stride = (q.max_hap_len + 2 * kLanes + 1 + 63) / 64 * 64;
+  const int entry_stride = (q.max_hap_len + 2 * kLanes + 4 + 63) / 64 * 64;   // 64 idle, the columns, 63 skew + 4 look-ahead
   const int carry_len = entry_stride;
   const int n_blocks = std::min(n_jobs, 256 * 8);
   if ((rc = c->entries.reserve(nh * (size_t)entry_stride * 4))) return rc;
