@@ -11,7 +11,8 @@ in HBM: plan -> fp32 forward kernel over all pairs -> precision policy -> fp64 r
 of the underflowed pairs -> log10 finalisation (doubles in HBM), and for N>1 the gather of
 every rank's results on rank 0 over RCCL (issued asynchronously: it overlaps the next step's
 kernels; all gathers complete inside the timed region).  Weak scaling: every rank owns its own 10k reads
-(same 128 haplotypes), i.e. the global batch is N x 10k reads sharded by read range.
+(same 128 haplotypes), i.e. the global batch is N x 10k reads sharded by read range.  `--strong` runs BASELINE
+config 4 instead: ONE 8000 x 125 batch (1 M pairs) cut into N read ranges balanced by cells (`"scaling": "strong"`).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the fp32 forward
 kernel): 12 FLOP per cell x cells per launch / its HIP-event duration,
@@ -105,7 +106,12 @@ def main():
     ap.add_argument("--haps", type=int, default=128)
     ap.add_argument("--double", action="store_true", help="useDoublePrecision (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (BASELINE config 4): ONE batch of --reads x --haps (default 8000 x 125 = 1 M pairs) "
+                         "sharded over the ranks by read range, balanced by cells")
     a = ap.parse_args()
+    if a.strong and a.reads == 10000 and a.haps == 128:
+        a.reads, a.haps = 8000, 125
 
     import torch
     import torch.distributed as dist
@@ -134,14 +140,21 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    # every rank: same haplotypes (seed), its own reads (read_seed)
-    batch = make_batch(a.workload, a.reads, a.haps, seed=DEFAULT_SEED, read_seed=DEFAULT_SEED + 1 + rank)
+    if a.strong:
+        # one global batch, this rank's contiguous read range of it (shard.py balances the ranges by cells)
+        from gkl_amd.shard import shard_batch
+        whole = make_batch(a.workload, a.reads, a.haps, seed=DEFAULT_SEED)
+        batch, bounds = shard_batch(whole, rank, world)
+        rows = [bounds[g + 1] - bounds[g] for g in range(world)]
+    else:
+        # every rank: same haplotypes (seed), its own reads (read_seed)
+        batch = make_batch(a.workload, a.reads, a.haps, seed=DEFAULT_SEED, read_seed=DEFAULT_SEED + 1 + rank)
+        rows = [a.reads] * world
     dbatch = native.DeviceBatch.upload(batch, dev)
     # record_events=2: kernels are bracketed with HIP events but no call synchronises, so the host-side planning of
     # step k+1 overlaps the kernels of step k; the event times are read after the timed region
     ctx = native.PairHmmContext(use_double=a.double, device=dev_index, record_events=2)
     sync_each_step = os.environ.get("GKL_BENCH_SYNC_EACH_STEP") == "1"   # A/B switch: the old behaviour
-    rows = [a.reads] * world
     stream = torch.cuda.current_stream(dev)
     # N>1: the gather of step k (RCCL, its own stream) overlaps the kernels of step k+1; two result buffers rotate
     gather = PipelinedGather(rows, a.haps, comm_dev, dist if world > 1 else _SingleRank())
@@ -208,12 +221,13 @@ def main():
             "metric": "pairhmm_gcups", "value": round(total_cells * a.steps / elapsed / 1e9, 2), "unit": "GCUPS",
             "likelihoods_per_s": round(total_pairs * a.steps / elapsed, 1),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if a.strong else "weak",
             "vs_baseline": None, "dtype": "f64" if a.double else "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {a.reads} reads x {a.haps} haps per GPU (reads 50-250 bp, haps "
+            "config": {"workload": f"{a.workload}: {a.reads} reads x {a.haps} haps {'in total' if a.strong else 'per GPU'} (reads 50-250 bp, haps "
                                    f"100-500 bp), {'fp64 all pairs' if a.double else 'fp32 + fp64 fallback policy'}, "
                                    f"inputs and log10 outputs resident in HBM",
-                       "pairs_per_gpu": batch.n_pairs, "cells_per_gpu": batch.cells,
+                       "pairs_per_gpu": batch.n_pairs, "cells_per_gpu": batch.cells,   # rank 0's share
                        "fallback_fraction": round(st["n_fallback"] / batch.n_pairs, 4),
                        "parallelism": f"read-range shard x{world}, gather to rank 0 overlapped with the next step" if world > 1 else "single GPU",
                        "finalize": "device log10 in double"},
