@@ -8,7 +8,8 @@
 // "skip what does not fit / has length 0" rule.  Integer work: results are bit-exact (oracle/sw_oracle.c).
 //
 // Mapping: the reference sweeps anti-diagonals with one SIMD vector; here a 64-lane wavefront is a systolic
-// array like the PairHMM kernels' -- lane L owns 4 or 8 consecutive rows (reference bases) in registers, the
+// array like the PairHMM kernels' -- lane L owns 1..8 consecutive rows (reference bases; chosen per pair so that
+// all 64 lanes are in use) in registers, the
 // alternate sequence streams through the lanes one column per step, the row above arrives by DPP
 // wave_shr:1 (H and F, 2 values per step).  Sequences longer than 64 lanes' worth of rows run as stripes, the
 // boundary row (H, F per column) carried through HBM.  One wavefront owns one pair from fill to text;
@@ -19,7 +20,7 @@
 //     nrow*ncol/2 bytes per pair with 8 rows per lane instead of the reference's 2 bytes per cell of a
 //     1024-stride matrix;
 //   * most steps have every lane inside its column range: that steady phase runs without a single select
-//     (ramp-up and drain keep the guarded step);
+//     (in ramp-up and drain the lanes outside their column range sit the step out under the EXEC mask);
 //   * maximum: H of the last row / last column goes to two small arrays; the order-dependent tie rule only
 //     ever matters among candidates equal to the global maximum, so a wave-parallel max is followed by an
 //     in-order pass over those candidates (ballot + scalar loop);
