@@ -5,6 +5,8 @@
 // :150-169 (batch loop + fp32->fp64 policy + log10), :189-192 (done).  There is no
 // CPU compute path in this library: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen()ed by multi-device contexts
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -16,6 +18,7 @@
 #include <condition_variable>
 #include <functional>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -87,38 +90,39 @@ struct PinBuf {
 }  // namespace
 
 // ------------------------------------------------------------------ context
-struct gklhip_ctx {
+// One device's engine: streams, tables, grow-only scratch.  The public gklhip_ctx owns one of these per
+// device of its list (one for the usual single-device context).
+struct DevCtx {
   gklhip_config cfg;
   int device = 0;
+  int n_cus = 256;
   hipStream_t stream = nullptr;
-  std::mutex mu;
   // tables
   DevBuf tab32, tab64;
   DevTables<float> dt32;
   DevTables<double> dt64;
   // per-call plan uploads (pinned staging -> device)
   // Two slots alternate from call to call: the plan of call k+1 is staged and uploaded (own stream) while the
-  // kernels of call k still read theirs -- back-to-back batches then never wait for the 1.7 MB plan block.
+  // kernels of call k still read theirs -- back-to-back batches then never wait for the plan block.
   PinBuf stage_slot[2];
   DevBuf plan_dev_slot[2];
   hipEvent_t stage_free_slot[2] = {nullptr, nullptr};   // the slot's upload has left the staging buffer
   hipEvent_t plan_unused_slot[2] = {nullptr, nullptr};  // the last call that used the slot's device copy has finished
   hipStream_t upload_stream = nullptr;
   int plan_slot = 0;
-  // small host-buffer calls: after the policy kernel the packed results and the fallback count come back at once;
-  // a call without underflowed pairs (the usual GATK region) then skips the whole fp64 stage
-  bool peek_after_policy = false;   // in: set by gklhip_compute
-  bool fallback_skipped = false;    // out
-  PinBuf peek_count;
   // per-call device scratch
-  DevBuf raw32, raw64, used64, list, counters, stream_buf, read_off_dev, out_dev;
+  DevBuf raw32, raw64, used64, counters, stream_buf, out_dev;
   DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist, hap_flags;
   // host-API device copies of the batch, packed results (device + pinned), finalisation workers
   DevBuf batch_dev, res_dev;
-  PinBuf res_pin, res_pin2, batch_stage;
+  PinBuf res_pin, res_pin2;
   WorkerPool workers;
-  hipStream_t copy_stream = nullptr;  // early D2H of the fp32 results while the fp64 pass runs
+  hipStream_t copy_stream = nullptr;  // early D2H of the fp32 results / device log10 of the kept pairs while the fp64 pass runs
   hipEvent_t policy_done = nullptr, early_copy_done = nullptr;
+  // scratch is per context and ordered by the stream of the call that uses it: a call on a different stream than
+  // the previous one first waits for that one's end
+  hipEvent_t call_done = nullptr;
+  bool have_call_done = false;
   // events: kEventRing sets of 6 (call start, main begin/end, fallback begin/end, call end); record_events == 1 uses
   // set 0 and synchronises every call, record_events == 2 rotates through the ring and never synchronises
   // (gklhip_get_step_times reads a set later)
@@ -135,13 +139,14 @@ struct gklhip_ctx {
   Plan plan;
   std::vector<PlanLane> long_lanes;
   std::vector<FwdJob> long_jobs;
+  std::vector<int64_t> sub_read_off;  // multi-device: this device's read range, offsets rebased to 0
   DevBuf carry;
 };
 
 namespace {
 
 template <typename T>
-int upload_tables(gklhip_ctx* c, const HostTables<T>& h, DevBuf* buf, DevTables<T>* dt) {
+int upload_tables(DevCtx* c, const HostTables<T>& h, DevBuf* buf, DevTables<T>* dt) {
   const size_t n = (size_t)kQuals * 2 + kMmEntries;
   int st = buf->reserve(n * sizeof(T));
   if (st) return st;
@@ -158,11 +163,15 @@ int upload_tables(gklhip_ctx* c, const HostTables<T>& h, DevBuf* buf, DevTables<
 
 size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// Layout of the per-call plan block (identical in pinned staging and on the device).
+// Layout of the per-call plan block (identical in pinned staging and on the device).  A small host-buffer call
+// appends its six input arrays (`batch`: 5 read arrays at `batch_stride`, then the haplotype bases), so that plan
+// and inputs travel in ONE copy.
 struct PlanLayout {
-  size_t lanes, groups, hap_len, hap_pos, hap_orig, hap_sidx, hap_group, stream_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count, total;
+  size_t lanes, groups, hap_len, hap_pos, hap_orig, hap_sidx, hap_group, hap_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count,
+      batch, batch_stride, total;
 };
-PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lanes, size_t n_long_jobs) {
+PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lanes, size_t n_long_jobs, size_t inline_read_bytes,
+                      size_t inline_hap_bytes) {
   PlanLayout l;
   size_t o = 0;
   l.lanes = o; o = align_up(o + p.lanes.size() * sizeof(PlanLane));
@@ -172,13 +181,16 @@ PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lane
   l.hap_orig = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_sidx = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_group = o; o = align_up(o + (size_t)n_haps * 4);
-  l.stream_src = o; o = align_up(o + p.stream_src.size() * 4);
+  l.hap_src = o; o = align_up(o + (size_t)n_haps * 4);
   l.y0_32 = o; o = align_up(o + (size_t)n_haps * 4);
   l.y0_64 = o; o = align_up(o + (size_t)n_haps * 8);
   l.read_off = o; o = align_up(o + (size_t)(n_reads + 1) * 8);
   l.long_lanes = o; o = align_up(o + n_long_lanes * sizeof(PlanLane));
   l.long_jobs = o; o = align_up(o + n_long_jobs * sizeof(FwdJob));
   l.long_count = o; o = align_up(o + 16);
+  l.batch = o;
+  l.batch_stride = align_up(inline_read_bytes);
+  if (inline_read_bytes) o = o + 5 * l.batch_stride + align_up(inline_hap_bytes);
   l.total = o;
   return l;
 }
@@ -212,11 +224,6 @@ void launch_stream(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
   if (fma) hipLaunchKernelGGL((pairhmm_fwd_stream_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
   else     hipLaunchKernelGGL((pairhmm_fwd_stream_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
 }
-template <int RPL>
-void launch_stream2(const FwdArgs<float>& a, int fma, int n_blocks, hipStream_t s) {
-  if (fma) hipLaunchKernelGGL((pairhmm_fwd_stream2_kernel<RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
-  else     hipLaunchKernelGGL((pairhmm_fwd_stream2_kernel<RPL, false>), dim3(n_blocks), dim3(64), 0, s, a);
-}
 template <typename T, int RPL>
 void launch_jobs(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
   if (fma) hipLaunchKernelGGL((pairhmm_fwd_jobs_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
@@ -229,50 +236,61 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
   else     hipLaunchKernelGGL((pairhmm_fwd_long_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a, carry, carry_len);
 }
 
-// Rows per lane.  fp32 main pass: 8 (one chunk per wavefront; 4 = the dual-chunk packed-math
-// kernel, opt-in).  fp64 passes: 6.  A read of length R needs R+1 rows; reads that exceed
+// Rows per lane.  fp32 main pass: 8 (4 for small batches).  fp64 passes: 6.  A read of length R needs R+1 rows; reads that exceed
 // 64*RPL rows go to the striped long-read kernel of the same RPL.
 #ifndef GKL_RPL_F64
 #define GKL_RPL_F64 6
 #endif
 constexpr int kRplF64 = GKL_RPL_F64;
-constexpr int64_t kPeekPairs = 65536;          // host-buffer calls up to this many pairs look at the fallback count before the fp64 stage
-constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size stage their inputs in one block
+constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block
+constexpr int64_t kDirectPairs = 4096;         // calls up to this many pairs: one fp64 job per flagged pair, no packing
+constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the policy + planning kernel (a grid barrier costs ~50 ns per block)
+constexpr int kFallbackWantedJobs = 6144;      // the packed fp64 pass is cut into about this many jobs (2 per wavefront slot)
+constexpr int64_t kOnePassPairs = 65536;      // host-buffer calls up to this many pairs finalise in one pass after the last kernel
 constexpr int kTargetCols = 2048;  // columns of a full-size haplotype group (sweep 1024..4096: flat within 2 %, optimum 1800..2600)
 #ifndef GKL_RPL_F32
 #define GKL_RPL_F32 8
 #endif
 constexpr int kRplF32 = GKL_RPL_F32;
-// fp32 main pass: which kernel.  rows_per_lane of the config: 0 = choose, 8 = the 8-row kernel, 4 = the dual-chunk
-// packed-math kernel (2 x 4 rows), -4 = the single-chunk 4-row kernel.  Choosing: a small batch (one GATK active
-// region) gives the 8-row kernel fewer jobs than the chip has wavefront slots worth filling (< 2 per SIMD), and a
-// lone wavefront issues one instruction per ~6 cycles; 4 rows per lane doubles the chunks and halves the step.
-struct F32Kernel { int rpl; bool dual; };
-F32Kernel pick_f32_kernel(int forced, int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off) {
-  if (forced == 4) return {4, true};
-  if (forced == -4) return {4, false};
-  if (forced == 8) return {kRplF32, false};
-  int64_t blocks = 0;
-  for (int r = 0; r < n_reads; r++) {
-    const int nb = blocks_for((int)(read_off[r + 1] - read_off[r]), kRplF32);
-    if (nb <= kLanes) blocks += nb;
-  }
-  const int64_t chunks = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
+// fp32 main pass: which kernel.  rows_per_lane of the config: 0 = choose, 8 / 4 / 2 = that many rows per lane.
+// Choosing: a small batch (one GATK active region) gives the 8-row kernel fewer jobs than the chip has wavefront
+// slots worth filling (< 2 per SIMD), and a lone wavefront issues one instruction per ~6 cycles; fewer rows per
+// lane mean more chunks and a shorter step (2 rows: reads of up to 127 bases).
+int pick_f32_rpl(int forced, int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off) {
+  int max_len = 0;
+  for (int r = 0; r < n_reads; r++) max_len = std::max(max_len, (int)(read_off[r + 1] - read_off[r]));
+  if (forced == 2 && max_len <= 2 * kLanes - 1) return 2;
+  if (forced == 4 || forced == -4 || forced == 2) return 4;
+  if (forced == 8) return kRplF32;
   const int64_t total_cols = hap_off[n_haps] + n_haps;
-  const int64_t groups = std::min<int64_t>(n_haps, std::max<int64_t>((total_cols + kTargetCols - 1) / kTargetCols,
-                                                                      (4096 + chunks - 1) / chunks));
-  return chunks * groups < 2048 ? F32Kernel{4, false} : F32Kernel{kRplF32, false};
+  auto jobs_at = [&](int rpl) {
+    int64_t blocks = 0;
+    for (int r = 0; r < n_reads; r++) {
+      const int nb = blocks_for((int)(read_off[r + 1] - read_off[r]), rpl);
+      if (nb <= kLanes) blocks += nb;
+    }
+    const int64_t chunks = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
+    const int64_t groups = std::min<int64_t>(n_haps, std::max<int64_t>((total_cols + kTargetCols - 1) / kTargetCols,
+                                                                        (4096 + chunks - 1) / chunks));
+    return chunks * groups;
+  };
+  if (jobs_at(kRplF32) >= 2048) return kRplF32;
+  if (jobs_at(4) >= 1024 || max_len > 2 * kLanes - 1) return 4;
+  return 2;
 }
 
-// The whole device-side pipeline on stream `s`; `db` holds DEVICE byte arrays, host offsets.
-int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int finalize_mode, hipStream_t s) {
+// The whole device-side pipeline on stream `s`: 5 launches in the policy mode (prep, fp32 forward, policy + planning
+// of the fp64 pass, fp64 forward over the job list, log10 of the recomputed pairs; + the log10 of the kept pairs on a
+// side stream in the device finalisation modes), no host synchronisation.  `db` holds host offsets and DEVICE byte
+// arrays -- or, with `inline_host`, HOST byte arrays that travel inside the plan block (small host-buffer calls: one
+// copy for plan and inputs).
+int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_mode, hipStream_t s, bool inline_host) {
   const int n_reads = db->n_reads, n_haps = db->n_haps;
   const int64_t n_pairs = (int64_t)n_reads * n_haps;
   gklhip_stats& st = c->stats;
   memset(&st, 0, sizeof st);
   st.n_pairs = n_pairs;
   c->have_last = false;
-  c->fallback_skipped = false;
   if (n_pairs == 0) return GKLHIP_OK;
   const bool use_double = c->cfg.use_double != 0;
   const int fma = c->cfg.fma_mode != 0;
@@ -281,25 +299,26 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   const auto t_plan0 = std::chrono::steady_clock::now();
   Plan& plan = c->plan;
   const int rpl64 = kRplF64;
-  const F32Kernel f32k = pick_f32_kernel(c->cfg.rows_per_lane, n_reads, n_haps, db->read_off, db->hap_off);
-  const int rpl_main = use_double ? rpl64 : f32k.rpl;
+  const int rpl_main = use_double ? rpl64 : pick_f32_rpl(c->cfg.rows_per_lane, n_reads, n_haps, db->read_off, db->hap_off);
   static const int target_cols_env = [] { const char* v = getenv("GKLHIP_TARGET_COLS"); return v ? atoi(v) : 0; }();
   build_plan(n_reads, n_haps, db->read_off, db->hap_off, rpl_main, target_cols_env > 0 ? target_cols_env : kTargetCols, &plan);
   // Long reads: pseudo-chunks (lane 0 names the read) + one striped job per (read, stream group)
-  // for the main pass; for the fp64 fallback the same pseudo-chunks feed build_jobs_kernel.
+  // for the main pass; for the fp64 fallback the same pseudo-chunks feed the run detection.
   std::vector<PlanLane>& long_lanes = c->long_lanes;
   std::vector<FwdJob>& long_jobs = c->long_jobs;
-  std::vector<int32_t> long64;  // reads too long for the packed fp64 pass
   long_lanes.clear(); long_jobs.clear();
-  for (int r = 0; r < n_reads; r++)
-    if (blocks_for((int)(db->read_off[r + 1] - db->read_off[r]), rpl64) > kLanes) long64.push_back(r);
   const std::vector<int32_t>& long_main = plan.long_reads;
   const int n_long_main = (int)long_main.size();
-  const int n_long64 = use_double ? 0 : (int)long64.size();
   // pseudo-chunk index space: [0, n_long_main) main-pass reads, then [n_long_main, +n_long64) fp64-pass reads
   for (int32_t r : long_main) { long_lanes.resize(long_lanes.size() + kLanes, PlanLane{-1, 0}); long_lanes[long_lanes.size() - kLanes] = PlanLane{r, 0}; }
-  if (!use_double)
-    for (int32_t r : long64) { long_lanes.resize(long_lanes.size() + kLanes, PlanLane{-1, 0}); long_lanes[long_lanes.size() - kLanes] = PlanLane{r, 0}; }
+  int n_long64 = 0;  // reads too long for the packed fp64 pass
+  if (!use_double && plan.max_read_len > kLanes * rpl64 - 1)
+    for (int r = 0; r < n_reads; r++)
+      if (blocks_for((int)(db->read_off[r + 1] - db->read_off[r]), rpl64) > kLanes) {
+        long_lanes.resize(long_lanes.size() + kLanes, PlanLane{-1, 0});
+        long_lanes[long_lanes.size() - kLanes] = PlanLane{r, 0};
+        n_long64++;
+      }
   for (int i = 0; i < n_long_main; i++)
     for (const PlanGroup& g : plan.groups) long_jobs.push_back(FwdJob{i, g.hap_begin, g.hap_end, 0});
   int carry_len = 0;
@@ -308,7 +327,8 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     carry_len = std::max(carry_len, plan.hap_pos[last] + plan.hap_len[last] - plan.hap_pos[g.hap_begin] + 3 * kLanes);
   }
   carry_len = (carry_len + 63) / 64 * 64;
-  const PlanLayout L = layout_for(plan, n_reads, n_haps, long_lanes.size(), long_jobs.size());
+  const size_t rl = (size_t)db->read_off[n_reads], hl = (size_t)db->hap_off[n_haps];
+  const PlanLayout L = layout_for(plan, n_reads, n_haps, long_lanes.size(), long_jobs.size(), inline_host ? rl : 0, inline_host ? hl : 0);
 
   // ---- stage + upload plan ----
   int rc;
@@ -327,7 +347,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   memcpy(hs + L.hap_orig, plan.hap_orig.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_sidx, plan.hap_sidx.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_group, plan.hap_group.data(), (size_t)n_haps * 4);
-  memcpy(hs + L.stream_src, plan.stream_src.data(), plan.stream_src.size() * 4);
+  memcpy(hs + L.hap_src, plan.hap_src.data(), (size_t)n_haps * 4);
   {
     // Y[0][j] = INITIAL_CONSTANT / (NUMBER)haplen, divided on the host (template.h:110,176)
     float* y32 = reinterpret_cast<float*>(hs + L.y0_32);
@@ -347,60 +367,86 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     memcpy(hs + L.long_count, lc, sizeof lc);
   }
   unsigned char* dp = plan_dev.as<unsigned char>();
-  if (L.total >= (256u << 10)) {
+  gklhip_batch dbi = *db;  // device pointers of the six byte arrays
+  if (inline_host) {
+    const uint8_t* srcs[5] = {db->read_bases, db->read_quals, db->ins_gop, db->del_gop, db->gcp};
+    for (int i = 0; i < 5; i++) memcpy(hs + L.batch + i * L.batch_stride, srcs[i], rl);
+    memcpy(hs + L.batch + 5 * L.batch_stride, db->hap_bases, hl);
+    unsigned char* d = dp + L.batch;
+    dbi.read_bases = d; dbi.read_quals = d + L.batch_stride; dbi.ins_gop = d + 2 * L.batch_stride;
+    dbi.del_gop = d + 3 * L.batch_stride; dbi.gcp = d + 4 * L.batch_stride; dbi.hap_bases = d + 5 * L.batch_stride;
+  }
+  // scratch is shared by the calls of a context: one on another stream than the last one waits for that one's end
+  if (c->have_call_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->call_done, 0));
+  // Big plans ride the upload stream (the copy overlaps the previous call's kernels); a small plan (GATK-sized
+  // call) is PULLED from the pinned staging block by the prep kernel itself: no copy-engine hop at all.
+  const bool pull = L.total < (256u << 10);
+  const unsigned char* hs_dev = nullptr;  // the staging block as the device sees it
+  if (pull) {
+    void* p = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&p, hs, 0));
+    hs_dev = static_cast<const unsigned char*>(p);
+    HIP_TRY(hipStreamWaitEvent(s, c->plan_unused_slot[slot], 0));
+  } else {
     HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->plan_unused_slot[slot], 0));  // readers of the old contents are done
     HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, c->upload_stream));
     HIP_TRY(hipEventRecord(c->stage_free_slot[slot], c->upload_stream));
     HIP_TRY(hipStreamWaitEvent(s, c->stage_free_slot[slot], 0));                    // kernels below read the new plan
-  } else {
-    // a small plan (GATK-sized call): the cross-stream hand-off would cost more than the copy
-    HIP_TRY(hipStreamWaitEvent(s, c->plan_unused_slot[slot], 0));
-    HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(c->stage_free_slot[slot], s));
   }
-  if (getenv("GKLHIP_TIMING"))
-    fprintf(stderr, "[gklhip] host plan + staging: %.3f ms (%d chunks, %zu stream entries, %zu plan bytes)\n",
+  static const bool timing = getenv("GKLHIP_TIMING") != nullptr;
+  if (timing)
+    fprintf(stderr, "[gklhip] host plan + staging: %.3f ms (%d chunks, %d stream entries, %zu plan bytes)\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count(),
-            plan.n_chunks, plan.stream_src.size(), L.total);
+            plan.n_chunks, plan.n_stream, L.total);
 
   // ---- scratch ----
   if ((rc = c->raw32.reserve((size_t)n_pairs * 4))) return rc;
   if ((rc = c->raw64.reserve((size_t)n_pairs * 8))) return rc;
   if ((rc = c->used64.reserve((size_t)n_pairs))) return rc;
-  if ((rc = c->list.reserve((size_t)n_pairs * 4))) return rc;
-  if ((rc = c->counters.reserve(64))) return rc;
+  if ((rc = c->counters.reserve(128))) return rc;
   if ((rc = c->read_fail.reserve((size_t)n_reads * 4))) return rc;
-  if ((rc = c->stream_buf.reserve(plan.stream_src.size() * 4))) return rc;
+  if ((rc = c->stream_buf.reserve((size_t)plan.n_stream * 4))) return rc;
   const int n_hist = use_double ? 0 : 2 * (n_haps + 2);
   if (!use_double && (rc = c->fail_hist.reserve((size_t)n_hist * 4))) return rc;
-  const int n_flag_words = (n_haps + 3) / 4;
-  if ((rc = c->hap_flags.reserve((size_t)n_flag_words * 4))) return rc;
-  {
-    const int n_clear = std::max({16, use_double ? 0 : n_reads, n_hist, n_flag_words});
-    hipLaunchKernelGGL(clear_kernel, dim3((unsigned)((n_clear + 255) / 256)), dim3(256), 0, s, c->counters.as<int32_t>(), 16,
-                       c->read_fail.as<int32_t>(), use_double ? 0 : n_reads, c->fail_hist.as<int32_t>(), n_hist,
-                       c->hap_flags.as<int32_t>(), n_flag_words);
-  }
+  if ((rc = c->hap_flags.reserve((size_t)n_haps))) return rc;
 
   const bool ev = c->cfg.record_events != 0;
   const bool deferred = c->cfg.record_events == 2;
   if (ev) {
-    c->ev = c->ev_ring[deferred ? c->calls % gklhip_ctx::kEventRing : 0];
-    c->ring_double[deferred ? c->calls % gklhip_ctx::kEventRing : 0] = use_double;
+    c->ev = c->ev_ring[deferred ? c->calls % DevCtx::kEventRing : 0];
+    c->ring_double[deferred ? c->calls % DevCtx::kEventRing : 0] = use_double;
     c->calls++;
   }
   if (ev) HIP_TRY(hipEventRecord(c->ev[0], s));
 
-  // ---- haplotype streams ----
-  const int n_stream = (int)plan.stream_src.size();
-  hipLaunchKernelGGL(build_stream_kernel, dim3((n_stream + 255) / 256), dim3(256), 0, s,
-                     reinterpret_cast<const int32_t*>(dp + L.stream_src), db->hap_bases,
-                     c->stream_buf.as<uint32_t>(), n_stream, reinterpret_cast<const int32_t*>(dp + L.hap_pos), n_haps,
-                     c->hap_flags.as<uint8_t>());
+  // ---- haplotype streams + clears: one launch ----
+  {
+    PrepArgs pa;
+    const unsigned char* pb = pull ? hs_dev : dp;  // pulling: this kernel reads the HOST copy of the plan
+    pa.hap_bases = (pull && inline_host) ? pb + L.batch + 5 * L.batch_stride : dbi.hap_bases;
+    pa.hap_src = reinterpret_cast<const int32_t*>(pb + L.hap_src);
+    pa.hap_len = reinterpret_cast<const int32_t*>(pb + L.hap_len);
+    pa.hap_pos = reinterpret_cast<const int32_t*>(pb + L.hap_pos);
+    pa.hap_group = reinterpret_cast<const int32_t*>(pb + L.hap_group);
+    pa.stream = c->stream_buf.as<uint32_t>();
+    pa.hap_has_n = c->hap_flags.as<uint8_t>();
+    pa.n_haps = n_haps;
+    pa.clear_a = c->counters.as<int32_t>(); pa.n_a = 32;
+    pa.clear_b = c->read_fail.as<int32_t>(); pa.n_b = use_double ? 0 : n_reads;
+    pa.clear_c = c->fail_hist.as<int32_t>(); pa.n_c = n_hist;
+    const int threads_needed = std::max({n_haps * 64, 32, pa.n_b, pa.n_c});
+    pa.hap_blocks = (threads_needed + kPrepBlock - 1) / kPrepBlock;
+    pa.pull_src = reinterpret_cast<const uint4*>(hs_dev);
+    pa.pull_dst = reinterpret_cast<uint4*>(dp);
+    pa.pull_n16 = pull ? (int32_t)(L.total / 16) : 0;
+    const int pull_blocks = pull ? (int)std::min<size_t>(64, (L.total / 16 + kPrepBlock * 4 - 1) / (kPrepBlock * 4)) : 0;
+    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)(pa.hap_blocks + pull_blocks)), dim3(kPrepBlock), 0, s, pa);
+    if (pull) HIP_TRY(hipEventRecord(c->stage_free_slot[slot], s));
+  }
 
   DevBatch b;
-  b.read_bases = db->read_bases; b.read_quals = db->read_quals; b.ins = db->ins_gop;
-  b.del = db->del_gop; b.gcp = db->gcp;
+  b.read_bases = dbi.read_bases; b.read_quals = dbi.read_quals; b.ins = dbi.ins_gop;
+  b.del = dbi.del_gop; b.gcp = dbi.gcp;
   b.read_off = reinterpret_cast<const int64_t*>(dp + L.read_off);
   b.n_reads = n_reads; b.n_haps = n_haps;
 
@@ -410,7 +456,6 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.hap_len = reinterpret_cast<const int32_t*>(dp + L.hap_len);
     a.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos);
     a.hap_orig = reinterpret_cast<const int32_t*>(dp + L.hap_orig);
-    a.hap_sidx = reinterpret_cast<const int32_t*>(dp + L.hap_sidx);
     a.hap_has_n = c->hap_flags.as<uint8_t>();
     a.groups = reinterpret_cast<const HapGroup*>(dp + L.groups);
     a.n_groups = (int)plan.groups.size();
@@ -423,7 +468,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
 
   FinalizeArgs fa;
   fa.raw32 = c->raw32.as<float>(); fa.raw64 = c->raw64.as<double>(); fa.out = out_dev;
-  fa.used64 = c->used64.as<uint8_t>(); fa.list = c->list.as<int32_t>();
+  fa.used64 = c->used64.as<uint8_t>();
   fa.count = c->counters.as<int32_t>(); fa.n = n_pairs; fa.mode = finalize_mode;
   fa.read_fail = c->read_fail.as<int32_t>(); fa.n_haps = n_haps;
   fa.log10_init_f = host_tables_f32().log10_initial;
@@ -440,10 +485,7 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
   st.n_hap_groups = (int)plan.groups.size();
   st.rows_per_lane = rpl_main;
   st.lane_fill = plan.n_chunks ? (float)((double)plan.useful_rows / ((double)plan.n_chunks * 64 * rpl_main)) : 0.f;
-  {
-    int64_t rl = db->read_off[n_reads], hl = db->hap_off[n_haps];
-    st.cells = rl * hl;
-  }
+  st.cells = (int64_t)rl * (int64_t)hl;
 
   if (ev) HIP_TRY(hipEventRecord(c->ev[1], s));
   if (use_double) {
@@ -462,8 +504,9 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
       launch_long<double, kRplF64>(la, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
+    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
     if (ev) { HIP_TRY(hipEventRecord(c->ev[3], s)); HIP_TRY(hipEventRecord(c->ev[4], s)); }
+    HIP_TRY(hipEventRecord(c->policy_done, s));  // (host path: "results are final from here")
   } else {
     FwdArgs<float> a{};
     fill_common(a);
@@ -471,9 +514,9 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     a.y0 = reinterpret_cast<const float*>(dp + L.y0_32);
     a.raw = c->raw32.as<float>();
     if (n_main_blocks > 0) {
-      if (f32k.dual)          launch_stream2<4>(a, fma, ((plan.n_chunks + 1) / 2) * (int)plan.groups.size(), s);
+      if (rpl_main == 2)      launch_stream<float, 2>(a, fma, n_main_blocks, s);
       else if (rpl_main == 4) launch_stream<float, 4>(a, fma, n_main_blocks, s);
-      else               launch_stream<float, kRplF32>(a, fma, n_main_blocks, s);
+      else                    launch_stream<float, kRplF32>(a, fma, n_main_blocks, s);
     }
     if (n_long_main > 0) {
       FwdArgs<float> la = a;
@@ -481,11 +524,59 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
       la.jobs = reinterpret_cast<const FwdJob*>(dp + L.long_jobs);
       la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
       la.job_next = c->counters.as<int32_t>() + 7;
-      if (rpl_main == 4) launch_long<float, 4>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
+      if (rpl_main <= 4) launch_long<float, 4>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);  // (2 is only chosen without long reads)
       else               launch_long<float, kRplF32>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
-    hipLaunchKernelGGL(policy_kernel, dim3((unsigned)((n_pairs + kPolicyBlock - 1) / kPolicyBlock)), dim3(kPolicyBlock), 0, s, fa);
+
+    // ---- precision policy + device-side planning of the fp64 recomputation (one launch) ----
+    const size_t n_groups = plan.groups.size();
+    (void)n_groups;
+    const size_t jobs_per_chunk = (size_t)n_haps;  // a job holds at least one haplotype and the jobs of a chunk do not overlap
+    const size_t max_jobs = (size_t)n_reads * jobs_per_chunk;
+    // Small calls skip the packing: every flagged pair is its own job (the read alone in a wavefront), emitted by
+    // the policy pass itself; reads of up to 127 bases then run two rows per lane.
+    const bool direct = n_pairs <= kDirectPairs && n_long64 == 0;
+    const bool direct2 = direct && plan.max_read_len <= 2 * kLanes - 1;
+    if ((rc = c->fail_order.reserve((size_t)n_reads * 4))) return rc;
+    if ((rc = c->lanes2.reserve((size_t)n_reads * kLanes * sizeof(LaneSlot)))) return rc;
+    if ((rc = c->jobs.reserve(2 * max_jobs * sizeof(FwdJob)))) return rc;  // as built + sorted by length
+    if (n_long64 > 0 && (rc = c->jobs_long.reserve((size_t)n_long64 * jobs_per_chunk * sizeof(FwdJob)))) return rc;
+    int32_t* cnts = c->counters.as<int32_t>();
+    const LaneSlot* pl = reinterpret_cast<const LaneSlot*>(dp + L.long_lanes);
+    {
+      PlanArgs pa;
+      pa.fa = fa;
+      pa.n_reads = n_reads; pa.n_haps = n_haps; pa.n_pairs_i = (int32_t)n_pairs;
+      pa.read_off = b.read_off;
+      pa.rpl = rpl64; pa.max_len = kLanes * rpl64 - 1;
+      pa.cnts = cnts;
+      pa.hist = c->fail_hist.as<int32_t>();
+      pa.pos = pa.hist + (n_haps + 2);
+      pa.order = c->fail_order.as<int32_t>();
+      pa.lanes2 = c->lanes2.as<LaneSlot>();
+      pa.hap_orig = reinterpret_cast<const int32_t*>(dp + L.hap_orig);
+      pa.hap_group = reinterpret_cast<const int32_t*>(dp + L.hap_group);
+      pa.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos);
+      pa.hap_len = reinterpret_cast<const int32_t*>(dp + L.hap_len);
+      pa.jobs = c->jobs.as<FwdJob>();
+      pa.sorted = c->jobs.as<FwdJob>() + max_jobs;
+      pa.long_lanes = pl + (size_t)n_long_main * kLanes;
+      pa.n_long = n_long64;
+      pa.jobs_long = c->jobs_long.as<FwdJob>();
+      pa.direct = direct ? 1 : 0;
+      pa.hap_sidx = reinterpret_cast<const int32_t*>(dp + L.hap_sidx);
+      pa.total_cols = (int32_t)std::min<int64_t>((int64_t)hl + n_haps, 0x7fffffff);
+      static const int wanted_env = [] { const char* v = getenv("GKLHIP_FB_WANTED_JOBS"); return v ? atoi(v) : 0; }();
+      pa.wanted_jobs = wanted_env > 0 ? wanted_env : kFallbackWantedJobs;
+      pa.min_job_cols = 256;
+      // every block must be resident at once (grid barriers): at most one per CU
+      // (direct mode: by pairs; else one block per CU -- the run detection is one block per chunk)
+      static const int blocks_env = [] { const char* v = getenv("GKLHIP_PLAN_BLOCKS"); return v ? atoi(v) : 0; }();
+      const int grid = direct ? (int)std::max<int64_t>(1, (n_pairs + kPlanBlock * 4 - 1) / (kPlanBlock * 4))
+                              : std::max(1, std::min(c->n_cus, blocks_env > 0 ? blocks_env : kPlanBlocks));
+      hipLaunchKernelGGL(policy_plan_kernel, dim3((unsigned)grid), dim3(kPlanBlock), 0, s, pa);
+    }
     HIP_TRY(hipEventRecord(c->policy_done, s));
     const bool side_finalize = finalize_mode == GKLHIP_FINALIZE_DEVICE_F64 || finalize_mode == GKLHIP_FINALIZE_DEVICE_REF32;
     if (side_finalize) {
@@ -493,64 +584,22 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
       hipLaunchKernelGGL(finalize32_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, c->copy_stream, fa);
       HIP_TRY(hipEventRecord(c->early_copy_done, c->copy_stream));
     }
-    if (c->peek_after_policy) {
-      if ((rc = c->peek_count.reserve(64))) return rc;
-      HIP_TRY(hipMemcpyAsync(c->res_pin.p, out_dev, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(c->peek_count.p, c->counters.p, 4, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      if (*c->peek_count.as<int32_t>() == 0) {
-        c->fallback_skipped = true;
-        if (ev) { HIP_TRY(hipEventRecord(c->ev[3], s)); HIP_TRY(hipEventRecord(c->ev[4], s)); }
-      }
-    }
-    if (!c->fallback_skipped) {
-    // ---- fp64 recomputation of the underflowed pairs ----
+    // ---- fp64 recomputation of the underflowed pairs: persistent wavefronts stream the job list -- same WaveJob
+    // template as the main pass, T = double (no jobs: the kernel's wavefronts leave at once) ----
     FwdArgs<double> d{};
     fill_common(d);
     d.tab = c->dt64;
     d.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
     d.raw = c->raw64.as<double>();
-    if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
-    // Plan the pass on the device (no host round trip): order affected reads by fallback count,
-    // pack them into chunks, queue one job per (chunk, needed haplotype run), then let persistent
-    // wavefronts stream those jobs -- same WaveJob template as the main pass, T = double.
-    const size_t n_groups = plan.groups.size();
-    if ((rc = c->fail_order.reserve((size_t)n_reads * 4))) return rc;
-    if ((rc = c->lanes2.reserve((size_t)n_reads * kLanes * sizeof(LaneSlot)))) return rc;
-    const size_t max_jobs = (size_t)n_reads * ((size_t)(n_haps + 1) / 2 + n_groups);
-    if ((rc = c->jobs.reserve(2 * max_jobs * sizeof(FwdJob)))) return rc;  // as built + sorted by length
-    int32_t* hist = c->fail_hist.as<int32_t>();
-    int32_t* pos = hist + (n_haps + 2);
-    int32_t* cnts = c->counters.as<int32_t>();  // [0] pairs [2] jobs [3] next job [4] fail reads [5] chunks
-    const unsigned rb = (unsigned)((n_reads + 255) / 256);
-    hipLaunchKernelGGL(fail_hist_kernel, dim3(rb), dim3(256), 0, s, c->read_fail.as<int32_t>(), n_reads, hist,
-                       b.read_off, kLanes * rpl64 - 1);
-    hipLaunchKernelGGL(fail_scan_kernel, dim3(1), dim3(64), 0, s, hist, n_haps, pos, cnts + 4);
-    hipLaunchKernelGGL(fail_scatter_kernel, dim3(rb), dim3(256), 0, s, c->read_fail.as<int32_t>(), n_reads, pos,
-                       c->fail_order.as<int32_t>(), b.read_off, kLanes * rpl64 - 1);
-    hipLaunchKernelGGL(pack_windows_kernel, dim3((unsigned)((n_reads + kPackWindow - 1) / kPackWindow)), dim3(64), 0, s,
-                       c->fail_order.as<int32_t>(), cnts + 4, b.read_off, rpl64, c->lanes2.as<LaneSlot>(), cnts + 5);
-    const int jb_threads = n_haps <= 64 ? 64 : n_haps <= 128 ? 128 : 256;
-    hipLaunchKernelGGL(build_jobs_kernel, dim3((unsigned)std::min(n_reads, 2048)), dim3(jb_threads),
-                       (size_t)(kLanes + 1) * 4 + (size_t)n_haps, s, c->lanes2.as<LaneSlot>(), cnts + 5,
-                       c->used64.as<uint8_t>(), n_haps, reinterpret_cast<const int32_t*>(dp + L.hap_orig),
-                       reinterpret_cast<const int32_t*>(dp + L.hap_group), c->jobs.as<FwdJob>(), cnts + 2);
-    hipLaunchKernelGGL(sort_jobs_kernel, dim3(1), dim3(1024), 0, s, c->jobs.as<FwdJob>(), cnts + 2,
-                       reinterpret_cast<const int32_t*>(dp + L.hap_pos), reinterpret_cast<const int32_t*>(dp + L.hap_len),
-                       c->jobs.as<FwdJob>() + max_jobs);
     d.chunk_lanes = c->lanes2.as<LaneSlot>();
     d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
     d.jobs = c->jobs.as<FwdJob>() + max_jobs;
-    launch_jobs<double, kRplF64>(d, fma, (int)std::min<int64_t>(n_pairs, 256 * 16), s);
+    if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
+    if (direct2)                                          launch_jobs<double, 2>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
+    else if (direct && plan.max_read_len <= 4 * kLanes - 1) launch_jobs<double, 4>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
+    else         launch_jobs<double, kRplF64>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
     if (n_long64 > 0) {
       // reads too long for a chunk: one pseudo-chunk each, same run detection, striped kernel
-      if ((rc = c->jobs_long.reserve((size_t)n_long64 * ((size_t)(n_haps + 1) / 2 + n_groups) * sizeof(FwdJob)))) return rc;
-      const LaneSlot* pl = reinterpret_cast<const LaneSlot*>(dp + L.long_lanes);
-      hipLaunchKernelGGL(build_jobs_kernel, dim3((unsigned)n_long64), dim3(jb_threads),
-                         (size_t)(kLanes + 1) * 4 + (size_t)n_haps, s, pl + (size_t)n_long_main * kLanes,
-                         reinterpret_cast<const int32_t*>(dp + L.long_count) + 2, c->used64.as<uint8_t>(), n_haps,
-                         reinterpret_cast<const int32_t*>(dp + L.hap_orig),
-                         reinterpret_cast<const int32_t*>(dp + L.hap_group), c->jobs_long.as<FwdJob>(), cnts + 8);
       FwdArgs<double> ld = d;
       ld.chunk_lanes = pl + (size_t)n_long_main * kLanes;
       ld.jobs = c->jobs_long.as<FwdJob>();
@@ -559,14 +608,15 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
       launch_long<double, kRplF64>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
-    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
-    }  // !fallback_skipped
+    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
     if (side_finalize) HIP_TRY(hipStreamWaitEvent(s, c->early_copy_done, 0));  // join the side stream
   }
   if (ev) HIP_TRY(hipEventRecord(c->ev[5], s));
   HIP_TRY(hipGetLastError());
 
   HIP_TRY(hipEventRecord(c->plan_unused_slot[slot], s));
+  HIP_TRY(hipEventRecord(c->call_done, s));
+  c->have_call_done = true;
   c->last_pairs = n_pairs;
   c->last_stream = s;
   c->have_last = true;
@@ -581,8 +631,490 @@ int run_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int final
     HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     st.n_fallback = use_double ? n_pairs : cnt[0];
+    if (timing && !use_double) {
+      int32_t k[32];
+      HIP_TRY(hipMemcpy(k, c->counters.p, sizeof k, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[gklhip] policy+plan phases after the policy (us): hist %.1f scan %.1f scatter %.1f pack %.1f jobs %.1f sort %.1f | "
+              "%d affected reads, %d chunks, %d jobs\n", k[16] * 0.01, k[17] * 0.01, k[18] * 0.01, k[19] * 0.01, k[20] * 0.01, k[21] * 0.01,
+              k[4], k[5], k[2]);
+    }
   } else {
     st.n_fallback = use_double ? n_pairs : -1;  // unknown without a sync; gklhip_get_raw fills it in
+  }
+  return GKLHIP_OK;
+}
+
+// ------------------------------------------------------------------ one device: lifecycle + host-buffer call
+void dev_done(DevCtx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->last_stream && c->have_last) (void)hipStreamSynchronize(c->last_stream);
+  for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev_slot[0], &c->plan_dev_slot[1], &c->raw32, &c->raw64, &c->used64,
+                    &c->counters, &c->stream_buf, &c->out_dev, &c->batch_dev, &c->read_fail,
+                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->res_dev, &c->hap_flags})
+    b->release();
+  c->stage_slot[0].release();
+  c->stage_slot[1].release();
+  c->res_pin.release();
+  c->res_pin2.release();
+  if (c->policy_done) (void)hipEventDestroy(c->policy_done);
+  if (c->early_copy_done) (void)hipEventDestroy(c->early_copy_done);
+  if (c->call_done) (void)hipEventDestroy(c->call_done);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  for (auto& set : c->ev_ring)
+    for (auto& e : set) if (e) (void)hipEventDestroy(e);
+  for (int k = 0; k < 2; k++) {
+    if (c->stage_free_slot[k]) (void)hipEventDestroy(c->stage_free_slot[k]);
+    if (c->plan_unused_slot[k]) (void)hipEventDestroy(c->plan_unused_slot[k]);
+  }
+  if (c->upload_stream) { (void)hipStreamSynchronize(c->upload_stream); (void)hipStreamDestroy(c->upload_stream); }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
+  *out = nullptr;
+  if (dev < 0 || dev >= ndev) return fail(GKLHIP_ERR_INVALID_ARG, "device %d of %d", dev, ndev);
+  HIP_TRY(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(GKLHIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
+  DevCtx* c = new (std::nothrow) DevCtx();
+  if (!c) return fail(GKLHIP_ERR_OOM, "context allocation failed");
+  c->cfg = cfg;
+  c->device = dev;
+  c->n_cus = std::max(1, prop.multiProcessorCount);
+  memset(&c->stats, 0, sizeof c->stats);
+  int rc = GKLHIP_OK;
+  auto bail = [&](int status) { dev_done(c); return status; };
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  for (int k = 0; k < 2; k++)
+    if (hipEventCreateWithFlags(&c->stage_free_slot[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->plan_unused_slot[k], hipEventDisableTiming) != hipSuccess)
+      return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  if (hipEventCreateWithFlags(&c->policy_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->early_copy_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->call_done, hipEventDisableTiming) != hipSuccess)
+    return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  for (int k = 0; k < 2; k++)
+    if (hipEventRecord(c->stage_free_slot[k], c->stream) != hipSuccess || hipEventRecord(c->plan_unused_slot[k], c->stream) != hipSuccess)
+      return bail(fail(GKLHIP_ERR_HIP, "hipEventRecord failed"));
+  {
+    const int sets = c->cfg.record_events == 2 ? DevCtx::kEventRing : 1;
+    for (int k = 0; k < sets; k++)
+      for (auto& e : c->ev_ring[k])
+        if (hipEventCreate(&e) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  }
+  if ((rc = upload_tables(c, host_tables_f32(), &c->tab32, &c->dt32))) return bail(rc);
+  if ((rc = upload_tables(c, host_tables_f64(), &c->tab64, &c->dt64))) return bail(rc);
+  *out = c;
+  return GKLHIP_OK;
+}
+
+// Host threads of the reference-exact finalisation.  maxNumberOfThreads caps the OpenMP compute threads of the
+// reference (IntelPairHmm.cc:72-89); here the compute is on the device and the only host work is log10f/log10 over
+// the results, so the value 1 (GATK's and the non-OpenMP build's default) means "not set": min(cores, 8) threads,
+// overridable with GKL_HIP_FINALIZE_THREADS.  Values > 1 are honoured as given.
+int finalize_threads(const DevCtx* c) {
+  static const int env = [] { const char* v = getenv("GKL_HIP_FINALIZE_THREADS"); return v ? atoi(v) : 0; }();
+  if (env > 0) return env;
+  const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+  int threads = c->cfg.max_threads;
+  if (threads <= 1) threads = std::min(hw, 8);
+  return std::max(1, std::min(threads, 64));
+}
+
+int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
+  const int64_t n_pairs = (int64_t)hb->n_reads * hb->n_haps;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  int rc;
+  const size_t rl = (size_t)hb->read_off[hb->n_reads], hl = (size_t)hb->hap_off[hb->n_haps];
+  const size_t stride = align_up(rl);
+  const size_t all_bytes = 5 * stride + align_up(hl);
+  // a GATK-sized call: the six arrays travel inside the plan block (ONE copy launch for plan + inputs)
+  const bool inline_inputs = all_bytes <= kSmallBatchBytes;
+  gklhip_batch db = *hb;
+  if (!inline_inputs) {
+    // H2D of the six byte arrays (one allocation, 256-byte aligned sub-buffers)
+    if ((rc = c->batch_dev.reserve(all_bytes))) return rc;
+    unsigned char* d = c->batch_dev.as<unsigned char>();
+    if (c->have_call_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->call_done, 0));
+    const uint8_t* srcs[5] = {hb->read_bases, hb->read_quals, hb->ins_gop, hb->del_gop, hb->gcp};
+    for (int i = 0; i < 5; i++) HIP_TRY(hipMemcpyAsync(d + i * stride, srcs[i], rl, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + 5 * stride, hb->hap_bases, hl, hipMemcpyHostToDevice, s));
+    db.read_bases = d; db.read_quals = d + stride; db.ins_gop = d + 2 * stride;
+    db.del_gop = d + 3 * stride; db.gcp = d + 4 * stride; db.hap_bases = d + 5 * stride;
+  }
+  const int mode = c->cfg.finalize;
+  const bool on_device = (mode == GKLHIP_FINALIZE_DEVICE_F64 || mode == GKLHIP_FINALIZE_DEVICE_REF32);
+  // Small calls: the kernels store their results straight into pinned host memory (posted writes over PCIe,
+  // 8 bytes per pair) -- a copy-engine transfer behind the last kernel costs ~15 us of queue hand-offs.
+  const bool direct_out = n_pairs <= kOnePassPairs;
+  double* pin_out = nullptr;
+  if (direct_out) {
+    if ((rc = c->res_pin.reserve((size_t)n_pairs * 8))) return rc;
+    void* p = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&p, c->res_pin.p, 0));
+    pin_out = static_cast<double*>(p);
+  }
+  if (on_device) {
+    if (direct_out) {
+      if ((rc = run_device(c, &db, pin_out, mode, s, inline_inputs))) return rc;
+      HIP_TRY(hipStreamSynchronize(s));
+      memcpy(out_host, c->res_pin.p, (size_t)n_pairs * 8);
+      return GKLHIP_OK;
+    }
+    if ((rc = c->out_dev.reserve((size_t)n_pairs * 8))) return rc;
+    if ((rc = run_device(c, &db, c->out_dev.as<double>(), mode, s, inline_inputs))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, c->out_dev.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return GKLHIP_OK;
+  }
+  // reference-exact finalisation on the host: one packed 8-byte word per pair comes back through pinned
+  // memory.  The fp32 results are final as soon as the policy has run, so in a big call they are copied out
+  // on a second stream and finalised by the host WHILE the fp64 recomputation pass runs; only the recomputed
+  // pairs are left for after the last kernel.
+  const int threads = finalize_threads(c);
+  const size_t bytes = (size_t)n_pairs * 8;
+  HostFinalizer fin;
+  if (direct_out) {
+    // a GATK-sized call (the fp64 stage of a region without underflowed pairs -- the usual case -- is two launches
+    // that find nothing to do): one pass over the words once the last kernel is done
+    if ((rc = run_device(c, &db, pin_out, kModePacked, s, inline_inputs))) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+    return GKLHIP_OK;
+  }
+  if ((rc = c->res_dev.reserve(bytes))) return rc;
+  if ((rc = c->res_pin.reserve(bytes))) return rc;
+  if (c->cfg.use_double) {
+    // all-fp64 mode: one D2H, one pass over the words
+    if ((rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s, inline_inputs))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+    return GKLHIP_OK;
+  }
+  if ((rc = c->res_pin2.reserve(bytes))) return rc;
+  if ((rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s, inline_inputs))) return rc;  // records policy_done
+  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->policy_done, 0));
+  HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+  HIP_TRY(hipEventRecord(c->early_copy_done, c->copy_stream));
+  HIP_TRY(hipMemcpyAsync(c->res_pin2.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));  // after the last kernel
+  HIP_TRY(hipEventSynchronize(c->early_copy_done));
+  fin.early(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+  HIP_TRY(hipStreamSynchronize(s));
+  c->stats.n_fallback = fin.late(&c->workers, c->res_pin2.as<uint64_t>(), out_host, threads);
+  return GKLHIP_OK;
+}
+
+// Host buffers in, host doubles out on one device.  An error return must not leave copies from the caller's
+// arrays (or into them) in flight: drain the streams first.
+int dev_compute_host(DevCtx* c, const gklhip_batch* hb, double* out_host) {
+  const int rc = dev_compute_host_impl(c, hb, out_host);
+  if (rc != GKLHIP_OK) {
+    const std::string keep = g_err;
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamSynchronize(c->upload_stream);
+    (void)hipGetLastError();
+    g_err = keep;
+  }
+  return rc;
+}
+
+// ------------------------------------------------------------------ several devices behind one context
+// One host thread per extra device: plans and enqueues that device's shard while the caller's thread does
+// device 0's.
+class DevWorker {
+ public:
+  DevWorker() : th_([this] { loop(); }) {}
+  ~DevWorker() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  void submit(std::function<int()> f) {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      task_ = std::move(f);
+      pending_ = true;
+      done_ = false;
+    }
+    cv_.notify_all();
+  }
+  int wait(std::string* err) {
+    std::unique_lock<std::mutex> l(mu_);
+    done_cv_.wait(l, [&] { return done_; });
+    if (rc_ != GKLHIP_OK && err) *err = err_;
+    return rc_;
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> l(mu_);
+    for (;;) {
+      cv_.wait(l, [&] { return quit_ || pending_; });
+      if (quit_) return;
+      pending_ = false;
+      std::function<int()> f = std::move(task_);
+      l.unlock();
+      const int rc = f();
+      const std::string e = g_err;  // the detail message is thread-local: carry it to the caller
+      l.lock();
+      rc_ = rc;
+      err_ = e;
+      done_ = true;
+      done_cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::function<int()> task_;
+  bool pending_ = false, done_ = true, quit_ = false;
+  int rc_ = GKLHIP_OK;
+  std::string err_;
+  std::thread th_;  // last member: the thread starts with everything above constructed
+};
+
+// RCCL, loaded on first use (a single-device context never touches it): the gather of the shards' results on
+// device 0 over xGMI, one ncclSend/ncclRecv pair per extra device inside ONE group, driven by this one process
+// (ncclCommInitAll) -- SURVEY 5.8 / 8(e).
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load() {
+    if (h) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) return false;
+    auto sym = [&](const char* n) { return dlsym(h, n); };
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
+      dlclose(h);
+      h = nullptr;
+      return false;
+    }
+    return true;
+  }
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+#define NCCL_TRY(expr)                                                                              \
+  do {                                                                                              \
+    ncclResult_t r__ = (expr);                                                                      \
+    if (r__ != ncclSuccess) return fail(GKLHIP_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r__)); \
+  } while (0)
+
+}  // namespace
+
+struct gklhip_ctx {
+  std::mutex mu;
+  gklhip_config cfg;
+  std::vector<DevCtx*> dev;                          // dev[0]: where the device-resident entry point gathers
+  std::vector<std::unique_ptr<DevWorker>> workers;   // workers[d-1] drives dev[d]
+  std::vector<int32_t> bounds;                       // read-range boundaries of the last call, [n_dev + 1]
+  std::vector<std::vector<int64_t>> sub_off;         // per device: its read range's offsets rebased to 0
+  bool use_rccl = false;
+  std::vector<ncclComm_t> comms;
+  hipEvent_t inputs_ready = nullptr;                 // device 0: the caller's stream has reached this call
+  std::vector<hipEvent_t> shard_done;                // [n_dev]: device d's results have landed on device 0
+  gklhip_stats stats;
+  int32_t last_reads = 0, last_haps = 0;
+  ~gklhip_ctx() {
+    workers.clear();  // joins the threads
+    for (size_t d = 0; d < comms.size(); d++)
+      if (comms[d]) { (void)hipSetDevice(dev[d]->device); (void)g_rccl.CommDestroy(comms[d]); }
+    for (size_t d = 0; d < shard_done.size(); d++)
+      if (shard_done[d]) { (void)hipSetDevice(dev[d]->device); (void)hipEventDestroy(shard_done[d]); }
+    if (inputs_ready) { (void)hipSetDevice(dev[0]->device); (void)hipEventDestroy(inputs_ready); }
+    for (DevCtx* d : dev) dev_done(d);
+  }
+};
+
+namespace {
+
+// Contiguous read ranges balanced by cells: a read's work is its length (every shard sees all haplotypes).  Same
+// rule as gkl_amd/shard.py:partition_reads (the cut point closest to p/n of the total, the lower one on a tie).
+void partition_reads(int n_reads, const int64_t* read_off, int n_parts, int32_t* bounds) {
+  const int64_t total = read_off[n_reads];
+  bounds[0] = 0;
+  for (int p = 1; p < n_parts; p++) {
+    const double target = (double)total * p / n_parts;
+    int i = (int)(std::lower_bound(read_off, read_off + n_reads + 1, target, [](int64_t v, double t) { return (double)v < t; }) - read_off);
+    if (i > 0 && (i > n_reads || std::fabs((double)read_off[i - 1] - target) <= std::fabs((double)read_off[std::min(i, n_reads)] - target))) i--;
+    bounds[p] = std::min(std::max(i, bounds[p - 1]), n_reads);
+  }
+  bounds[n_parts] = n_reads;
+}
+
+// Shard d of `b` (contiguous read range, every haplotype): pointers into the same arrays, offsets rebased.
+gklhip_batch shard_view(gklhip_ctx* c, const gklhip_batch* b, int d) {
+  const int r0 = c->bounds[d], r1 = c->bounds[d + 1];
+  std::vector<int64_t>& off = c->sub_off[(size_t)d];
+  off.resize((size_t)(r1 - r0) + 1);
+  const int64_t base = b->read_off[r0];
+  for (int r = r0; r <= r1; r++) off[(size_t)(r - r0)] = b->read_off[r] - base;
+  gklhip_batch v = *b;
+  v.n_reads = r1 - r0;
+  v.read_off = off.data();
+  v.read_bases += base; v.read_quals += base; v.ins_gop += base; v.del_gop += base; v.gcp += base;
+  return v;
+}
+
+void merge_stats(gklhip_ctx* c) {
+  gklhip_stats t;
+  memset(&t, 0, sizeof t);
+  bool unknown = false;
+  for (size_t d = 0; d < c->dev.size(); d++) {
+    if (c->bounds[d + 1] == c->bounds[d]) continue;
+    const gklhip_stats& s = c->dev[d]->stats;
+    t.n_pairs += s.n_pairs; t.cells += s.cells; t.cells_fp64 += s.cells_fp64;
+    if (s.n_fallback < 0) unknown = true; else t.n_fallback += s.n_fallback;
+    t.n_chunks += s.n_chunks; t.n_long_pairs += s.n_long_pairs;
+    t.n_hap_groups = std::max(t.n_hap_groups, s.n_hap_groups);
+    t.rows_per_lane = std::max(t.rows_per_lane, s.rows_per_lane);
+    t.ms_fwd_main = std::max(t.ms_fwd_main, s.ms_fwd_main);
+    t.ms_fwd_fallback = std::max(t.ms_fwd_fallback, s.ms_fwd_fallback);
+    t.ms_total_device = std::max(t.ms_total_device, s.ms_total_device);
+    t.lane_fill += s.lane_fill * (float)s.n_chunks;
+  }
+  if (t.n_chunks) t.lane_fill /= (float)t.n_chunks;
+  if (unknown) t.n_fallback = -1;
+  c->stats = t;
+}
+
+// Run fn(d) for every device with a non-empty shard: device 0 on this thread, the others on their workers.
+template <typename F>
+int for_each_shard(gklhip_ctx* c, F fn) {
+  const int n = (int)c->dev.size();
+  for (int d = 1; d < n; d++)
+    if (c->bounds[d + 1] > c->bounds[d]) c->workers[(size_t)d - 1]->submit([=] { return fn(d); });
+  int rc = c->bounds[1] > c->bounds[0] ? fn(0) : GKLHIP_OK;
+  const std::string err0 = g_err;
+  for (int d = 1; d < n; d++)
+    if (c->bounds[d + 1] > c->bounds[d]) {
+      std::string e;
+      const int r = c->workers[(size_t)d - 1]->wait(&e);
+      if (r != GKLHIP_OK && rc == GKLHIP_OK) { rc = r; g_err = e; }
+    }
+  if (rc != GKLHIP_OK && !err0.empty() && g_err.empty()) g_err = err0;
+  return rc;
+}
+
+int multi_compute_host(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
+  const int n = (int)c->dev.size();
+  c->bounds.assign((size_t)n + 1, 0);
+  partition_reads(hb->n_reads, hb->read_off, n, c->bounds.data());
+  // every device copies its own read range straight from the caller's arrays (its own PCIe link) and its
+  // results straight back: the host path needs no device-to-device step at all
+  const int rc = for_each_shard(c, [=](int d) {
+    const gklhip_batch v = shard_view(c, hb, d);
+    return dev_compute_host(c->dev[(size_t)d], &v, out_host + (int64_t)c->bounds[(size_t)d] * hb->n_haps);
+  });
+  merge_stats(c);
+  return rc;
+}
+
+// Device-resident call on several devices: inputs and `out_dev` live on device 0.  Device d > 0 pulls its read
+// range and the haplotypes over xGMI (peer copies on its own stream), computes, and its results are gathered into
+// out_dev: RCCL send/recv in one group (distinct devices) or a peer copy.  Nothing synchronises with the host;
+// the caller's stream `s` ends up waiting for every shard.
+int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int mode, hipStream_t s) {
+  const int n = (int)c->dev.size();
+  c->bounds.assign((size_t)n + 1, 0);
+  partition_reads(db->n_reads, db->read_off, n, c->bounds.data());
+  DevCtx* root = c->dev[0];
+  HIP_TRY(hipSetDevice(root->device));
+  HIP_TRY(hipEventRecord(c->inputs_ready, s));
+  const int n_haps = db->n_haps;
+  const size_t hl = (size_t)db->hap_off[n_haps];
+  int rc = for_each_shard(c, [=](int d) -> int {
+    DevCtx* dc = c->dev[(size_t)d];
+    const gklhip_batch v = shard_view(c, db, d);
+    if (d == 0) return run_device(dc, &v, out_dev, mode, s, false);
+    HIP_TRY(hipSetDevice(dc->device));
+    hipStream_t sd = dc->stream;
+    const size_t rl = (size_t)v.read_off[v.n_reads], stride = align_up(rl);
+    int r;
+    if ((r = dc->batch_dev.reserve(5 * stride + align_up(hl)))) return r;
+    if ((r = dc->out_dev.reserve((size_t)v.n_reads * n_haps * 8))) return r;
+    unsigned char* dst = dc->batch_dev.as<unsigned char>();
+    HIP_TRY(hipStreamWaitEvent(sd, c->inputs_ready, 0));
+    const uint8_t* srcs[5] = {v.read_bases, v.read_quals, v.ins_gop, v.del_gop, v.gcp};
+    for (int i = 0; i < 5; i++)
+      HIP_TRY(hipMemcpyPeerAsync(dst + i * stride, dc->device, srcs[i], root->device, rl, sd));
+    HIP_TRY(hipMemcpyPeerAsync(dst + 5 * stride, dc->device, v.hap_bases, root->device, hl, sd));
+    gklhip_batch lv = v;
+    lv.read_bases = dst; lv.read_quals = dst + stride; lv.ins_gop = dst + 2 * stride;
+    lv.del_gop = dst + 3 * stride; lv.gcp = dst + 4 * stride; lv.hap_bases = dst + 5 * stride;
+    if ((r = run_device(dc, &lv, dc->out_dev.as<double>(), mode, sd, false))) return r;
+    if (!c->use_rccl) {
+      HIP_TRY(hipMemcpyPeerAsync(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, root->device, dc->out_dev.p, dc->device,
+                                 (size_t)v.n_reads * n_haps * 8, sd));
+      HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], sd));
+    }
+    return GKLHIP_OK;
+  });
+  if (rc == GKLHIP_OK && c->use_rccl) {
+    // the one exchange step: every extra device sends its slice, device 0 receives them, all in one group
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int d = 1; d < n; d++) {
+      const size_t cnt = (size_t)(c->bounds[(size_t)d + 1] - c->bounds[(size_t)d]) * n_haps;
+      if (!cnt) continue;
+      NCCL_TRY(g_rccl.Send(c->dev[(size_t)d]->out_dev.p, cnt, ncclDouble, 0, c->comms[(size_t)d], c->dev[(size_t)d]->stream));
+      NCCL_TRY(g_rccl.Recv(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, cnt, ncclDouble, d, c->comms[0], s));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    for (int d = 1; d < n; d++)
+      if (c->bounds[(size_t)d + 1] > c->bounds[(size_t)d]) {
+        HIP_TRY(hipSetDevice(c->dev[(size_t)d]->device));
+        HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], c->dev[(size_t)d]->stream));
+      }
+  }
+  HIP_TRY(hipSetDevice(root->device));
+  if (rc == GKLHIP_OK)
+    for (int d = 1; d < n; d++)
+      if (c->bounds[(size_t)d + 1] > c->bounds[(size_t)d]) HIP_TRY(hipStreamWaitEvent(s, c->shard_done[(size_t)d], 0));
+  merge_stats(c);
+  return rc;
+}
+
+int parse_device_list(const char* v, std::vector<int32_t>* out) {
+  out->clear();
+  if (!v) return GKLHIP_OK;
+  const char* p = v;
+  while (*p) {
+    while (*p == ' ' || *p == ',') p++;
+    if (!*p) break;
+    char* end = nullptr;
+    const long d = strtol(p, &end, 10);
+    if (end == p || d < 0 || d > 1023) return fail(GKLHIP_ERR_INVALID_ARG, "GKL_HIP_DEVICES: cannot parse \"%s\"", v);
+    out->push_back((int32_t)d);
+    p = end;
   }
   return GKLHIP_OK;
 }
@@ -614,7 +1146,7 @@ int gklhip_device_count(void) {
   return n;
 }
 
-int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
+int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_t n_devices, gklhip_ctx** out_ctx) {
   if (!out_ctx) return fail(GKLHIP_ERR_INVALID_ARG, "out_ctx is NULL");
   *out_ctx = nullptr;
   gklhip_config c0;
@@ -630,72 +1162,94 @@ int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
     (void)hipGetLastError();
     return fail(GKLHIP_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU compute path)");
   }
-  int dev = c0.device;
-  if (dev < 0) { HIP_TRY(hipGetDevice(&dev)); }
-  if (dev >= ndev) return fail(GKLHIP_ERR_INVALID_ARG, "device %d of %d", dev, ndev);
-  HIP_TRY(hipSetDevice(dev));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, dev));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(GKLHIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
-  gklhip_ctx* c = new (std::nothrow) gklhip_ctx();
+  std::vector<int32_t> list;
+  if (devices && n_devices > 0) list.assign(devices, devices + n_devices);
+  if (list.empty()) {
+    int dev = c0.device;
+    if (dev < 0) { HIP_TRY(hipGetDevice(&dev)); }
+    list.push_back(dev);
+  }
+  if (list.size() > 64) return fail(GKLHIP_ERR_INVALID_ARG, "%zu devices in the list (at most 64)", list.size());
+  std::unique_ptr<gklhip_ctx> c(new (std::nothrow) gklhip_ctx());
   if (!c) return fail(GKLHIP_ERR_OOM, "context allocation failed");
   c->cfg = c0;
-  c->device = dev;
   memset(&c->stats, 0, sizeof c->stats);
-  int rc = GKLHIP_OK;
-  auto bail = [&](int status) { gklhip_done(c); return status; };
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
-  if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
-  for (int k = 0; k < 2; k++)
-    if (hipEventCreateWithFlags(&c->stage_free_slot[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->plan_unused_slot[k], hipEventDisableTiming) != hipSuccess)
-      return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
-  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
-  if (hipEventCreateWithFlags(&c->policy_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->early_copy_done, hipEventDisableTiming) != hipSuccess)
-    return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
-  for (int k = 0; k < 2; k++)
-    if (hipEventRecord(c->stage_free_slot[k], c->stream) != hipSuccess || hipEventRecord(c->plan_unused_slot[k], c->stream) != hipSuccess)
-      return bail(fail(GKLHIP_ERR_HIP, "hipEventRecord failed"));
-  {
-    const int sets = c->cfg.record_events == 2 ? gklhip_ctx::kEventRing : 1;
-    for (int k = 0; k < sets; k++)
-      for (auto& e : c->ev_ring[k])
-        if (hipEventCreate(&e) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  for (int32_t d : list) {
+    DevCtx* dc = nullptr;
+    gklhip_config dcfg = c0;
+    dcfg.device = d;
+    const int rc = dev_init(dcfg, d, ndev, &dc);
+    if (rc) return rc;
+    c->dev.push_back(dc);
   }
-  if ((rc = upload_tables(c, host_tables_f32(), &c->tab32, &c->dt32))) return bail(rc);
-  if ((rc = upload_tables(c, host_tables_f64(), &c->tab64, &c->dt64))) return bail(rc);
-  *out_ctx = c;
+  const int n = (int)c->dev.size();
+  c->sub_off.resize((size_t)n);
+  c->bounds.assign((size_t)n + 1, 0);
+  if (n > 1) {
+    bool distinct = true;
+    for (int i = 0; i < n; i++)
+      for (int j = i + 1; j < n; j++) distinct &= list[(size_t)i] != list[(size_t)j];
+    for (int d = 1; d < n; d++) c->workers.emplace_back(new DevWorker());
+    c->shard_done.assign((size_t)n, nullptr);
+    HIP_TRY(hipSetDevice(c->dev[0]->device));
+    HIP_TRY(hipEventCreateWithFlags(&c->inputs_ready, hipEventDisableTiming));
+    for (int d = 1; d < n; d++) {
+      HIP_TRY(hipSetDevice(c->dev[(size_t)d]->device));
+      HIP_TRY(hipEventCreateWithFlags(&c->shard_done[(size_t)d], hipEventDisableTiming));
+      if (c->dev[(size_t)d]->device != c->dev[0]->device) {
+        // direct xGMI loads/stores between device 0 and this one (already enabled / unsupported: the copies then bounce)
+        (void)hipDeviceEnablePeerAccess(c->dev[0]->device, 0);
+        (void)hipGetLastError();
+        (void)hipSetDevice(c->dev[0]->device);
+        (void)hipDeviceEnablePeerAccess(c->dev[(size_t)d]->device, 0);
+        (void)hipGetLastError();
+      }
+    }
+    // Gather over RCCL when the devices are distinct (a communicator cannot hold a device twice; the 0,0 list of
+    // the one-GPU tests gathers with plain copies).  GKL_HIP_GATHER=peer|rccl overrides.
+    const char* g = getenv("GKL_HIP_GATHER");
+    const bool want_rccl = g ? strcmp(g, "rccl") == 0 : distinct;
+    if (want_rccl) {
+      if (!distinct) return fail(GKLHIP_ERR_INVALID_ARG, "GKL_HIP_GATHER=rccl needs distinct devices");
+      std::lock_guard<std::mutex> l(g_rccl_mu);
+      if (!g_rccl.load()) {
+        if (g) return fail(GKLHIP_ERR_HIP, "GKL_HIP_GATHER=rccl but librccl.so cannot be loaded: %s", dlerror());
+      } else {
+        c->comms.assign((size_t)n, nullptr);
+        std::vector<int> devs(list.begin(), list.end());
+        NCCL_TRY(g_rccl.CommInitAll(c->comms.data(), n, devs.data()));
+        c->use_rccl = true;
+      }
+    }
+  }
+  HIP_TRY(hipSetDevice(c->dev[0]->device));
+  *out_ctx = c.release();
   return GKLHIP_OK;
+}
+
+int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
+  // GKL_HIP_DEVICES=0,1,...: shard every call over these devices (used when the config does not pin one)
+  std::vector<int32_t> list;
+  if (!cfg || cfg->device < 0) {
+    const int rc = parse_device_list(getenv("GKL_HIP_DEVICES"), &list);
+    if (rc) { if (out_ctx) *out_ctx = nullptr; return rc; }
+  }
+  return gklhip_init_devices(cfg, list.empty() ? nullptr : list.data(), (int32_t)list.size(), out_ctx);
 }
 
 int gklhip_done(gklhip_ctx* c) {
   if (!c) return GKLHIP_OK;
-  (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev_slot[0], &c->plan_dev_slot[1], &c->raw32, &c->raw64, &c->used64, &c->list,
-                    &c->counters, &c->stream_buf, &c->read_off_dev, &c->out_dev, &c->batch_dev, &c->read_fail,
-                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->res_dev, &c->hap_flags})
-    b->release();
-  c->stage_slot[0].release();
-  c->stage_slot[1].release();
-  c->res_pin.release();
-  c->res_pin2.release();
-  c->batch_stage.release();
-  c->peek_count.release();
-  if (c->policy_done) (void)hipEventDestroy(c->policy_done);
-  if (c->early_copy_done) (void)hipEventDestroy(c->early_copy_done);
-  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
-  for (auto& set : c->ev_ring)
-    for (auto& e : set) if (e) (void)hipEventDestroy(e);
-  for (int k = 0; k < 2; k++) {
-    if (c->stage_free_slot[k]) (void)hipEventDestroy(c->stage_free_slot[k]);
-    if (c->plan_unused_slot[k]) (void)hipEventDestroy(c->plan_unused_slot[k]);
-  }
-  if (c->upload_stream) { (void)hipStreamSynchronize(c->upload_stream); (void)hipStreamDestroy(c->upload_stream); }
-  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  return GKLHIP_OK;
+}
+
+int gklhip_num_devices(gklhip_ctx* c) { return c ? (int)c->dev.size() : 0; }
+
+int gklhip_gather_backend(gklhip_ctx* c) { return !c || c->dev.size() < 2 ? 0 : c->use_rccl ? 2 : 1; }
+
+int gklhip_partition_reads(int32_t n_reads, const int64_t* read_off, int32_t n_parts, int32_t* bounds_out) {
+  if (n_reads < 0 || n_parts <= 0 || !read_off || !bounds_out) return fail(GKLHIP_ERR_INVALID_ARG, "bad arguments to gklhip_partition_reads");
+  partition_reads(n_reads, read_off, n_parts, bounds_out);
   return GKLHIP_OK;
 }
 
@@ -706,11 +1260,19 @@ int gklhip_compute_device(gklhip_ctx* c, const gklhip_batch* dev_batch, double* 
   if (!out_dev && (int64_t)dev_batch->n_reads * dev_batch->n_haps > 0)
     return fail(GKLHIP_ERR_INVALID_ARG, "output array is NULL");
   std::lock_guard<std::mutex> lock(c->mu);
-  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipSetDevice(c->dev[0]->device));
   int mode = c->cfg.finalize;
   if (mode != GKLHIP_FINALIZE_DEVICE_F64 && mode != GKLHIP_FINALIZE_DEVICE_REF32) mode = GKLHIP_FINALIZE_DEVICE_F64;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);  // NULL = HIP's default stream
-  return run_device(c, dev_batch, out_dev, mode, s);
+  c->last_reads = dev_batch->n_reads; c->last_haps = dev_batch->n_haps;
+  if (c->dev.size() == 1 || (int64_t)dev_batch->n_reads * dev_batch->n_haps == 0) {
+    c->bounds.assign(c->dev.size() + 1, dev_batch->n_reads);
+    c->bounds[0] = 0;
+    rc = run_device(c->dev[0], dev_batch, out_dev, mode, s, false);
+    c->stats = c->dev[0]->stats;
+    return rc;
+  }
+  return multi_compute_device(c, dev_batch, out_dev, mode, s);
 }
 
 int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
@@ -721,90 +1283,20 @@ int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
   if (n_pairs == 0) return GKLHIP_OK;
   if (!out_host) return fail(GKLHIP_ERR_INVALID_ARG, "output array is NULL");
   std::lock_guard<std::mutex> lock(c->mu);
-  HIP_TRY(hipSetDevice(c->device));
-  hipStream_t s = c->stream;
-  // H2D of the six byte arrays (one allocation, 256-byte aligned sub-buffers)
-  const size_t rl = (size_t)hb->read_off[hb->n_reads], hl = (size_t)hb->hap_off[hb->n_haps];
-  const size_t stride = align_up(rl);
-  if ((rc = c->batch_dev.reserve(5 * stride + align_up(hl)))) return rc;
-  unsigned char* d = c->batch_dev.as<unsigned char>();
-  const uint8_t* srcs[5] = {hb->read_bases, hb->read_quals, hb->ins_gop, hb->del_gop, hb->gcp};
-  const size_t all_bytes = 5 * stride + align_up(hl);
-  if (all_bytes <= kSmallBatchBytes) {
-    // a GATK-sized call: gather the six arrays in one pinned block and pay ONE copy launch instead of six
-    // (each costs the host ~6 us; the block is tiny).  The previous call has completed (this entry point
-    // synchronises before it returns), so the block is free.
-    if ((rc = c->batch_stage.reserve(all_bytes))) return rc;
-    unsigned char* hs = c->batch_stage.as<unsigned char>();
-    for (int i = 0; i < 5; i++) memcpy(hs + i * stride, srcs[i], rl);
-    memcpy(hs + 5 * stride, hb->hap_bases, hl);
-    HIP_TRY(hipMemcpyAsync(d, hs, all_bytes, hipMemcpyHostToDevice, s));
-  } else {
-    for (int i = 0; i < 5; i++) HIP_TRY(hipMemcpyAsync(d + i * stride, srcs[i], rl, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d + 5 * stride, hb->hap_bases, hl, hipMemcpyHostToDevice, s));
+  c->last_reads = hb->n_reads; c->last_haps = hb->n_haps;
+  if (c->dev.size() == 1) {
+    c->bounds.assign(2, hb->n_reads);
+    c->bounds[0] = 0;
+    rc = dev_compute_host(c->dev[0], hb, out_host);
+    c->stats = c->dev[0]->stats;
+    return rc;
   }
-  gklhip_batch db = *hb;
-  db.read_bases = d; db.read_quals = d + stride; db.ins_gop = d + 2 * stride;
-  db.del_gop = d + 3 * stride; db.gcp = d + 4 * stride; db.hap_bases = d + 5 * stride;
-  const int mode = c->cfg.finalize;
-  const bool on_device = (mode == GKLHIP_FINALIZE_DEVICE_F64 || mode == GKLHIP_FINALIZE_DEVICE_REF32);
-  if (on_device) {
-    if ((rc = c->out_dev.reserve((size_t)n_pairs * 8))) return rc;
-    if ((rc = run_device(c, &db, c->out_dev.as<double>(), mode, s))) return rc;
-    HIP_TRY(hipMemcpyAsync(out_host, c->out_dev.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return GKLHIP_OK;
-  }
-  // reference-exact finalisation on the host: one packed 8-byte word per pair comes back through pinned
-  // memory.  The fp32 results are final as soon as the policy kernel has run, so they are copied out on a
-  // second stream and finalised by the host WHILE the fp64 recomputation pass runs; only the recomputed
-  // pairs are left for after the last kernel.
-  int threads = c->cfg.max_threads;
-  if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  const size_t bytes = (size_t)n_pairs * 8;
-  if ((rc = c->res_dev.reserve(bytes))) return rc;
-  if ((rc = c->res_pin.reserve(bytes))) return rc;
-  HostFinalizer fin;
-  if (c->cfg.use_double) {
-    if ((rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
-    return GKLHIP_OK;
-  }
-  if (n_pairs <= kPeekPairs) {
-    // GATK-sized call: one D2H after the policy kernel; no underflowed pair (the usual case) = done
-    c->peek_after_policy = true;
-    rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s);
-    c->peek_after_policy = false;
-    if (rc) return rc;
-    if (c->fallback_skipped) {
-      c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
-      return GKLHIP_OK;
-    }
-    fin.early(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);  // overlaps the fp64 pass
-    if ((rc = c->res_pin2.reserve(bytes))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->res_pin2.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    c->stats.n_fallback = fin.late(&c->workers, c->res_pin2.as<uint64_t>(), out_host, threads);
-    return GKLHIP_OK;
-  }
-  if ((rc = c->res_pin2.reserve(bytes))) return rc;
-  if ((rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s))) return rc;  // records policy_done
-  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->policy_done, 0));
-  HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
-  HIP_TRY(hipEventRecord(c->early_copy_done, c->copy_stream));
-  HIP_TRY(hipMemcpyAsync(c->res_pin2.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));  // after the last kernel
-  HIP_TRY(hipEventSynchronize(c->early_copy_done));
-  fin.early(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
-  HIP_TRY(hipStreamSynchronize(s));
-  c->stats.n_fallback = fin.late(&c->workers, c->res_pin2.as<uint64_t>(), out_host, threads);
-  return GKLHIP_OK;
+  return multi_compute_host(c, hb, out_host);
 }
 
 void* gklhip_host_alloc(size_t bytes) {
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault | hipHostMallocPortable) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
@@ -815,15 +1307,16 @@ void gklhip_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
-int gklhip_get_step_times(gklhip_ctx* c, int32_t steps_back, float* ms_main, float* ms_fallback, float* ms_total) {
-  if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
-  std::lock_guard<std::mutex> lock(c->mu);
+int gklhip_get_step_times(gklhip_ctx* ctx, int32_t steps_back, float* ms_main, float* ms_fallback, float* ms_total) {
+  if (!ctx) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DevCtx* c = ctx->dev[0];  // (several devices: device 0's shard)
   if (c->cfg.record_events != 2) return fail(GKLHIP_ERR_INVALID_ARG, "context was not created with record_events = 2");
-  if (steps_back < 0 || steps_back >= gklhip_ctx::kEventRing || steps_back >= c->calls)
+  if (steps_back < 0 || steps_back >= DevCtx::kEventRing || steps_back >= c->calls)
     return fail(GKLHIP_ERR_INVALID_ARG, "steps_back %d outside the %d recorded calls", steps_back,
-                (int)std::min<int64_t>(c->calls, gklhip_ctx::kEventRing));
+                (int)std::min<int64_t>(c->calls, DevCtx::kEventRing));
   HIP_TRY(hipSetDevice(c->device));
-  const int slot = (int)((c->calls - 1 - steps_back) % gklhip_ctx::kEventRing);
+  const int slot = (int)((c->calls - 1 - steps_back) % DevCtx::kEventRing);
   hipEvent_t* e = c->ev_ring[slot];
   HIP_TRY(hipEventSynchronize(e[5]));
   float ms = 0;
@@ -840,20 +1333,32 @@ int gklhip_get_stats(gklhip_ctx* c, gklhip_stats* out) {
   return GKLHIP_OK;
 }
 
-int gklhip_get_raw(gklhip_ctx* c, float* raw32, double* raw64, uint8_t* used64) {
-  if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
-  std::lock_guard<std::mutex> lock(c->mu);
-  if (!c->have_last) return fail(GKLHIP_ERR_INVALID_ARG, "no completed call to read back");
-  HIP_TRY(hipSetDevice(c->device));
-  hipStream_t s = c->last_stream;
-  const size_t n = (size_t)c->last_pairs;
-  if (raw32 && !c->cfg.use_double) HIP_TRY(hipMemcpyAsync(raw32, c->raw32.p, n * 4, hipMemcpyDeviceToHost, s));
-  if (raw64) HIP_TRY(hipMemcpyAsync(raw64, c->raw64.p, n * 8, hipMemcpyDeviceToHost, s));
-  if (used64) HIP_TRY(hipMemcpyAsync(used64, c->used64.p, n, hipMemcpyDeviceToHost, s));
-  int32_t cnt[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  c->stats.n_fallback = c->cfg.use_double ? (int64_t)n : cnt[0];
+int gklhip_get_raw(gklhip_ctx* ctx, float* raw32, double* raw64, uint8_t* used64) {
+  if (!ctx) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int64_t n_fallback = 0;
+  bool any = false;
+  for (size_t d = 0; d < ctx->dev.size(); d++) {
+    DevCtx* c = ctx->dev[d];
+    if (ctx->dev.size() > 1 && ctx->bounds[d + 1] == ctx->bounds[d]) continue;
+    if (!c->have_last) continue;
+    any = true;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->last_stream;
+    const size_t n = (size_t)c->last_pairs;
+    const size_t at = (size_t)ctx->bounds[d] * (size_t)ctx->last_haps;
+    if (raw32 && !c->cfg.use_double) HIP_TRY(hipMemcpyAsync(raw32 + at, c->raw32.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (raw64) HIP_TRY(hipMemcpyAsync(raw64 + at, c->raw64.p, n * 8, hipMemcpyDeviceToHost, s));
+    if (used64) HIP_TRY(hipMemcpyAsync(used64 + at, c->used64.p, n, hipMemcpyDeviceToHost, s));
+    int32_t cnt[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->stats.n_fallback = c->cfg.use_double ? (int64_t)n : cnt[0];
+    n_fallback += c->stats.n_fallback;
+  }
+  if (!any) return fail(GKLHIP_ERR_INVALID_ARG, "no completed call to read back");
+  ctx->stats.n_fallback = n_fallback;
+  HIP_TRY(hipSetDevice(ctx->dev[0]->device));
   return GKLHIP_OK;
 }
 
@@ -886,6 +1391,39 @@ int64_t gklhip_get_table_f64(int which, double* dst, int64_t cap) {
   if (!v) return -1;
   if (dst) memcpy(dst, v->data(), sizeof(double) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
   return (int64_t)v->size();
+}
+
+// Diagnostics: load RCCL and run one send/recv pair inside one group on a one-device communicator (what the
+// multi-device gather does per extra device).  0 = ok.
+int gklhip_rccl_selftest(int32_t device) {
+  std::lock_guard<std::mutex> l(g_rccl_mu);
+  if (!g_rccl.load()) return fail(GKLHIP_ERR_HIP, "librccl.so cannot be loaded: %s", dlerror());
+  HIP_TRY(hipSetDevice(device));
+  ncclComm_t comm = nullptr;
+  const int devs[1] = {device};
+  NCCL_TRY(g_rccl.CommInitAll(&comm, 1, devs));
+  const size_t n = 4096;
+  double *src = nullptr, *dst = nullptr;
+  HIP_TRY(hipMalloc(&src, n * 8));
+  HIP_TRY(hipMalloc(&dst, n * 8));
+  std::vector<double> h(n), back(n, 0.0);
+  for (size_t i = 0; i < n; i++) h[i] = (double)i * 0.5 - 7.0;
+  HIP_TRY(hipMemcpy(src, h.data(), n * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(dst, 0, n * 8));
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  NCCL_TRY(g_rccl.GroupStart());
+  NCCL_TRY(g_rccl.Send(src, n, ncclDouble, 0, comm, s));
+  NCCL_TRY(g_rccl.Recv(dst, n, ncclDouble, 0, comm, s));
+  NCCL_TRY(g_rccl.GroupEnd());
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpy(back.data(), dst, n * 8, hipMemcpyDeviceToHost));
+  (void)hipStreamDestroy(s);
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  (void)g_rccl.CommDestroy(comm);
+  if (memcmp(h.data(), back.data(), n * 8) != 0) return fail(GKLHIP_ERR_HIP, "RCCL self send/recv returned different data");
+  return GKLHIP_OK;
 }
 
 }  // extern "C"

@@ -11,43 +11,59 @@
 
 namespace gklhip {
 
-// Zeroes the small per-call arrays (counters, per-read fail counts, fail histogram, haplotype flags) in one launch;
-// hipMemsetAsync blits cost a barrier bubble of ~50 us per step between back-to-back batches.
-__global__ void clear_kernel(int32_t* a, int na, int32_t* b, int nb, int32_t* c, int nc, int32_t* d, int nd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < na) a[i] = 0;
-  if (i < nb) b[i] = 0;
-  if (i < nc) c[i] = 0;
-  if (i < nd) d[i] = 0;
-}
-
-// stream_src (host plan) -> stream entries: haplotype base codes / separators / idle.
-// A thread that meets an 'N' also flags its haplotype (hap_has_n, zeroed beforehand: the fp64 kernels route such
-// haplotypes through the general step, see WaveJob::kCodes); it finds the haplotype by bisecting hap_pos.
-__global__ void build_stream_kernel(const int32_t* __restrict__ src, const uint8_t* __restrict__ hap_bases,
-                                    uint32_t* __restrict__ stream, int n, const int32_t* __restrict__ hap_pos,
-                                    int n_haps, uint8_t* __restrict__ hap_has_n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t s = src[i];
-  uint32_t e;
-  if (s >= 0) {
-    const uint8_t b = hap_bases[s];  // pairhmm_common.h:57-61: A0 C1 T2 G3 N4, anything else 0
-    e = b == 'C' ? 1u : b == 'T' ? 2u : b == 'G' ? 3u : b == 'N' ? 4u : 0u;
-    if (b == 'N') {
-      int lo = 0, hi = n_haps - 1;  // largest stream-order haplotype whose first column is at or before i
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (hap_pos[mid] <= i) lo = mid; else hi = mid - 1;
-      }
-      hap_has_n[lo] = 1;
-    }
-  } else if (s == -1) {
-    e = kEntIdle;
-  } else {
-    e = kEntSep | (uint32_t)(-2 - s);
+// Per-call preparation in ONE launch (it used to be a clear kernel + a stream kernel fed by a host-built source
+// index per column): one wavefront per haplotype turns its bases into stream entries (base codes, then the
+// separator, then -- behind the last haplotype of a group -- 64 idle entries of drain room), coalesced, and
+// flags a haplotype that contains an 'N' (the fp64 kernels route such haplotypes through the general step, see
+// WaveJob::kCodes).  The same launch zeroes the small per-call arrays the later kernels count into.
+struct PrepArgs {
+  const uint8_t* hap_bases;
+  const int32_t* hap_src;    // [n_haps] stream order: offset of the haplotype's first base in hap_bases
+  const int32_t* hap_len;    // [n_haps] stream order
+  const int32_t* hap_pos;    // [n_haps] stream order: stream index of column 1
+  const int32_t* hap_group;  // [n_haps] stream order
+  uint32_t* stream;
+  uint8_t* hap_has_n;        // [n_haps] stream order (every entry written: no clear needed)
+  int32_t n_haps;
+  int32_t* clear_a; int32_t n_a;  // counters
+  int32_t* clear_b; int32_t n_b;  // per-read fallback counts
+  int32_t* clear_c; int32_t n_c;  // fallback-count histogram
+  // small host-buffer calls: the plan block (plan arrays + the call's six input arrays) sits in pinned host memory
+  // and this kernel PULLS it into HBM itself -- a copy-engine transfer in front of the first kernel costs ~20 us
+  // of queue hand-offs, more than everything this kernel does.  The pointers above then point into the HOST copy
+  // (the device copy is complete only when this kernel has finished).
+  const uint4* pull_src; uint4* pull_dst; int32_t pull_n16;  // 16-byte words
+  int32_t hap_blocks;  // blocks [0, hap_blocks) build the stream, the rest pull
+};
+constexpr int kPrepBlock = 256;
+__global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
+  if ((int)blockIdx.x >= a.hap_blocks) {
+    const int stride = ((int)gridDim.x - a.hap_blocks) * kPrepBlock;
+    for (int w = ((int)blockIdx.x - a.hap_blocks) * kPrepBlock + (int)threadIdx.x; w < a.pull_n16; w += stride) a.pull_dst[w] = a.pull_src[w];
+    return;
   }
-  stream[i] = e;
+  const int i = blockIdx.x * kPrepBlock + threadIdx.x;
+  if (i < a.n_a) a.clear_a[i] = 0;
+  if (i < a.n_b) a.clear_b[i] = 0;
+  if (i < a.n_c) a.clear_c[i] = 0;
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * (kPrepBlock / 64) + (threadIdx.x >> 6);
+  if (k >= a.n_haps) return;
+  const int len = a.hap_len[k], pos = a.hap_pos[k];
+  const uint8_t* src = a.hap_bases + a.hap_src[k];
+  bool has_n = false;
+  for (int c = lane; c < len; c += 64) {
+    const uint8_t b = src[c];  // pairhmm_common.h:57-61: A0 C1 T2 G3 N4, anything else 0
+    a.stream[pos + c] = b == 'C' ? 1u : b == 'T' ? 2u : b == 'G' ? 3u : b == 'N' ? 4u : 0u;
+    has_n |= b == 'N';
+  }
+  const bool group_ends = k + 1 == a.n_haps || a.hap_group[k + 1] != a.hap_group[k];
+  if (lane == 0) {
+    a.stream[pos + len] = kEntSep | (uint32_t)k;
+    a.hap_has_n[k] = 0;
+  }
+  if (group_ends) a.stream[pos + len + 1 + lane] = kEntIdle;
+  if (__ballot(has_n) != 0 && lane == 0) a.hap_has_n[k] = 1;
 }
 
 // Host finalisation (reference-exact log10f / log10 of the host libm) needs, per pair, either the raw
@@ -62,8 +78,7 @@ struct FinalizeArgs {
   const double* raw64;
   double* out;
   uint8_t* used64;
-  int32_t* list;
-  int32_t* count;
+  int32_t* count;      // [0] number of pairs the policy sent to the fp64 pass
   int32_t* read_fail;  // [n_reads] number of haplotypes each read must be recomputed against
   int32_t n_haps;
   int64_t n;
@@ -73,51 +88,8 @@ struct FinalizeArgs {
   double log10_init_d;         // log10(2^1020)
 };
 
-// Precision policy of IntelPairHmm.cc:157-165 on the raw fp32 sums: keep (and
-// finalise) pairs with sum >= 1e-28f, queue the rest for the fp64 kernel.
-constexpr int kPolicyBlock = 1024;
-__global__ __launch_bounds__(kPolicyBlock) void policy_kernel(FinalizeArgs a) {
-  __shared__ int32_t wave_cnt[kPolicyBlock / 64], wave_base[kPolicyBlock / 64];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in_range = i < a.n;
-  const float v = in_range ? a.raw32[i] : 1.0f;
-  const bool fails = in_range && v < 1e-28f;  // NaN compares false and stays fp32, like the reference
-  // One atomic per BLOCK on the queue counter: atomics on a single address retire one per ~7 ns at the L2, and
-  // one per wavefront (20 k of them for the bench batch) made this kernel take 150 us.
-  const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
-  const uint64_t mask = __ballot(fails);
-  if (lane == 0) wave_cnt[wave] = __builtin_popcountll(mask);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int total = 0;
-    for (int w = 0; w < kPolicyBlock / 64; w++) { wave_base[w] = total; total += wave_cnt[w]; }
-    const int base = total ? atomicAdd(a.count, total) : 0;
-    for (int w = 0; w < kPolicyBlock / 64; w++) wave_base[w] += base;
-  }
-  __syncthreads();
-  if (mask) {
-    const int leader = __builtin_ctzll(mask);
-    const int32_t read = fails ? (int32_t)(i / a.n_haps) : -1;
-    if (fails) a.list[wave_base[wave] + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int32_t)i;
-    // r-major pairs: the failing lanes of a wavefront usually belong to one read (n_haps >= 64) or a few
-    const int32_t lead_read = __shfl(read, leader, 64);
-    const uint64_t same = __ballot(fails && read == lead_read);
-    if (lane == leader) atomicAdd(a.read_fail + lead_read, __builtin_popcountll(same));
-    if (fails && read != lead_read) atomicAdd(a.read_fail + read, 1);
-  }
-  if (!in_range) return;
-  if (fails) {
-    a.used64[i] = 1;
-    if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[i] = 0;  // "pending": filled in by finalize64_kernel
-  } else {
-    a.used64[i] = 0;
-    // the device log10 of the kept pairs is finalize32_kernel's job: it runs beside the fp64 pass
-    if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[i] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
-  }
-}
-
 // log10 of the fp32 sums the policy kept (device finalisation modes).  Launched on the context's side stream
-// right after policy_kernel, so its ~1.3 M double-precision log10 overlap the planning kernels and the fp64 pass.
+// right after the policy, so its ~1.3 M double-precision log10 overlap the fp64 pass.
 __global__ void finalize32_kernel(FinalizeArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n || a.used64[i]) return;
@@ -126,13 +98,12 @@ __global__ void finalize32_kernel(FinalizeArgs a) {
   else if (a.mode == GKLHIP_FINALIZE_DEVICE_REF32) a.out[i] = (double)((float)log10((double)v) - a.log10_init_f);
 }
 
-// log10 of the fp64 sums: all pairs (useDoublePrecision) or the queued ones.
-__global__ void finalize64_kernel(FinalizeArgs a, int use_list) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = use_list ? (int64_t)*a.count : a.n;
-  if (i >= n) return;
-  const int64_t p = use_list ? (int64_t)a.list[i] : i;
-  if (!use_list) a.used64[p] = 1;
+// log10 of the fp64 sums: all pairs (useDoublePrecision: all_pairs != 0) or the ones the policy flagged.
+__global__ void finalize64_kernel(FinalizeArgs a, int all_pairs) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n) return;
+  if (all_pairs) a.used64[p] = 1;
+  else if (!a.used64[p]) return;
   if (a.mode >= 0) a.out[p] = log10(a.raw64[p]) - a.log10_init_d;
   if (a.mode == kModePacked) {
     uint64_t bits = (uint64_t)__double_as_longlong(a.raw64[p]);
@@ -141,168 +112,345 @@ __global__ void finalize64_kernel(FinalizeArgs a, int use_list) {
   }
 }
 
-// Packed fp64 fallback, step 2 (device): for every chunk of the second read packing, find the
-// runs of consecutive haplotypes (stream order, never across a stream group) that at least one
-// of its reads must be recomputed against, and queue one wave job per run.
-__global__ void build_jobs_kernel(const LaneSlot* __restrict__ lanes, const int32_t* __restrict__ n_chunks,
-                                  const uint8_t* __restrict__ used64, int n_haps,
-                                  const int32_t* __restrict__ hap_orig, const int32_t* __restrict__ hap_group,
-                                  FwdJob* __restrict__ jobs, int32_t* __restrict__ job_count) {
-  extern __shared__ int32_t smem[];
-  int32_t* s_reads = smem;                                   // [64] distinct reads of the chunk
-  uint8_t* need = reinterpret_cast<uint8_t*>(smem + kLanes + 1);  // [n_haps]
-  const int total = *n_chunks;
-  for (int c = blockIdx.x; c < total; c += gridDim.x) {
-  __syncthreads();
-  if (threadIdx.x == 0) smem[kLanes] = 0;
-  __syncthreads();
-  if (threadIdx.x < kLanes) {
-    const LaneSlot sl = lanes[(int64_t)c * kLanes + threadIdx.x];
-    if (sl.read >= 0 && sl.block == 0) s_reads[atomicAdd(&smem[kLanes], 1)] = sl.read;
-  }
-  __syncthreads();
-  const int nr = smem[kLanes];
-  for (int k = threadIdx.x; k < n_haps; k += blockDim.x) {
-    const int h = hap_orig[k];
-    uint8_t nd = 0;
-    for (int i = 0; i < nr; i++) nd |= used64[(int64_t)s_reads[i] * n_haps + h];
-    need[k] = nd;
-  }
-  __syncthreads();
-  // a needed haplotype starts a run if its predecessor is not needed or lies in another stream group
-  for (int k = threadIdx.x; k < n_haps; k += blockDim.x) {
-    if (!need[k]) continue;
-    if (k > 0 && need[k - 1] && hap_group[k - 1] == hap_group[k]) continue;
-    int e = k + 1;
-    while (e < n_haps && need[e] && hap_group[e] == hap_group[k]) e++;
-    FwdJob j;
-    j.chunk = c; j.hap_begin = k; j.hap_end = e; j.pad_ = 0;
-    jobs[atomicAdd(job_count, 1)] = j;
-  }
-  }  // chunk loop
-}
-
-// Packed fp64 fallback, step 3 (device): order the job list by decreasing length (counting sort on
-// columns / 128, one block), so that the persistent wavefronts of the jobs kernel start the long runs
-// first and the kernel's tail is made of short ones.
-constexpr int kJobClasses = 64;
-__global__ __launch_bounds__(1024) void sort_jobs_kernel(const FwdJob* __restrict__ jobs, const int32_t* __restrict__ job_count,
-                                                         const int32_t* __restrict__ hap_pos,
-                                                         const int32_t* __restrict__ hap_len, FwdJob* __restrict__ sorted) {
-  __shared__ int32_t cnt[kJobClasses], base[kJobClasses];
-  const int n = *job_count;
-  if (threadIdx.x < kJobClasses) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  auto cls_of = [&](const FwdJob& j) {
-    const int cols = hap_pos[j.hap_end - 1] + hap_len[j.hap_end - 1] - hap_pos[j.hap_begin];
-    const int c = cols >> 7;
-    return kJobClasses - 1 - (c < kJobClasses - 1 ? c : kJobClasses - 1);  // class 0 = longest
-  };
-  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&cnt[cls_of(jobs[i])], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int c = 0; c < kJobClasses; c++) { base[c] = acc; acc += cnt[c]; }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const FwdJob j = jobs[i];
-    sorted[atomicAdd(&base[cls_of(j)], 1)] = j;
-  }
-}
-
-// ---- packed fp64 fallback, step 1 (device): order the affected reads by how many haplotypes
-// they failed against (counting sort, most first) and pack them, window by window, into 64-lane
-// chunks with best-fit-decreasing -- the device twin of pack_reads_windowed(), so the pass needs
-// no host round trip.  Reads with similar fallback counts share chunks; in nested patterns (a
-// read underflows against every haplotype shorter than some length) a chunk then needs one
-// contiguous run of the length-sorted haplotype stream.
+// ---- precision policy + planning of the packed fp64 recomputation pass: ONE launch -------------------------
+// Phases, separated by grid barriers (the blocks of this kernel are all resident: at most one per CU):
+//   P  policy of IntelPairHmm.cc:157-165 on the raw fp32 sums: keep pairs with sum >= 1e-28f, flag the rest for
+//      the fp64 kernel and count, per read, how many haplotypes it failed against;
+//   H  histogram of those counts over the reads that fit a chunk;   S  bucket starts for DESCENDING count;
+//   C  counting-sort scatter: affected reads ordered by how many haplotypes they failed against;
+//   W  window by window (kPackWindow reads, one wavefront each) best-fit-decreasing packing into 64-lane chunks --
+//      the device twin of pack_reads_windowed().  Reads with similar fallback counts share chunks; in nested
+//      patterns (a read underflows against every haplotype shorter than some length) a chunk then needs one
+//      contiguous run of the length-sorted haplotype stream;
+//   J  per chunk, the runs of consecutive haplotypes (stream order, never across a stream group) that at least
+//      one of its reads must be recomputed against: one wave job per run (also for the pseudo-chunks of reads too
+//      long for a chunk, which feed the striped kernel);
+//   O  the job list ordered by decreasing length (counting sort on columns / 128, one block), so that the
+//      persistent wavefronts of the jobs kernel start the long runs first and the kernel's tail is short.
+// These were eight launches with the chip idle in between (0.17 ms per call); the pass needs no host round trip.
+// None of the arrays written here is declared const/__restrict__: data produced in one phase is read in the next,
+// and the compiler must not move such reads to the scalar cache, which the barrier's fences do not invalidate.
 constexpr int kPackWindow = 96;
+constexpr int kJobClasses = 64;
+constexpr int kPlanBlock = 1024;
 
-// (reads longer than max_len bases do not fit a chunk: they take the striped long-read path)
-__global__ void fail_hist_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ hist,
-                                 const int64_t* __restrict__ read_off, int max_len) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads && read_fail[r] > 0 && read_off[r + 1] - read_off[r] <= max_len) atomicAdd(hist + read_fail[r], 1);
-}
+struct PlanArgs {
+  FinalizeArgs fa;
+  int32_t n_reads, n_haps, n_pairs_i;
+  const int64_t* read_off;
+  int32_t rpl;           // rows per lane of the fp64 kernel
+  int32_t max_len;       // longest read that fits a chunk at that rpl
+  int32_t* cnts;         // [0] fp64 pairs [2] jobs [3] next job [4] affected reads [5] chunks [8] long jobs [9] next long job
+                         // [10] grid barrier
+  int32_t* hist;         // [n_haps + 2]
+  int32_t* pos;          // [n_haps + 2]
+  int32_t* order;        // [n_reads]
+  LaneSlot* lanes2;      // [n_reads * 64] worst case
+  const int32_t* hap_orig;
+  const int32_t* hap_group;
+  const int32_t* hap_pos;
+  const int32_t* hap_len;
+  FwdJob* jobs;          // as built
+  FwdJob* sorted;        // by decreasing length
+  const LaneSlot* long_lanes;  // pseudo-chunks (lane 0 names the read) of reads too long for a chunk
+  int32_t n_long;
+  FwdJob* jobs_long;
+  // direct mode (small calls, chosen by the host): every flagged pair becomes its own job -- the read alone in a
+  // wavefront against that one haplotype -- straight from the policy pass: no packing, no barriers.  Lane use is
+  // poor (a 100-base read fills a quarter of the lanes) and irrelevant: such a call leaves most of the chip idle
+  // and what counts is the length of the longest dependent chain.
+  int32_t direct;
+  const int32_t* hap_sidx;  // caller's haplotype index -> stream order
+  // job length: runs are cut after `wanted` columns' worth ... see phase J
+  int32_t total_cols;    // columns + separators of all haplotypes
+  int32_t wanted_jobs;   // the pass is cut into about this many jobs (when the runs allow it)
+  int32_t min_job_cols;
+};
 
-// one block: bucket start positions for DESCENDING fail count; pos[c] = #reads with count > c
-__global__ void fail_scan_kernel(const int32_t* __restrict__ hist, int n_haps, int32_t* __restrict__ pos,
-                                 int32_t* __restrict__ n_fail_reads) {
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int c = n_haps; c >= 1; c--) { pos[c] = acc; acc += hist[c]; }
-    *n_fail_reads = acc;
-  }
-}
-
-__global__ void fail_scatter_kernel(const int32_t* __restrict__ read_fail, int n_reads, int32_t* __restrict__ pos,
-                                    int32_t* __restrict__ order, const int64_t* __restrict__ read_off, int max_len) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_reads && read_fail[r] > 0 && read_off[r + 1] - read_off[r] <= max_len)
-    order[atomicAdd(pos + read_fail[r], 1)] = r;
-}
-
-__global__ __launch_bounds__(64) void pack_windows_kernel(const int32_t* __restrict__ order,
-                                                          const int32_t* __restrict__ n_fail_reads,
-                                                          const int64_t* __restrict__ read_off, int rpl,
-                                                          LaneSlot* __restrict__ lanes, int32_t* __restrict__ n_chunks) {
-  // One wavefront per window of <= 96 reads; everything is wave-parallel: rank sort by lanes
-  // needed (descending, stable), then best fit where the 64 lanes each watch up to two bins and
-  // a shuffle reduction picks the fullest bin that still fits.
-  __shared__ int32_t s_read[kPackWindow], s_need[kPackWindow], s_sread[kPackWindow], s_sneed[kPackWindow];
-  __shared__ int32_t s_bin[kPackWindow], s_off[kPackWindow];
-  const int lane = threadIdx.x;
-  const int n = *n_fail_reads;
-  const int w0 = blockIdx.x * kPackWindow;
-  if (w0 >= n) return;
-  const int cnt = min(kPackWindow, n - w0);
-  for (int i = lane; i < cnt; i += kLanes) {
-    const int r = order[w0 + i];
-    s_read[i] = r;
-    s_need[i] = (int)((read_off[r + 1] - read_off[r] + rpl) / rpl);  // blocks_for()
-  }
+// All threads of all blocks call this the same number of times.  `target` counts arrivals expected so far.
+__device__ __forceinline__ void grid_barrier(int32_t* bar, int32_t& target) {
   __syncthreads();
-  for (int i = lane; i < cnt; i += kLanes) {
-    const int ni = s_need[i];
-    int rank = 0;
-    for (int j = 0; j < cnt; j++) {
-      const int nj = s_need[j];
-      rank += (nj > ni) || (nj == ni && j < i);
+  if (gridDim.x > 1) {
+    if (threadIdx.x == 0) {
+      target += (int32_t)gridDim.x;
+      __threadfence();  // release this block's writes (agent scope: writes back the XCD's L2)
+      atomicAdd(bar, 1);
+      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
+      __threadfence();  // acquire the other blocks' writes
     }
-    s_sread[rank] = s_read[i];
-    s_sneed[rank] = ni;
+    __syncthreads();
   }
-  __syncthreads();
-  int free0 = 0, free1 = 0;  // free lanes of bins `lane` and `lane + 64` (0 = bin not open)
-  int nb = 0;                // bins opened so far (wave-uniform)
-  for (int i = 0; i < cnt; i++) {
-    const int nn = s_sneed[i];
-    // key = free*256 + bin for bins that fit, smallest free wins (best fit); none -> large
-    int key = 0x7fffffff;
-    if (free0 >= nn) key = free0 * 256 + lane;
-    if (free1 >= nn && free1 * 256 + lane + kLanes < key) key = free1 * 256 + lane + kLanes;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) key = min(key, __shfl_xor(key, d, kLanes));
-    int bin, off;
-    if (key == 0x7fffffff) { bin = nb++; off = 0; }
-    else { bin = key & 255; off = kLanes - (key >> 8); }
-    if (bin == lane) free0 = (key == 0x7fffffff ? kLanes : free0) - nn;
-    if (bin == lane + kLanes) free1 = (key == 0x7fffffff ? kLanes : free1) - nn;
-    if (lane == 0) { s_bin[i] = bin; s_off[i] = off; }
-  }
-  int base = 0;
-  if (lane == 0) base = atomicAdd(n_chunks, nb);
-  base = __shfl(base, 0, kLanes);
-  __syncthreads();
-  LaneSlot idle; idle.read = -1; idle.block = 0;
-  for (int i = lane; i < nb * kLanes; i += kLanes) lanes[(int64_t)base * kLanes + i] = idle;
-  __syncthreads();
-  for (int i = 0; i < cnt; i++)
-    for (int b = lane; b < s_sneed[i]; b += kLanes) {
-      LaneSlot sl; sl.read = s_sread[i]; sl.block = b;
-      lanes[(int64_t)(base + s_bin[i]) * kLanes + s_off[i] + b] = sl;
+}
+
+// counters are written with atomics (performed at the L2) and read back through it
+__device__ __forceinline__ int32_t ld_cnt(int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int job_class(const FwdJob& j, const int32_t* hap_pos, const int32_t* hap_len) {
+  const int cols = hap_pos[j.hap_end - 1] + hap_len[j.hap_end - 1] - hap_pos[j.hap_begin];
+  const int c = cols >> 7;
+  return kJobClasses - 1 - (c < kJobClasses - 1 ? c : kJobClasses - 1);  // class 0 = longest
+}
+
+// Run detection for one (pseudo-)chunk by ONE wavefront, 64 haplotypes (stream order) at a time: lane = haplotype.
+// A needed haplotype starts a job if its predecessor is not needed, lies in another stream group, or lies in another
+// cut_cols-wide window of the stream (jobs are cut on a fixed grid of stream positions -- no prefix sums), or if it is
+// the first of its 64-haplotype segment; the job ends at the next start or the next haplotype that is not needed.
+// Everything is ballots and bit tricks on the two masks; one atomic on the job counter per segment.
+__device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const LaneSlot* lanes, int c, FwdJob* jobs,
+                                                     int32_t* job_count, int cut_cols, int lane) {
+  const LaneSlot sl = lanes[(int64_t)c * kLanes + lane];
+  uint64_t reads = __ballot(sl.read >= 0 && sl.block == 0);  // lanes that name a read of the chunk
+  for (int k0 = 0; k0 < a.n_haps; k0 += kLanes) {
+    const int k = k0 + lane;
+    const bool in = k < a.n_haps;
+    const int h = in ? a.hap_orig[k] : 0;
+    uint8_t nd = 0;
+    for (uint64_t m = reads; m; m &= m - 1) {
+      const int r = __builtin_amdgcn_readlane(sl.read, __builtin_ctzll(m));
+      if (in) nd |= a.fa.used64[(int64_t)r * a.n_haps + h];
     }
+    const uint64_t need = __ballot(in && nd != 0);
+    if (!need) continue;
+    bool start = false;
+    if (in && nd) {
+      start = lane == 0 || !((need >> (lane - 1)) & 1ull) || a.hap_group[k - 1] != a.hap_group[k] ||
+              a.hap_pos[k - 1] / cut_cols != a.hap_pos[k] / cut_cols;
+    }
+    const uint64_t starts = __ballot(start);
+    int32_t base = 0;
+    if (lane == 0) base = atomicAdd(job_count, __builtin_popcountll(starts));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (start) {
+      const uint64_t after = lane == kLanes - 1 ? 0ull : (~0ull << (lane + 1));
+      const uint64_t stop = (starts | ~need) & after;
+      const int e = stop ? __builtin_ctzll(stop) : kLanes;
+      FwdJob j;
+      j.chunk = c; j.hap_begin = k; j.hap_end = min(k0 + e, a.n_haps); j.solo = 0;
+      jobs[base + __builtin_popcountll(starts & ((1ull << lane) - 1ull))] = j;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
+  __shared__ int32_t s_i32[kPlanBlock];  // phase S: scan; O: class counters
+  __shared__ int32_t s_wave[kPlanBlock / 64];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
+  int32_t target = 0;
+  int32_t* bar = a.cnts + 10;
+
+  // ---- P: policy ----
+  {
+    int32_t my_fails = 0;
+    for (int64_t base = (int64_t)blk * kPlanBlock; base < a.fa.n; base += (int64_t)nblk * kPlanBlock) {
+      const int64_t i = base + tid;
+      const bool in_range = i < a.fa.n;
+      const float v = in_range ? a.fa.raw32[i] : 1.0f;
+      const bool fails = in_range && v < 1e-28f;  // NaN compares false and stays fp32, like the reference
+      const uint64_t mask = __ballot(fails);
+      if (mask) {
+        // r-major pairs: the failing lanes of a wavefront usually belong to one read (n_haps >= 64) or a few
+        const int leader = __builtin_ctzll(mask);
+        const int32_t read = fails ? (int32_t)(i / a.n_haps) : -1;
+        const int32_t lead_read = __shfl(read, leader, 64);
+        const uint64_t same = __ballot(fails && read == lead_read);
+        if (lane == leader) atomicAdd(a.fa.read_fail + lead_read, __builtin_popcountll(same));
+        if (fails && read != lead_read) atomicAdd(a.fa.read_fail + read, 1);
+        if (lane == 0) my_fails += __builtin_popcountll(mask);
+      }
+      if (a.direct && mask) {
+        int32_t at = 0;
+        if (lane == 0) at = atomicAdd(a.cnts + 2, __builtin_popcountll(mask));
+        at = __shfl(at, 0, 64) + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (fails) {
+          const int32_t r = (int32_t)(i / a.n_haps), k = a.hap_sidx[(int32_t)(i - (int64_t)r * a.n_haps)];
+          FwdJob j;
+          j.chunk = r; j.hap_begin = k; j.hap_end = k + 1; j.solo = 1;
+          a.sorted[at] = j;
+        }
+      }
+      if (in_range) {
+        a.fa.used64[i] = fails ? 1 : 0;
+        // "pending" (0) for the flagged pairs: finalize64_kernel fills them in; the device log10 of the kept pairs
+        // is finalize32_kernel's job, which runs beside the fp64 pass
+        if (a.fa.mode == kModePacked)
+          reinterpret_cast<uint64_t*>(a.fa.out)[i] = fails ? 0ull : (kPackedF32Tag | (uint64_t)__float_as_uint(v));
+      }
+    }
+    // one atomic per block on the pair counter (same-address atomics retire one per ~7 ns at the L2)
+    if (lane == 0) s_wave[wave] = my_fails;
+    __syncthreads();
+    if (tid == 0) {
+      int total = 0;
+      for (int w = 0; w < kPlanBlock / 64; w++) total += s_wave[w];
+      if (total) atomicAdd(a.cnts + 0, total);
+    }
+  }
+  if (a.direct) return;
+  grid_barrier(bar, target);
+  const int n_fail = ld_cnt(a.cnts + 0);
+  if (n_fail == 0) return;  // nothing underflowed (uniform across the grid: read after the barrier)
+  const uint64_t clk0 = wall_clock64();
+  auto stamp = [&](int k) { if (blk == 0 && tid == 0) a.cnts[16 + k] = (int32_t)(wall_clock64() - clk0); };
+
+  // ---- H: histogram of fallback counts (reads longer than max_len take the striped long-read path) ----
+  for (int r = blk * kPlanBlock + tid; r < a.n_reads; r += nblk * kPlanBlock) {
+    const int f = a.fa.read_fail[r];
+    if (f > 0 && a.read_off[r + 1] - a.read_off[r] <= a.max_len) atomicAdd(a.hist + f, 1);
+  }
+  grid_barrier(bar, target);
+  stamp(0);
+
+  // ---- S: bucket starts for DESCENDING count: pos[c] = #reads with count > c (block 0; the others go on) ----
+  if (blk == 0) {
+    // per-thread contiguous segments of the count range [1, n_haps], highest counts first
+    const int n = a.n_haps;
+    const int per = (n + kPlanBlock - 1) / kPlanBlock;
+    const int hi = n - tid * per, lo = max(hi - per, 0);  // this thread owns counts (lo, hi]
+    int sum = 0;
+    for (int c = hi; c > lo; c--) sum += a.hist[c];
+    int32_t* s_scan = s_i32;
+    s_scan[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int t = 0; t < kPlanBlock; t++) { const int v = s_scan[t]; s_scan[t] = acc; acc += v; }
+      __hip_atomic_store(a.cnts + 4, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    int acc = s_scan[tid];
+    for (int c = hi; c > lo; c--) { a.pos[c] = acc; acc += a.hist[c]; }
+  }
+  grid_barrier(bar, target);
+  stamp(1);
+
+  // ---- C: scatter ----
+  for (int r = blk * kPlanBlock + tid; r < a.n_reads; r += nblk * kPlanBlock) {
+    const int f = a.fa.read_fail[r];
+    if (f > 0 && a.read_off[r + 1] - a.read_off[r] <= a.max_len) a.order[atomicAdd(a.pos + f, 1)] = r;
+  }
+  grid_barrier(bar, target);
+  stamp(2);
+
+  // ---- W: pack windows, one wavefront per window ----
+  {
+    // One wavefront per window of <= kPackWindow reads: rank sort by lanes needed (descending, stable), then best fit.
+    static_assert(kPackWindow <= 2 * kLanes, "the window's lane counts sit in two registers per lane");
+    __shared__ int32_t s_pack[kPlanBlock / 64][7][kPackWindow];
+    int32_t* s_read = s_pack[wave][0]; int32_t* s_needl = s_pack[wave][1]; int32_t* s_sread = s_pack[wave][2];
+    int32_t* s_sneed = s_pack[wave][3]; int32_t* s_bin = s_pack[wave][4]; int32_t* s_off = s_pack[wave][5];
+    int32_t* s_next = s_pack[wave][6];
+    const int n = ld_cnt(a.cnts + 4);
+    const int n_win = (n + kPackWindow - 1) / kPackWindow;
+    for (int w = blk * (kPlanBlock / 64) + wave; w < n_win; w += nblk * (kPlanBlock / 64)) {
+      const int w0 = w * kPackWindow;
+      const int cnt = min(kPackWindow, n - w0);
+      for (int i = lane; i < cnt; i += kLanes) {
+        const int r = a.order[w0 + i];
+        s_read[i] = r;
+        s_needl[i] = (int)((a.read_off[r + 1] - a.read_off[r] + a.rpl) / a.rpl);  // blocks_for()
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < cnt; i += kLanes) {
+        const int ni = s_needl[i];
+        int rank = 0;
+        for (int j = 0; j < cnt; j++) {
+          const int nj = s_needl[j];
+          rank += (nj > ni) || (nj == ni && j < i);
+        }
+        s_sread[rank] = s_read[i];
+        s_sneed[rank] = ni;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // best fit: lane f owns the stack of open bins with exactly f free lanes (linked through s_next), a wave-uniform
+      // bit mask says which stacks are non-empty -- the smallest free size that fits is one ctz away
+      int head = -1;
+      uint64_t avail = 0;
+      int nb = 0;  // bins opened so far
+      const int need_lo = lane < cnt ? s_sneed[lane] : 0, need_hi = lane + kLanes < cnt ? s_sneed[lane + kLanes] : 0;
+      for (int i = 0; i < cnt; i++) {
+        const int nn = __builtin_amdgcn_readlane(i < kLanes ? need_lo : need_hi, i & 63);  // 1..64
+        const uint64_t fits = nn >= kLanes ? 0ull : (avail >> nn) << nn;
+        int bin, f;
+        if (fits) {
+          f = __builtin_ctzll(fits);
+          bin = __builtin_amdgcn_readlane(head, f);
+          const int nxt = __builtin_amdgcn_readfirstlane(s_next[bin]);
+          if (lane == f) head = nxt;
+          if (nxt < 0) avail &= ~(1ull << f);
+        } else {
+          bin = nb++;
+          f = kLanes;
+        }
+        const int left = f - nn;
+        if (left > 0) {
+          const int old = __builtin_amdgcn_readlane(head, left);
+          if (lane == 0) s_next[bin] = old;
+          if (lane == left) head = bin;
+          avail |= 1ull << left;
+        }
+        if (lane == 0) { s_bin[i] = bin; s_off[i] = kLanes - f; }
+      }
+      int base = 0;
+      if (lane == 0) base = atomicAdd(a.cnts + 5, nb);
+      base = __shfl(base, 0, kLanes);
+      __builtin_amdgcn_wave_barrier();
+      LaneSlot idle; idle.read = -1; idle.block = 0;
+      for (int i = lane; i < nb * kLanes; i += kLanes) a.lanes2[(int64_t)base * kLanes + i] = idle;
+      __builtin_amdgcn_wave_barrier();  // (same wavefront wrote the idle slots: program order per lane is not enough across lanes)
+      __threadfence_block();
+      for (int i = 0; i < cnt; i++)
+        for (int b = lane; b < s_sneed[i]; b += kLanes) {
+          LaneSlot sl; sl.read = s_sread[i]; sl.block = b;
+          a.lanes2[(int64_t)(base + s_bin[i]) * kLanes + s_off[i] + b] = sl;
+        }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  grid_barrier(bar, target);
+  stamp(3);
+
+  // ---- J: jobs = needed haplotype runs per chunk, one wavefront per chunk ----
+  {
+    const int total = ld_cnt(a.cnts + 5);
+    // Job length.  A run is at most a stream group (~2048 columns); a big batch has thousands of them and the
+    // longest-first order keeps the tail short.  A small one (an eighth of a batch on each of 8 GPUs, a GATK region)
+    // would hand a few hundred long jobs to 3072 wavefront slots -- one wavefront per SIMD issues an instruction only
+    // every ~6 cycles -- so runs are cut to about (estimated wave-steps of the pass / wanted_jobs) columns:
+    // wave-steps ~ chunks x all columns x the fraction of (affected read, haplotype) pairs that were flagged.
+    const int n_fail_reads = ld_cnt(a.cnts + 4);
+    const double density = (double)n_fail / ((double)max(n_fail_reads, 1) * (double)a.n_haps);
+    const double est_steps = (double)max(total, 1) * (double)a.total_cols * fmin(density, 1.0);
+    const int cut_cols = max(a.min_job_cols, (int)fmin(est_steps / (double)a.wanted_jobs, 1e9));
+    const int n_waves = nblk * (kPlanBlock / 64), w = blk * (kPlanBlock / 64) + wave;
+    for (int c = w; c < total; c += n_waves) build_jobs_for_chunk(a, a.lanes2, c, a.jobs, a.cnts + 2, cut_cols, lane);
+    for (int c = w; c < a.n_long; c += n_waves) build_jobs_for_chunk(a, a.long_lanes, c, a.jobs_long, a.cnts + 8, 0x7fffffff, lane);
+  }
+  grid_barrier(bar, target);
+  stamp(4);
+
+  // ---- O: order the jobs longest first (block 0) ----
+  if (blk != 0) return;
+  {
+    int32_t* cnt = s_i32;                // [kJobClasses]
+    int32_t* base = s_i32 + kJobClasses; // [kJobClasses]
+    const int n = ld_cnt(a.cnts + 2);
+    __syncthreads();
+    if (tid < kJobClasses) cnt[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kPlanBlock) atomicAdd(&cnt[job_class(a.jobs[i], a.hap_pos, a.hap_len)], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int c = 0; c < kJobClasses; c++) { base[c] = acc; acc += cnt[c]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kPlanBlock) {
+      const FwdJob j = a.jobs[i];
+      a.sorted[atomicAdd(&base[job_class(j, a.hap_pos, a.hap_len)], 1)] = j;
+    }
+  }
+  stamp(5);
 }
 
 }  // namespace gklhip

@@ -75,7 +75,8 @@ struct LaneSlot {  // one lane of a chunk: which read it holds, and which RPL-ro
 };
 
 struct FwdJob {  // one wave job of the job-list pass: stream haps [hap_begin, hap_end) through a chunk
-  int32_t chunk, hap_begin, hap_end, pad_;
+  int32_t chunk, hap_begin, hap_end;
+  int32_t solo;  // != 0: `chunk` is a READ index and the wavefront holds that read alone (no lane table)
 };
 
 template <typename T>
@@ -86,9 +87,8 @@ struct FwdArgs {
   const int32_t* hap_len;   // [n_haps] stream order
   const int32_t* hap_pos;   // [n_haps] stream index of column 1, stream order
   const int32_t* hap_orig;  // [n_haps] stream order -> caller's hap index
-  const int32_t* hap_sidx;  // [n_haps] caller's hap index -> stream order
   const T* y0;              // [n_haps] stream order: INITIAL_CONSTANT / (T)haplen (host-computed)
-  const uint8_t* hap_has_n; // [n_haps] stream order: the haplotype contains an 'N' (set by build_stream_kernel)
+  const uint8_t* hap_has_n; // [n_haps] stream order: the haplotype contains an 'N' (set by prep_kernel)
   const HapGroup* groups;
   int32_t n_groups;
   const LaneSlot* chunk_lanes;  // [n_chunks * 64]
@@ -101,62 +101,23 @@ struct FwdArgs {
 };
 
 // ---- cross-lane helpers -----------------------------------------------------
-// wave_shr:1 (DPP ctrl 0x138): lane L reads lane L-1 across the whole wavefront;
-// lane 0 keeps `old` (bound_ctrl off) or reads 0 (bound_ctrl on).
-//
-// GKL_DPP_NOP=1 writes the DPP ops as inline asm that always carries an `s_nop 1` (in
-// tools/ubench_mix.hip a DPP op straight behind VALU work costs ~11 extra cycles, behind an
-// s_nop none).  In the real kernels it measured neutral (single chunk) to -4 % (dual chunk),
-// so the compiler-scheduled builtin stays the default.  (Also measured neutral, +-1.5 %: issuing
-// step u+1's entry shift and LDS prior reads ahead of step u's arithmetic -- LDS latency is
-// already hidden by the other waves; and the LDS-crossbar ds_bpermute instead of DPP.)
-#ifndef GKL_DPP_NOP
-#define GKL_DPP_NOP 0
-#endif
+// wave_shr:1 (DPP ctrl 0x138): lane L reads lane L-1 across the whole wavefront; lane 0 reads 0
+// (bound_ctrl on) or keeps `old` (bound_ctrl off).
 __device__ __forceinline__ uint32_t dpp_shr1_keep(uint32_t old, uint32_t src) {
-  if (GKL_DPP_NOP) {
-    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
-    return old;
-  }
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138, 0xf, 0xf, false);
 }
 __device__ __forceinline__ uint32_t dpp_shr1_zero(uint32_t src) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x138, 0xf, 0xf, true);
 }
-// (lane above) & mask in one instruction
-__device__ __forceinline__ uint32_t dpp_shr1_and(uint32_t src, uint32_t mask) {
-  if (GKL_DPP_NOP) {
-    uint32_t d;
-    asm volatile("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                 : "=v"(d) : "v"(src), "v"(mask));
-    return d;
-  }
-  return dpp_shr1_zero(src) & mask;
-}
-// value of the lane above, ANDed with this lane's mask (0 for lanes that start a
-// read or are idle, ~0 otherwise).
-#ifndef GKL_ABL
-#define GKL_ABL 0  // timing ablations for tools/ablate.sh (results are WRONG when != 0)
-#endif
-#ifndef GKL_XLANE
-#define GKL_XLANE 0  // 0: DPP wave_shr:1 (VALU)   1: ds_bpermute_b32 (LDS crossbar, no LDS memory)
-#endif
-__device__ __forceinline__ uint32_t lane_above_u32(uint32_t v) {
-  if (GKL_XLANE == 1) {
-    const int src = (int)((__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) - 1u) & 63u) << 2;
-    return (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v);
-  }
-  return dpp_shr1_zero(v);
-}
+// value of the lane above, ANDed with this lane's mask (0 for lanes that start a read or are
+// idle, ~0 otherwise); the compiler folds the AND into the DPP op (v_and_b32_dpp).
 __device__ __forceinline__ float recv_above(float v, uint32_t lmask) {
-  if (GKL_ABL == 1) return __uint_as_float(__float_as_uint(v) & lmask);
-  if (GKL_XLANE == 0) return __uint_as_float(dpp_shr1_and(__float_as_uint(v), lmask));
-  return __uint_as_float(lane_above_u32(__float_as_uint(v)) & lmask);
+  return __uint_as_float(dpp_shr1_zero(__float_as_uint(v)) & lmask);
 }
 __device__ __forceinline__ double recv_above(double v, uint32_t lmask) {
   const uint64_t u = (uint64_t)__double_as_longlong(v);
-  const uint32_t lo = GKL_XLANE == 0 ? dpp_shr1_and((uint32_t)u, lmask) : (lane_above_u32((uint32_t)u) & lmask);
-  const uint32_t hi = GKL_XLANE == 0 ? dpp_shr1_and((uint32_t)(u >> 32), lmask) : (lane_above_u32((uint32_t)(u >> 32)) & lmask);
+  const uint32_t lo = dpp_shr1_zero((uint32_t)u) & lmask;
+  const uint32_t hi = dpp_shr1_zero((uint32_t)(u >> 32)) & lmask;
   return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
@@ -201,8 +162,8 @@ __device__ __forceinline__ T m_inner(T md, T xd, T yd, T pmm, T pgapm) {
 // ---- the per-wave job ---------------------------------------------------------
 template <typename T, int RPL, bool FMA>
 struct WaveJob {
-  static constexpr int kVecBytes = 16;
-  static constexpr int kPerVec = kVecBytes / (int)sizeof(T);        // rows per 16-byte LDS vector
+  static constexpr int kVecBytes = RPL * (int)sizeof(T) < 16 ? RPL * (int)sizeof(T) : 16;
+  static constexpr int kPerVec = kVecBytes / (int)sizeof(T);        // rows per LDS vector (16 bytes; 8 for two fp32 rows per lane)
   static constexpr int kPlanes = RPL / kPerVec;                      // 16-byte vectors per lane per code
   static constexpr int kRowBytes = kPlanes * kLanes * kVecBytes;     // one base code, all rows
   // Prior table: one plane per haplotype base code.  fp32 keeps five (A C T G N = 10 KB, 4 wavefronts per SIMD
@@ -386,17 +347,14 @@ struct WaveJob {
 
   // Fast step: every lane is inside a haplotype (entry = base code 0..4).
   __device__ __forceinline__ void step_fast(uint32_t entry, int lane) {
-    if (GKL_ABL == 4) ent = entry; else
     shift_entry(entry);
     T pr[RPL], nM[RPL], nX[RPL], nY[RPL];
-    if (GKL_ABL == 2) { for (int s = 0; s < RPL; s++) pr[s] = pMM[s]; } else
     load_priors(ent, lane, pr);
     advance(pr, nM, nX, nY);
 #pragma unroll
     for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
     dM = rM; dX = rX; dY = rY;
     fetch_above();
-    if (GKL_ABL == 3) return;
     sM = sM + nM[RPL - 1];  // ascending-column sums (:354-369)
     sX = sX + nX[RPL - 1];
   }
@@ -430,7 +388,7 @@ struct WaveJob {
     advance(pr, nM, nX, nY);
     const T tM = sM + nM[RPL - 1], tX = sX + nX[RPL - 1];  // on a separator both addends are 0
     T y0n = T(0);
-    if (GKL_ABL != 6 && sep) {
+    if (sep) {
       const int k = (int)(ent & 0x7fffffffu);
       if (k == k_cur) {  // k_cur is always inside [hap_begin, hap_end)
         if (out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + orig_cur] = sM + sX;
@@ -513,9 +471,9 @@ struct WaveJob {
 #pragma unroll
       for (int u = 0; u < V; u++) e[u] = sp[t + u];
 #pragma unroll
-      for (int u = 0; u < V; u++) { if (GKL_ABL == 5) step_fast(e[u] & 3u, lane); else step_any(a, e[u], lane, hap_begin, hap_end, k_cur, orig_cur, y0_next); }
+      for (int u = 0; u < V; u++) step_any(a, e[u], lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
     }
-    for (; t < end; t++) { if (GKL_ABL == 5) step_fast(sp[t] & 3u, lane); else step_any(a, sp[t], lane, hap_begin, hap_end, k_cur, orig_cur, y0_next); }
+    for (; t < end; t++) step_any(a, sp[t], lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
   }
 
   // One 64-lane STRIPE of a read that is longer than a chunk (the reference's stripe loop with
@@ -560,230 +518,6 @@ struct WaveJob {
   }
 };
 
-// ---- the dual-chunk fp32 job: packed math ------------------------------------
-// Two independent 64-lane chunks share one wavefront: lane L holds RPL rows of chunk A
-// and RPL rows of chunk B as float2 register pairs (A in .x, B in .y).  Both chunks see
-// the same haplotype stream, so every operation of the recurrence is the same
-// instruction on naturally aligned pairs -> v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32
-// with no shuffles (a single chunk cannot be packed: row s needs row s-1, which is
-// never pair-aligned with it).  Same arithmetic per element, hence the same bits.
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ v2f fma_v(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-template <bool FMA>
-__device__ __forceinline__ v2f mul_add2_v(v2f a, v2f b, v2f c, v2f d) {
-  if (FMA) return fma_v(a, b, c * d);
-  return c * d + a * b;
-}
-template <bool FMA>
-__device__ __forceinline__ v2f m_inner_v(v2f md, v2f xd, v2f yd, v2f pmm, v2f pgapm) {
-  if (FMA) return fma_v(yd, pgapm, fma_v(xd, pgapm, md * pmm));
-  return (md * pmm + xd * pgapm) + yd * pgapm;
-}
-
-template <int RPL, bool FMA>
-struct WaveJob2 {
-  static_assert(RPL % 2 == 0, "two rows x two chunks fill one 16-byte LDS vector");
-  static constexpr int kPlanes = RPL / 2;                 // float4 = (A[2p], B[2p], A[2p+1], B[2p+1])
-  static constexpr int kRowBytes = kPlanes * kLanes * 16;  // one base code
-  static constexpr int kLdsBytes = 5 * kRowBytes;  // codes A C T G N; idle columns are handled in step_any
-  typedef float v4f __attribute__((ext_vector_type(4)));
-
-  v2f M[RPL], X[RPL], Y[RPL];
-  v2f pMM[RPL], pGAPM[RPL], pMX[RPL], pXX[RPL], pMY[RPL];
-  v2f dM, dX, dY, rM, rX, rY, sM, sX;
-  uint32_t ent;
-  uint32_t lmask[2];
-  int32_t out_read[2];
-  int32_t padb_slot[2];
-  unsigned char* lds;
-
-  // rows of ONE chunk's lane (same layout rules as WaveJob::setup)
-  __device__ __forceinline__ void load_rows(const FwdArgs<float>& a, LaneSlot slot, int which, float* match,
-                                            float* mism, int* code) {
-    int R = 0, first = 0;
-    int64_t roff = 0;
-    out_read[which] = -1;
-    padb_slot[which] = -1;
-    lmask[which] = 0u;
-    if (slot.read >= 0) {
-      roff = a.b.read_off[slot.read];
-      R = (int)(a.b.read_off[slot.read + 1] - roff);
-      const int n_blocks = (R + RPL) / RPL;
-      const int pads = n_blocks * RPL - R;
-      first = slot.block * RPL - pads;
-      if (slot.block == n_blocks - 1) out_read[which] = slot.read;
-      if (slot.block != 0) lmask[which] = ~0u;
-    }
-#pragma unroll
-    for (int s = 0; s < RPL; s++) {
-      const int v = first + s;
-      float mm = 0.f, gapm = 0.f, mx = 0.f, xx = 0.f, my = 0.f;
-      match[s] = mism[s] = 0.f;
-      code[s] = -1;
-      if (slot.read >= 0 && v >= 0) {
-        const int64_t at = roff + v;
-        const int qi = a.b.ins[at] & 127, qd = a.b.del[at] & 127, qc = a.b.gcp[at] & 127;
-        const int qq = a.b.read_quals[at] & 127;
-        const int hi = qi > qd ? qi : qd, lo = qi > qd ? qd : qi;
-        mm = a.tab.mm[((hi * (hi + 1)) >> 1) + lo];
-        const float pc = a.tab.ph2pr[qc];
-        gapm = 1.0f - pc;
-        mx = a.tab.ph2pr[qi];
-        xx = pc;
-        my = a.tab.ph2pr[qd];
-        match[s] = 1.0f - a.tab.ph2pr[qq];
-        mism[s] = a.tab.div3[qq];
-        const uint8_t bb = a.b.read_bases[at];
-        code[s] = bb == 'C' ? 1 : bb == 'T' ? 2 : bb == 'G' ? 3 : bb == 'N' ? 4 : 0;
-      } else if (slot.read >= 0 && v == -1) {
-        xx = 1.0f;
-        padb_slot[which] = s;
-      }
-      pMM[s][which] = mm; pGAPM[s][which] = gapm; pMX[s][which] = mx; pXX[s][which] = xx; pMY[s][which] = my;
-    }
-  }
-
-  __device__ __forceinline__ void setup(const FwdArgs<float>& a, int lane, LaneSlot sa, LaneSlot sb) {
-    float matchA[RPL], mismA[RPL], matchB[RPL], mismB[RPL];
-    int codeA[RPL], codeB[RPL];
-    load_rows(a, sa, 0, matchA, mismA, codeA);
-    load_rows(a, sb, 1, matchB, mismB, codeB);
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-#pragma unroll
-      for (int pl = 0; pl < kPlanes; pl++) {
-        v4f v;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-          const int s = pl * 2 + k;
-          const bool hitA = (c == codeA[s]) || (c == 4) || (codeA[s] == 4);
-          const bool hitB = (c == codeB[s]) || (c == 4) || (codeB[s] == 4);
-          v[2 * k + 0] = codeA[s] < 0 ? 0.f : (hitA ? matchA[s] : mismA[s]);
-          v[2 * k + 1] = codeB[s] < 0 ? 0.f : (hitB ? matchB[s] : mismB[s]);
-        }
-        *reinterpret_cast<v4f*>(lds + c * kRowBytes + pl * (kLanes * 16) + lane * 16) = v;
-      }
-    }
-  }
-
-  __device__ __forceinline__ void reset_state(float y0) {
-#pragma unroll
-    for (int s = 0; s < RPL; s++) {
-      M[s] = X[s] = v2f{0.f, 0.f};
-      Y[s] = v2f{s == padb_slot[0] ? y0 : 0.f, s == padb_slot[1] ? y0 : 0.f};
-    }
-    dM = dX = dY = sM = sX = v2f{0.f, 0.f};
-    ent = kEntIdle;
-    fetch_above();
-  }
-
-  __device__ __forceinline__ void fetch_above() {
-    rM = recv2(M[RPL - 1]);
-    rX = recv2(X[RPL - 1]);
-    rY = recv2(Y[RPL - 1]);
-  }
-
-  __device__ __forceinline__ void load_priors(uint32_t code, int lane, v2f* pr) const {
-    const unsigned char* p = lds + code * (uint32_t)kRowBytes + (uint32_t)lane * 16;
-#pragma unroll
-    for (int pl = 0; pl < kPlanes; pl++) {
-      const v4f v = *reinterpret_cast<const v4f*>(p + pl * (kLanes * 16));
-      pr[2 * pl] = v2f{v[0], v[1]};
-      pr[2 * pl + 1] = v2f{v[2], v[3]};
-    }
-  }
-
-  __device__ __forceinline__ v2f recv2(v2f v) const {
-    return v2f{recv_above(v.x, lmask[0]), recv_above(v.y, lmask[1])};
-  }
-
-  __device__ __forceinline__ void advance(const v2f* pr, v2f* nM, v2f* nX, v2f* nY) const {
-    nM[0] = m_inner_v<FMA>(dM, dX, dY, pMM[0], pGAPM[0]) * pr[0];
-#pragma unroll
-    for (int s = 1; s < RPL; s++)
-      nM[s] = m_inner_v<FMA>(M[s - 1], X[s - 1], Y[s - 1], pMM[s], pGAPM[s]) * pr[s];
-#pragma unroll
-    for (int s = 0; s < RPL; s++) nY[s] = mul_add2_v<FMA>(Y[s], pXX[s], M[s], pMY[s]);
-    nX[0] = mul_add2_v<FMA>(rX, pXX[0], rM, pMX[0]);
-#pragma unroll
-    for (int s = 1; s < RPL; s++) nX[s] = mul_add2_v<FMA>(nX[s - 1], pXX[s], nM[s - 1], pMX[s]);
-  }
-
-  __device__ __forceinline__ void step_fast(uint32_t entry, int lane) {
-    if (GKL_ABL == 4) ent = entry; else
-    ent = dpp_shr1_keep(entry, ent);
-    v2f pr[RPL], nM[RPL], nX[RPL], nY[RPL];
-    if (GKL_ABL == 2) { for (int s = 0; s < RPL; s++) pr[s] = pMM[s]; } else
-    load_priors(ent, lane, pr);
-    advance(pr, nM, nX, nY);
-#pragma unroll
-    for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
-    dM = rM; dX = rX; dY = rY;
-    fetch_above();
-    if (GKL_ABL == 3) return;
-    sM = sM + nM[RPL - 1];
-    sX = sX + nX[RPL - 1];
-  }
-
-  __device__ __forceinline__ void step_any(const FwdArgs<float>& a, uint32_t entry, int lane, int hap_begin,
-                                           int hap_end) {
-    ent = dpp_shr1_keep(entry, ent);
-    const bool sep = (int32_t)ent < 0;
-    const bool off = sep || ent == kEntIdle;
-    v2f pr[RPL], nM[RPL], nX[RPL], nY[RPL];
-    load_priors(off ? 0u : ent, lane, pr);
-#pragma unroll
-    for (int s = 0; s < RPL; s++) pr[s] = off ? v2f{0.f, 0.f} : pr[s];
-    advance(pr, nM, nX, nY);
-    if (sep) {
-      const int k = (int)(ent & 0x7fffffffu);
-      const bool mine = (k >= hap_begin) && (k < hap_end);
-      const v2f tot = sM + sX;
-      if (mine && out_read[0] >= 0) a.raw[(int64_t)out_read[0] * a.b.n_haps + a.hap_orig[k]] = tot.x;
-      if (mine && out_read[1] >= 0) a.raw[(int64_t)out_read[1] * a.b.n_haps + a.hap_orig[k]] = tot.y;
-      const float y0n = (mine && k + 1 < hap_end) ? a.y0[k + 1] : 0.f;
-#pragma unroll
-      for (int s = 0; s < RPL; s++) {
-        M[s] = X[s] = v2f{0.f, 0.f};
-        Y[s] = v2f{s == padb_slot[0] ? y0n : 0.f, s == padb_slot[1] ? y0n : 0.f};
-      }
-      sM = sX = v2f{0.f, 0.f};
-    } else {
-#pragma unroll
-      for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
-      sM = sM + nM[RPL - 1];
-      sX = sX + nX[RPL - 1];
-    }
-    dM = rM; dX = rX; dY = rY;
-    fetch_above();
-  }
-
-  __device__ __forceinline__ void run(const FwdArgs<float>& a, int lane, int hap_begin, int hap_end) {
-    constexpr int U = 8;
-    const int sb = a.hap_pos[hap_begin];
-    const uint32_t* __restrict__ sp = a.stream + sb;
-    reset_state(a.y0[hap_begin]);
-    int t = 0;
-    int fast_from = kLanes - 1;
-    for (int k = hap_begin; k < hap_end; k++) {
-      const int sep_at = a.hap_pos[k] - sb + a.hap_len[k];
-      const int slow_end = fast_from < sep_at ? fast_from : sep_at;
-      for (; t < slow_end; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
-      for (; t + U <= sep_at; t += U) {
-        uint32_t e[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) e[u] = sp[t + u];
-#pragma unroll
-        for (int u = 0; u < U; u++) step_fast(e[u], lane);
-      }
-      for (; t < sep_at; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
-      fast_from = sep_at + kLanes;
-    }
-    for (; t < fast_from; t++) step_any(a, sp[t], lane, hap_begin, hap_end);
-  }
-};
-
 // ---- kernels -------------------------------------------------------------------
 // Main pass: block (one wavefront) = (chunk of packed reads) x (haplotype group).
 template <typename T, int RPL, bool FMA>
@@ -801,28 +535,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
   job.run(a, lane, grp.hap_begin, grp.hap_end);
 }
 
-// Main fp32 pass, packed: block = (two chunks of packed reads) x (haplotype group).
-template <int RPL, bool FMA>
-__global__ __launch_bounds__(64) void pairhmm_fwd_stream2_kernel(FwdArgs<float> a) {
-  using Job = WaveJob2<RPL, FMA>;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
-  const int lane = threadIdx.x;
-  const int n_pairs_of_chunks = (a.n_chunks + 1) / 2;
-  const int g = blockIdx.x / n_pairs_of_chunks;
-  const int pair = blockIdx.x - g * n_pairs_of_chunks;
-  const HapGroup grp = a.groups[g];
-  const int ca = 2 * pair, cb = 2 * pair + 1;
-  LaneSlot sa = a.chunk_lanes[(int64_t)ca * kLanes + lane];
-  LaneSlot sb;
-  sb.read = -1; sb.block = 0;
-  if (cb < a.n_chunks) sb = a.chunk_lanes[(int64_t)cb * kLanes + lane];
-  Job job;
-  job.lds = lds;
-  job.setup(a, lane, sa, sb);
-  __syncthreads();
-  job.run(a, lane, grp.hap_begin, grp.hap_end);
-}
-
 // Job-list pass (packed fp64 recomputation): persistent wavefronts pull (chunk, haplotype run)
 // jobs built on the device from the fallback flags; chunks come from a second read packing
 // that groups reads with similar fallback patterns.
@@ -834,18 +546,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
   const int n = *a.job_count;
   Job job;
   job.lds = lds;
-  int loaded_chunk = -1;
+  int loaded_chunk = INT32_MIN;
   for (;;) {
     int idx = 0;
     if (lane == 0) idx = atomicAdd(a.job_next, 1);
     idx = __builtin_amdgcn_readfirstlane(idx);
     if (idx >= n) break;
     const FwdJob j = a.jobs[idx];
-    if (j.chunk != loaded_chunk) {
+    const int chunk_id = j.solo ? ~j.chunk : j.chunk;
+    if (chunk_id != loaded_chunk) {
+      LaneSlot slot;
+      if (j.solo) {  // the read alone in the wavefront: lanes 0 .. ceil((R+1)/RPL)-1 hold its row blocks
+        const int R = (int)(a.b.read_off[j.chunk + 1] - a.b.read_off[j.chunk]);
+        slot.read = lane < (R + RPL) / RPL ? j.chunk : -1;
+        slot.block = lane;
+      } else {
+        slot = a.chunk_lanes[(int64_t)j.chunk * kLanes + lane];
+      }
       __syncthreads();  // previous job's LDS reads are done
-      job.setup(a, lane, a.chunk_lanes[(int64_t)j.chunk * kLanes + lane]);
+      job.setup(a, lane, slot);
       __syncthreads();
-      loaded_chunk = j.chunk;
+      loaded_chunk = chunk_id;
     }
     job.run(a, lane, j.hap_begin, j.hap_end);
   }

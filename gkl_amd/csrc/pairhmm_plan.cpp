@@ -1,6 +1,7 @@
 #include "pairhmm_plan.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace gklhip {
@@ -22,6 +23,7 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   p.hap_orig.resize(n_haps);
   p.hap_sidx.resize(n_haps);
   p.hap_group.resize(n_haps);
+  p.hap_src.resize(n_haps);
   int64_t total_cols = 0;
   std::iota(p.hap_orig.begin(), p.hap_orig.end(), 0);
   std::stable_sort(p.hap_orig.begin(), p.hap_orig.end(), [&](int32_t a, int32_t b) {
@@ -48,7 +50,9 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
       if (nb <= kLanes) blocks += nb;
     }
     const int64_t chunks_est = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
-    const int64_t by_jobs = (kWantedJobs + chunks_est - 1) / chunks_est;
+    static const int wanted_env = [] { const char* v = getenv("GKLHIP_WANTED_JOBS"); return v ? atoi(v) : 0; }();
+    const int64_t wanted = wanted_env > 0 ? wanted_env : kWantedJobs;
+    const int64_t by_jobs = (wanted + chunks_est - 1) / chunks_est;
     if (by_jobs >= n_groups) n_groups = (int)by_jobs;
     else equal_split = false;
   }
@@ -67,30 +71,28 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
     want.assign((size_t)n_big, (head + n_big - 1) / n_big);
     want.insert(want.end(), tail, tail + 4);
   }
-  p.stream_src.reserve((size_t)total_cols + (want.size() + (size_t)n_haps / 8 + 2) * kLanes);
   {
     int h = 0;
     size_t gi = 0;
     while (h < n_haps) {
       PlanGroup g;
       g.hap_begin = h;
-      g.stream_begin = (int32_t)p.stream_src.size();
+      g.stream_begin = p.n_stream;
       g.pad_ = 0;
       int64_t cols = 0;
       const bool last = gi + 1 >= want.size();
       const int64_t share = want[std::min(gi, want.size() - 1)];
       // at least one haplotype per group; stop once the group reached its share (the last group takes the rest)
       do {  // h is a stream-order index here
-        p.hap_pos[h] = (int32_t)p.stream_src.size();
+        p.hap_pos[h] = p.n_stream;
         p.hap_group[h] = (int32_t)p.groups.size();
-        const int64_t base = hap_off[p.hap_orig[h]];
-        for (int c = 0; c < p.hap_len[h]; c++) p.stream_src.push_back((int32_t)(base + c));
-        p.stream_src.push_back(-2 - h);  // separator of stream-order hap h
+        p.hap_src[h] = (int32_t)hap_off[p.hap_orig[h]];
+        p.n_stream += p.hap_len[h] + 1;  // columns + separator
         cols += p.hap_len[h] + 1;
         h++;
       } while (h < n_haps && (last || cols + (p.hap_len[h] + 1) / 2 < share));
       g.hap_end = h;
-      for (int i = 0; i < kLanes; i++) p.stream_src.push_back(-1);  // drain room
+      p.n_stream += kLanes;  // drain room (idle entries)
       p.groups.push_back(g);
       gi++;
     }

@@ -29,8 +29,10 @@ struct Plan {
   std::vector<int32_t> hap_orig;    // stream order -> caller index
   std::vector<int32_t> hap_sidx;    // caller index -> stream order
   std::vector<int32_t> hap_group;   // stream order -> index into groups
-  // stream source: >= 0 index into hap_bases; -1 idle; <= -2 separator of stream hap (-2-k)
-  std::vector<int32_t> stream_src;
+  std::vector<int32_t> hap_src;     // stream order: offset of the haplotype's first base in hap_bases
+  // Stream layout (built on the device by prep_kernel): per group, for each of its haplotypes hap_len column
+  // entries + 1 separator, then 64 idle entries of drain room.
+  int32_t n_stream = 0;             // total stream entries
   std::vector<int32_t> long_reads;  // reads with more than 64*rows_per_lane-1 bases: striped kernel
   int64_t useful_rows = 0;
   int max_read_len = 0;

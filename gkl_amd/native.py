@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgklhip_pairhmm.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_OOM, ERR_HIP, ERR_UNSUPPORTED = range(6)
 FINALIZE_REFERENCE_HOST, FINALIZE_DEVICE_F64, FINALIZE_DEVICE_REF32 = 0, 1, 2
 
@@ -75,6 +75,16 @@ def load_library(path: Optional[str] = None):
     lib.gklhip_last_error.restype = C.c_char_p
     lib.gklhip_init.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     lib.gklhip_init.restype = C.c_int
+    lib.gklhip_init_devices.argtypes = [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.gklhip_init_devices.restype = C.c_int
+    lib.gklhip_num_devices.argtypes = [C.c_void_p]
+    lib.gklhip_num_devices.restype = C.c_int
+    lib.gklhip_gather_backend.argtypes = [C.c_void_p]
+    lib.gklhip_gather_backend.restype = C.c_int
+    lib.gklhip_partition_reads.argtypes = [C.c_int32, _i64p, C.c_int32, C.POINTER(C.c_int32)]
+    lib.gklhip_partition_reads.restype = C.c_int
+    lib.gklhip_rccl_selftest.argtypes = [C.c_int32]
+    lib.gklhip_rccl_selftest.restype = C.c_int
     lib.gklhip_done.argtypes = [C.c_void_p]
     lib.gklhip_done.restype = C.c_int
     lib.gklhip_compute.argtypes = [C.c_void_p, C.POINTER(CBatch), C.c_void_p]
@@ -145,21 +155,52 @@ class DeviceBatch:
                       self.hap_off.ctypes.data_as(_i64p), *[x.data_ptr() for x in t])
 
 
+def partition_reads(read_off, n_parts: int):
+    """The library's sharding rule (gklhip_partition_reads): boundaries of contiguous read ranges balanced by cells."""
+    lib = load_library()
+    ro = np.ascontiguousarray(read_off, np.int64)
+    bounds = (C.c_int32 * (n_parts + 1))()
+    st = lib.gklhip_partition_reads(ro.size - 1, ro.ctypes.data_as(_i64p), n_parts, bounds)
+    if st != OK:
+        _raise(lib, st)
+    return list(bounds)
+
+
+def rccl_selftest(device: int = 0) -> None:
+    lib = load_library()
+    st = lib.gklhip_rccl_selftest(device)
+    if st != OK:
+        _raise(lib, st)
+
+
 class PairHmmContext:
-    """One gklhip context (= one initNative)."""
+    """One gklhip context (= one initNative).  `devices` = a list of device ordinals: every call is sharded over
+    them inside the library (a device may appear twice)."""
 
     def __init__(self, use_double: bool = False, max_threads: int = 1, device: int = -1,
                  fma_mode: int = 1, finalize: int = -1, record_events: bool = False,
-                 rows_per_lane: int = 0, lib_path: Optional[str] = None):
+                 rows_per_lane: int = 0, lib_path: Optional[str] = None, devices=None):
         self.lib = load_library(lib_path)
         cfg = Config(ABI_VERSION, device, int(use_double), int(max_threads), int(fma_mode),
                      int(finalize), int(record_events), int(rows_per_lane))
         h = C.c_void_p()
-        st = self.lib.gklhip_init(C.byref(cfg), C.byref(h))
+        if devices:
+            arr = (C.c_int32 * len(devices))(*devices)
+            st = self.lib.gklhip_init_devices(C.byref(cfg), arr, len(devices), C.byref(h))
+        else:
+            st = self.lib.gklhip_init(C.byref(cfg), C.byref(h))
         if st != OK:
             _raise(self.lib, st)
         self.handle = h
         self.use_double = bool(use_double)
+
+    @property
+    def n_devices(self) -> int:
+        return self.lib.gklhip_num_devices(self.handle)
+
+    @property
+    def gather_backend(self) -> str:
+        return ("none", "peer", "rccl")[self.lib.gklhip_gather_backend(self.handle)]
 
     def close(self):
         if getattr(self, "handle", None):

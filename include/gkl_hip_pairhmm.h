@@ -19,6 +19,9 @@
  *                          avx-pairhmm-template.h:235-372
  *   gklhip_compute_device  same, with the batch already resident in HBM
  *   gklhip_done            doneNative: IntelPairHmm.cc:189-192
+ *   gklhip_init_devices    same as gklhip_init for a LIST of devices: every call is then cut into contiguous
+ *                          read ranges balanced by cells, one per device -- what the reference's OpenMP
+ *                          `schedule(dynamic,1)` loop over pairs (IntelPairHmm.cc:151-154) is to its cores
  *
  * The flat batch replaces the std::vector<testcase> that JavaData::getData builds
  * (JavaData.h:65-111; testcase = pairhmm_common.h:43-47): reads x haplotypes cross
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GKLHIP_ABI_VERSION 1
+#define GKLHIP_ABI_VERSION 2
 
 typedef struct gklhip_ctx gklhip_ctx; /* opaque; one per initNative */
 
@@ -68,7 +71,8 @@ typedef struct {
   int32_t abi_version;  /* GKLHIP_ABI_VERSION */
   int32_t device;       /* HIP device ordinal, -1 = current device */
   int32_t use_double;   /* PairHMMNativeArguments.useDoublePrecision (IntelPairHmm.cc:70) */
-  int32_t max_threads;  /* maxNumberOfThreads: host threads for the reference-exact finalize */
+  int32_t max_threads;  /* maxNumberOfThreads: host threads for the reference-exact finalize; <= 1 (the reference's
+                           default) = not set: min(cores, 8), or GKL_HIP_FINALIZE_THREADS */
   int32_t fma_mode;     /* 1 = arithmetic of GKL's AVX-512 objects (gcc-contracted FMA; default),
                            0 = arithmetic of GKL's AVX objects (separate mul/add) */
   int32_t finalize;     /* gklhip_finalize for gklhip_compute_device; -1 = default */
@@ -76,7 +80,7 @@ typedef struct {
                            2 = record into a ring of 64 event sets WITHOUT synchronising: calls pipeline, the
                                times are read afterwards with gklhip_get_step_times */
   int32_t rows_per_lane;/* fp32 main kernel: 0 = auto (8 rows per lane; 4 for small batches), 8 = 8-row kernel,
-                           4 = the dual-chunk packed-math kernel, -4 = the single-chunk 4-row kernel */
+                           4 = 4-row kernel */
 } gklhip_config;
 
 /* Flat structure-of-arrays batch. Offsets always live on the host; the byte
@@ -111,9 +115,29 @@ typedef struct {
   float lane_fill;         /* useful rows / (chunks * 64 * rows_per_lane) of the main pass */
 } gklhip_stats;
 
-/* Lifecycle. */
+/* Lifecycle.  gklhip_init uses cfg->device; when that is -1 and the environment names a list
+ * (GKL_HIP_DEVICES=0,1,2,...), it is gklhip_init_devices with that list. */
 int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx);
 int gklhip_done(gklhip_ctx* ctx);
+
+/* One context over several devices of this node, driven by this one process (one host thread per extra device).
+ * Every call is sharded by contiguous read ranges balanced by cells (gklhip_partition_reads), haplotypes and tables
+ * replicated.  gklhip_compute: each device copies its range from the caller's host arrays and its results back over
+ * its own PCIe link -- no device-to-device step.  gklhip_compute_device: inputs and the output array live on
+ * devices[0]; the other devices pull their ranges over xGMI and their results are gathered into the output array --
+ * with RCCL (ncclCommInitAll + one ncclSend/ncclRecv pair per device in one group; librccl.so is dlopen()ed by the
+ * first multi-device context) when the devices are distinct, with peer copies otherwise (a device may be listed
+ * twice: two shards on one GPU, what the one-GPU tests do).  GKL_HIP_GATHER=peer|rccl overrides the choice.
+ * devices == NULL or n_devices <= 0: cfg->device alone. */
+int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_t n_devices, gklhip_ctx** out_ctx);
+int gklhip_num_devices(gklhip_ctx* ctx);
+/* 0 = single device (no gather), 1 = peer copies, 2 = RCCL. */
+int gklhip_gather_backend(gklhip_ctx* ctx);
+/* The sharding rule: bounds_out[0] = 0 <= ... <= bounds_out[n_parts] = n_reads, contiguous read ranges whose summed
+ * read lengths (= cells, every range meets every haplotype) are as equal as cut points between reads allow. */
+int gklhip_partition_reads(int32_t n_reads, const int64_t* read_off, int32_t n_parts, int32_t* bounds_out);
+/* Diagnostics: dlopen RCCL and run the gather's send/recv group on a one-device communicator.  0 = ok. */
+int gklhip_rccl_selftest(int32_t device);
 
 /* Host buffers in, host doubles out (n_reads*n_haps). What the JNI shim calls.  The byte arrays
  * are copied to the device asynchronously; when they live in memory from gklhip_host_alloc the
@@ -129,7 +153,8 @@ void gklhip_host_free(void* p);
 
 /* Byte arrays and `out_dev` in HBM; launches on `hip_stream` (a hipStream_t; NULL = HIP's
  * default stream) and returns without a host sync when record_events == 0 (the fp64
- * recomputation pass is planned on the device). One stream per context. */
+ * recomputation pass is planned on the device).  The context's scratch is ordered by that stream; a
+ * call on a different stream than the previous one first waits (on the device) for that one's end. */
 int gklhip_compute_device(gklhip_ctx* ctx, const gklhip_batch* dev_batch, double* out_dev,
                           void* hip_stream);
 

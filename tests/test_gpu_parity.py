@@ -140,10 +140,10 @@ def test_hc_batch_policy_and_tolerance(native, ctx32, ctx64, oracle):
     assert np.mean(ref32 == out) > 0.9
 
 
-@pytest.mark.parametrize("rpl", [4, 8, -4])
+@pytest.mark.parametrize("rpl", [4, 8])
 def test_every_fp32_kernel_variant_bit_exact(native, oracle, rpl):
-    """rows_per_lane 8 = the 8-row kernel (what auto picks for big batches), 4 = dual-chunk packed kernel,
-    -4 = single-chunk 4-row kernel (what auto picks for small batches)."""
+    """rows_per_lane 8 = the 8-row kernel (what auto picks for big batches), 4 = the 4-row kernel (what auto
+    picks for small batches)."""
     b = make_batch("hc", 150, 12, seed=77)
     rng = np.random.RandomState(abs(rpl))
     b2 = random_batch(rng, 30, 7, read_len=(1, 250), hap_len=(1, 90), alphabet=b"ACGTN")
@@ -152,6 +152,30 @@ def test_every_fp32_kernel_variant_bit_exact(native, oracle, rpl):
         check_against_oracle(c, oracle, b)
         assert c.stats()["rows_per_lane"] == abs(rpl)
         check_against_oracle(c, oracle, b2)
+
+
+def test_two_rows_per_lane_and_direct_fp64_jobs(native, oracle):
+    """Small calls whose reads have at most 127 bases run two rows per lane (fp32 pass, and the fp64 pass when every
+    flagged pair is its own job); `rows_per_lane=2` with longer reads falls back to 4."""
+    rng = np.random.RandomState(22)
+    short = random_batch(rng, 40, 9, read_len=(1, 127), hap_len=(20, 200), alphabet=b"ACGTN")
+    with native.PairHmmContext() as c:
+        _, u = check_against_oracle(c, oracle, short)
+        assert c.stats()["rows_per_lane"] == 2 and 0 < u.sum() < u.size
+    for fma in (0, 1):
+        with native.PairHmmContext(rows_per_lane=2, fma_mode=fma) as c:
+            check_against_oracle(c, oracle, short, fma_mode=fma)
+            assert c.stats()["rows_per_lane"] == 2
+            check_against_oracle(c, oracle, make_batch("hc", 60, 8, seed=3), fma_mode=fma)   # reads up to 250 bases
+            assert c.stats()["rows_per_lane"] == 4
+    # direct jobs with six rows per lane (reads longer than 127 bases), N in haplotypes, and a long read that
+    # switches the call back to the packed planner
+    mixed = random_batch(rng, 30, 7, read_len=(100, 380), hap_len=(50, 400), alphabet=b"ACGTN")
+    longb = random_batch(rng, 12, 6, read_len=(300, 500), hap_len=(200, 500), related=False, qual_range=(25, 45))
+    with native.PairHmmContext() as c:
+        check_against_oracle(c, oracle, mixed)
+        _, u = check_against_oracle(c, oracle, longb)
+        assert u.all()
 
 
 def test_auto_picks_the_kernel_by_batch_size(native, oracle):

@@ -115,12 +115,9 @@ def test_jni_concurrent_callers_get_their_own_slot(oracle, n_threads, slots, mon
     assert out.tobytes() == oracle.batch(b, n_threads=8).tobytes()
 
 
-def test_jni_onload_probes_for_a_device(monkeypatch):
+def _check_jni_onload(monkeypatch, have_gpu):
     # JNI_OnLoad (not in the reference): JNI_ERR without a usable gfx950 device, so that System.load fails and
     # NativeLibraryLoader.load() returns false (GATK then falls back); JNI_VERSION_1_8 with one, or when forced
-    import ctypes as C
-    import torch
-    have_gpu = torch.cuda.is_available()
     for name in ("libgkl_pairhmm.so", "libgkl_pdhmm.so", "libgkl_smithwaterman.so"):
         lib = C.CDLL(os.path.join(os.path.dirname(mockjni.JNI_LIB), name))
         lib.JNI_OnLoad.restype = C.c_int
@@ -131,15 +128,35 @@ def test_jni_onload_probes_for_a_device(monkeypatch):
         assert lib.JNI_OnLoad(None, None) == 0x00010008
 
 
-def test_utils_library_gates_on_the_gpu():
+def _check_utils_library(have_gpu):
     """libgkl_utils.so replacement: IntelPairHmm.load() asks isAvxSupported() first
     (IntelPairHmm.java:66-75); here that answers "is a gfx950 device usable"."""
-    import torch
     mockjni.build()
     lib = C.CDLL(mockjni.SO)
     out = (C.c_int * 6)()
     path = os.path.join(ROOT, "gkl_amd", "lib", "libgkl_utils.so")
     assert lib.mockjni_run_utils(path.encode(), out) == 0
-    have_gpu = torch.cuda.is_available()
     assert bool(out[1]) == have_gpu and bool(out[2]) == have_gpu and out[3] == 0
     assert out[4] >= 1 and out[5] == 1  # FTZ can be switched on, like utils.cc:44-55
+
+
+def test_jni_onload_probes_for_a_device(monkeypatch):
+    import torch
+    _check_jni_onload(monkeypatch, torch.cuda.is_available())
+
+
+def test_utils_library_gates_on_the_gpu():
+    import torch
+    _check_utils_library(torch.cuda.is_available())
+
+
+@pytest.mark.gpu
+def test_jni_onload_with_a_device(monkeypatch):
+    # the device-present branch, in a driver-observed -m gpu process: JNI_OnLoad -> JNI_VERSION_1_8
+    _check_jni_onload(monkeypatch, True)
+
+
+@pytest.mark.gpu
+def test_utils_library_with_a_device():
+    # isAvxSupported / isAvx2Supported -> true on the GPU box (what IntelPairHmm.load() gates on)
+    _check_utils_library(True)

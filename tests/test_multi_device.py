@@ -1,0 +1,105 @@
+"""Multi-device sharding INSIDE the library (behind the C ABI and the JNI symbols): contiguous read ranges balanced by
+cells, one per device of the context's list, results gathered -- what the reference's OpenMP loop over pairs
+(IntelPairHmm.cc:151-154) is to its cores.  The one-GPU test box lists device 0 twice (two shards, two streams, the
+peer-copy gather); the RCCL calls of the real gather are exercised on a one-device communicator."""
+import numpy as np
+import pytest
+
+from gkl_amd import shard
+from gkl_amd.synth import make_batch, random_batch
+from tests import mockjni
+
+
+def test_library_partition_rule_equals_the_python_one():
+    # the torch.distributed harness (gkl_amd/shard.py) and the library must cut a batch at the same reads
+    from gkl_amd import native
+    rng = np.random.RandomState(5)
+    for _ in range(200):
+        n = int(rng.randint(1, 400))
+        lens = rng.randint(1, 300, size=n)
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum(lens)
+        for parts in (1, 2, 3, 4, 8, 13):
+            assert native.partition_reads(off, parts) == shard.partition_reads(lens, parts), (n, parts)
+    # fewer reads than parts: empty ranges, still monotone and complete
+    off = np.array([0, 10, 30], np.int64)
+    b = native.partition_reads(off, 8)
+    assert b[0] == 0 and b[-1] == 2 and all(x <= y for x, y in zip(b, b[1:]))
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,use_double", [([0, 0], False), ([0, 0, 0], False), ([0, 0], True)])
+def test_two_shards_on_one_gpu_host_path_bit_exact(oracle, devices, use_double):
+    from gkl_amd import native
+    b = make_batch("hc", 700, 24, seed=31)
+    with native.PairHmmContext(devices=devices, use_double=use_double) as c:
+        assert c.n_devices == len(devices) and c.gather_backend == "peer"
+        out = c.compute(b)
+        r32, r64, u = c.raw(b.n_pairs)
+        st = c.stats()
+    oo, o32, o64, ou = oracle.batch(b, use_double=use_double, want_raw=True, n_threads=8)
+    assert np.array_equal(u, ou)
+    if not use_double:
+        assert np.array_equal(bits(r32), bits(o32))
+    assert np.array_equal(bits(r64[u == 1]), bits(o64[ou == 1]))
+    assert np.array_equal(bits(out), bits(oo)), "host-finalised likelihoods are not bit-identical"
+    assert st["n_pairs"] == b.n_pairs and st["n_fallback"] == int(ou.sum())
+    # fewer reads than devices: empty shards are skipped
+    tiny = random_batch(np.random.RandomState(1), 2, 3)
+    with native.PairHmmContext(devices=[0, 0, 0, 0]) as c:
+        assert np.array_equal(bits(c.compute(tiny)), bits(oracle.batch(tiny, n_threads=2)))
+
+
+@pytest.mark.gpu
+def test_two_shards_on_one_gpu_device_resident_path(oracle):
+    import torch
+    from gkl_amd import native
+    b = make_batch("hc", 900, 32, seed=32)
+    db = native.DeviceBatch.upload(b, "cuda:0")
+    expd = oracle.batch(b, use_double=True, n_threads=8)
+    with native.PairHmmContext(device=0) as one, native.PairHmmContext(devices=[0, 0]) as two:
+        ref = one.compute_device(db)
+        torch.cuda.synchronize()
+        out = torch.full((b.n_pairs,), float("nan"), dtype=torch.float64, device="cuda:0")
+        for _ in range(3):  # back-to-back calls: the shards' streams and the caller's must stay ordered
+            two.compute_device(db, out)
+        torch.cuda.synchronize()
+        r32, r64, u = two.raw(b.n_pairs)
+    # sharding changes which wavefront computes a pair, never the arithmetic: identical to the single-device result
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref.cpu().numpy()))
+    assert np.max(np.abs(out.cpu().numpy() - expd) / np.abs(expd)) < 1e-5
+    _, o32, _, ou = oracle.batch(b, want_raw=True, n_threads=8)
+    assert np.array_equal(u, ou) and np.array_equal(bits(r32), bits(o32))
+
+
+@pytest.mark.gpu
+def test_jni_path_shards_over_the_device_list(oracle, monkeypatch):
+    # computeLikelihoodsNative itself scales: GKL_HIP_DEVICES is read by initNative
+    monkeypatch.setenv("GKL_HIP_DEVICES", "0,0")
+    b = make_batch("hc", 300, 12, seed=33)
+    rc, out, cls, msg, _ = mockjni.run(b)
+    assert rc == 0, (cls, msg)
+    assert out.tobytes() == oracle.batch(b, n_threads=8).tobytes()
+
+
+@pytest.mark.gpu
+def test_rccl_send_recv_group_runs():
+    # the gather's RCCL calls (dlopen, ncclCommInitAll, grouped ncclSend/ncclRecv) on a one-device communicator
+    from gkl_amd import native
+    native.rccl_selftest(0)
+
+
+@pytest.mark.gpu
+def test_bad_device_list_is_rejected(monkeypatch):
+    from gkl_amd import native
+    from gkl_amd.errors import IllegalArgumentException
+    with pytest.raises(IllegalArgumentException):
+        native.PairHmmContext(devices=[0, 99])
+    monkeypatch.setenv("GKL_HIP_DEVICES", "0;1")
+    with pytest.raises(IllegalArgumentException):
+        native.PairHmmContext()

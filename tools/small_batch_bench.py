@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gkl_amd import native  # noqa: E402
 from gkl_amd.synth import make_batch  # noqa: E402
 
-for kind, nr, nh in (("hc", 100, 10), ("region", 100, 10), ("region", 300, 16), ("hc", 1000, 32), ("region", 2000, 64)):
+for kind, nr, nh in (("hc", 100, 10), ("region", 100, 10), ("region", 300, 16), ("hc", 1000, 32), ("region", 2000, 64), ("hc", 1250, 128)):
     b = make_batch(kind, nr, nh)
     db = native.DeviceBatch.upload(b)
     out = torch.empty(b.n_pairs, dtype=torch.float64, device="cuda")
