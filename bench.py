@@ -7,12 +7,22 @@ HaplotypeCaller-shaped 10k-read x 128-haplotype batch, 1..N GPUs of one node.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one full pass of the hot path over one batch with the inputs already resident
-in HBM: plan -> fp32 forward kernel over all pairs -> precision policy -> fp64 recomputation
-of the underflowed pairs -> log10 finalisation (doubles in HBM), and for N>1 the gather of
-every rank's results on rank 0 over RCCL (issued asynchronously: it overlaps the next step's
-kernels; all gathers complete inside the timed region).  Weak scaling: every rank owns its own 10k reads
-(same 128 haplotypes), i.e. the global batch is N x 10k reads sharded by read range.  `--strong` runs BASELINE
-config 4 instead: ONE 8000 x 125 batch (1 M pairs) cut into N read ranges balanced by cells (`"scaling": "strong"`).
+in HBM: plan -> fp32 forward kernel over all pairs -> precision policy + planning of the fp64
+pass -> fp64 recomputation of the underflowed pairs -> log10 finalisation (doubles in HBM), and
+for N>1 the gather of every rank's results on rank 0 over RCCL (issued asynchronously: it
+overlaps the next step's kernels; all gathers complete inside the timed region).
+
+N>1 is STRONG scaling by default (north_star: "a 10k-read x 128-haplotype batch at 1/2/4/8
+GPUs"): the SAME 10k x 128 batch is cut into N contiguous read ranges balanced by cells (the
+library's own sharding rule, gklhip_partition_reads), one per rank, haplotypes replicated.
+`--weak` gives every rank its own 10k reads instead; `--config4` shards BASELINE config 4
+(8000 x 125 = 1 M pairs).
+
+The timed loop never synchronises inside: the host-side planning of step k+1 overlaps the
+kernels of step k.  `value` = cells of K steps / wall time of K steps.  The latency of ONE call
+(nothing to overlap with) is reported separately under "single_call" and "small_batch".
+(`--overlap` alternates consecutive steps between two contexts on two streams; measured: no
+gain -- one step's kernels already saturate the chip -- so it is not the default.)
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the fp32 forward
 kernel): 12 FLOP per cell x cells per launch / its HIP-event duration,
@@ -24,6 +34,7 @@ process may use (cgroup quota respected; `cores` = threads actually used).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -96,6 +107,65 @@ class _SingleRank:
         return 0
 
 
+def _median_ms(fn, calls, warm):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(calls):
+        t = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t)
+    return float(np.median(ts)) * 1e3
+
+
+def host_call_record(native, batch, dev_index, calls=30, warm=15, max_threads=1):
+    """One batch through gklhip_compute (what computeLikelihoodsNative calls after marshalling): host arrays in,
+    host doubles out, H2D/D2H and the reference-exact host log10 included.  Latency of back-to-back single calls."""
+    out = np.empty(batch.n_pairs)
+    with native.PinnedBatch(batch) as pb:   # page-locked marshalling buffers, like the JNI shim's arenas
+        with native.PairHmmContext(device=dev_index, max_threads=max_threads) as c:
+            ms = _median_ms(lambda: c.compute(pb, out), calls, warm)
+        with native.PairHmmContext(device=dev_index, max_threads=max_threads, record_events=True) as c:
+            for _ in range(max(3, warm // 3)):
+                c.compute(pb, out)
+            st = c.stats()
+    k = st["ms_fwd_main"] + st["ms_fwd_fallback"]
+    return {"ms_per_call": round(ms, 4), "gcups": round(batch.cells / ms / 1e6, 1),
+            "kernels_ms": round(k, 4), "over_kernels": round(ms / k - 1.0, 3) if k > 0 else None,
+            "pairs": batch.n_pairs, "fallback_fraction": round(st["n_fallback"] / batch.n_pairs, 4)}
+
+
+def in_library_probe(n_dev, reads, haps, workload, steps, warmup):
+    """Child-process mode: ONE process drives n_dev devices through a multi-device context (GKL_HIP_DEVICES),
+    i.e. what a JVM calling computeLikelihoodsNative gets.  Prints one JSON object."""
+    import torch
+    from gkl_amd import native
+    from gkl_amd.synth import DEFAULT_SEED, make_batch
+    b = make_batch(workload, reads, haps, seed=DEFAULT_SEED)
+    res = {"devices": n_dev}
+    with native.PairHmmContext(devices=list(range(n_dev))) as c:
+        res["gather"] = c.gather_backend
+        db = native.DeviceBatch.upload(b, "cuda:0")
+        out = torch.empty(b.n_pairs, dtype=torch.float64, device="cuda:0")
+        for _ in range(warmup):
+            c.compute_device(db, out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c.compute_device(db, out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res["device_resident"] = {"ms_per_step": round(dt * 1e3, 3), "gcups": round(b.cells / dt / 1e9, 1)}
+        with native.PairHmmContext(device=0) as one:
+            ref = one.compute_device(db)
+            torch.cuda.synchronize()
+        res["bit_identical_to_single_device"] = bool(torch.equal(ref, out))
+        host_out = np.empty(b.n_pairs)
+        ms = _median_ms(lambda: c.compute(b, host_out), 6, 2)
+        res["host_path"] = {"ms_per_call": round(ms, 3), "gcups": round(b.cells / ms / 1e6, 1)}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,17 +176,24 @@ def main():
     ap.add_argument("--haps", type=int, default=128)
     ap.add_argument("--double", action="store_true", help="useDoublePrecision (BASELINE config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling (BASELINE config 4): ONE batch of --reads x --haps (default 8000 x 125 = 1 M pairs) "
-                         "sharded over the ranks by read range, balanced by cells")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single_call / small_batch / host_path / no_fallback sub-records")
+    ap.add_argument("--weak", action="store_true", help="N>1: every rank owns its own --reads reads (weak scaling) instead of a "
+                                                        "read range of the one batch")
+    ap.add_argument("--config4", action="store_true", help="BASELINE config 4: ONE 8000 x 125 batch (1 M pairs), sharded")
+    ap.add_argument("--strong", action="store_true", help="(default for N>1; kept for compatibility)")
+    ap.add_argument("--overlap", action="store_true", help="two contexts on two streams alternate between consecutive steps "
+                                                           "(measured: no gain, the chip is saturated by one step's kernels)")
+    ap.add_argument("--in-library-probe", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args()
-    if a.strong and a.reads == 10000 and a.haps == 128:
+    if a.config4:
         a.reads, a.haps = 8000, 125
+    if a.in_library_probe:
+        return in_library_probe(a.in_library_probe, a.reads, a.haps, a.workload, a.steps, a.warmup)
 
     import torch
     import torch.distributed as dist
     from gkl_amd import native
-    from gkl_amd.shard import PipelinedGather
+    from gkl_amd.shard import PipelinedGather, shard_batch
     from gkl_amd.synth import DEFAULT_SEED, make_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,55 +217,56 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    if a.strong:
-        # one global batch, this rank's contiguous read range of it (shard.py balances the ranges by cells)
-        from gkl_amd.shard import shard_batch
-        whole = make_batch(a.workload, a.reads, a.haps, seed=DEFAULT_SEED)
-        batch, bounds = shard_batch(whole, rank, world)
-        rows = [bounds[g + 1] - bounds[g] for g in range(world)]
-    else:
+    strong = world > 1 and not a.weak
+    whole = None
+    if a.weak and world > 1:
         # every rank: same haplotypes (seed), its own reads (read_seed)
         batch = make_batch(a.workload, a.reads, a.haps, seed=DEFAULT_SEED, read_seed=DEFAULT_SEED + 1 + rank)
         rows = [a.reads] * world
+    else:
+        # one global batch, this rank's contiguous read range of it (balanced by cells; shard.partition_reads is the
+        # library's gklhip_partition_reads rule, tests/test_multi_device.py pins the two to each other)
+        whole = make_batch(a.workload, a.reads, a.haps, seed=DEFAULT_SEED)
+        batch, bounds = shard_batch(whole, rank, world)
+        rows = [bounds[g + 1] - bounds[g] for g in range(world)]
     dbatch = native.DeviceBatch.upload(batch, dev)
     # record_events=2: kernels are bracketed with HIP events but no call synchronises, so the host-side planning of
-    # step k+1 overlaps the kernels of step k; the event times are read after the timed region
-    ctx = native.PairHmmContext(use_double=a.double, device=dev_index, record_events=2)
-    sync_each_step = os.environ.get("GKL_BENCH_SYNC_EACH_STEP") == "1"   # A/B switch: the old behaviour
-    stream = torch.cuda.current_stream(dev)
-    # N>1: the gather of step k (RCCL, its own stream) overlaps the kernels of step k+1; two result buffers rotate
-    gather = PipelinedGather(rows, a.haps, comm_dev, dist if world > 1 else _SingleRank())
-    dev_out = None if comm_dev == dev else torch.empty(batch.n_pairs, dtype=torch.float64, device=dev)
+    # step k+1 overlaps the kernels of step k; the event times are read after the timed region.
+    n_ctx = 2 if a.overlap else 1
+    ctxs = [native.PairHmmContext(use_double=a.double, device=dev_index, record_events=2) for _ in range(n_ctx)]
+    streams = [torch.cuda.Stream(dev) for _ in range(n_ctx)]
+    # N>1: the gather of step k (RCCL, its own stream) overlaps the kernels of step k+1; result buffers rotate
+    gather = PipelinedGather(rows, a.haps, comm_dev, dist if world > 1 else _SingleRank(), depth=max(2, n_ctx))
+    dev_out = None if comm_dev == dev else [torch.empty(batch.n_pairs, dtype=torch.float64, device=dev) for _ in range(n_ctx)]
     counter = [0]
 
     def step():
         k = counter[0]
         counter[0] += 1
-        out = gather.buffer(k)
-        if dev_out is None:
-            ctx.compute_device(dbatch, out, stream)
-        else:  # dry-run backend (gloo): results cross to the host first
-            ctx.compute_device(dbatch, dev_out, stream)
-            out.copy_(dev_out)
-        gather.submit(k)
+        i = k % n_ctx
+        with torch.cuda.stream(streams[i]):
+            out = gather.buffer(k)
+            if dev_out is None:
+                ctxs[i].compute_device(dbatch, out, streams[i])
+            else:  # dry-run backend (gloo): results cross to the host first
+                ctxs[i].compute_device(dbatch, dev_out[i], streams[i])
+                out.copy_(dev_out[i])
+            gather.submit(k)
+
+    def drain():
+        gather.finish()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
 
     for _ in range(a.warmup):
         step()
-    gather.finish()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize(dev)
+    drain()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-        if sync_each_step:
-            torch.cuda.synchronize(dev)
-    gather.finish()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize(dev)
+    drain()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
@@ -200,63 +278,133 @@ def main():
     else:
         total_cells, total_pairs = float(batch.cells), float(batch.n_pairs)
 
-    # HIP-event times of the timed steps (the ring holds the last 64 calls)
-    times = [ctx.step_times(k) for k in range(min(a.steps, 64))]
+    # HIP-event times of the timed steps (each context's ring holds its last 64 calls)
+    times = []
+    for i, c in enumerate(ctxs):
+        # the timed steps of context i are its LAST calls
+        n_mine = sum(1 for k in range(a.warmup, a.warmup + a.steps) if k % n_ctx == i)
+        times += [c.step_times(k) for k in range(min(n_mine, 64))]
     ms_main, ms_fb, ms_dev = ([t[i] for t in times] for i in range(3))
     if rank == 0:
-        st = ctx.stats()
+        st = ctxs[0].stats()
         with native.PairHmmContext(use_double=a.double, device=dev_index, record_events=1) as probe:
-            probe.compute_device(dbatch, torch.empty(batch.n_pairs, dtype=torch.float64, device=dev), stream)
-            st["n_fallback"] = probe.stats()["n_fallback"]   # needs a synchronising call: outside the timed region
+            pout = torch.empty(batch.n_pairs, dtype=torch.float64, device=dev)
+            for _ in range(2):
+                probe.compute_device(dbatch, pout)
+            torch.cuda.synchronize(dev)
+            # latency of ONE call: nothing to overlap with (synchronised before and after)
+            def one_call():
+                probe.compute_device(dbatch, pout)
+                torch.cuda.synchronize(dev)
+            single_ms = _median_ms(one_call, 5, 1)
+            pst = probe.stats()
+            st["n_fallback"] = pst["n_fallback"]   # needs a synchronising call: outside the timed region
         k_ms = float(np.mean(ms_main))
+        fb_ms = float(np.mean(ms_fb))
+        step_ms = elapsed / a.steps * 1e3
         achieved = FLOP_PER_CELL * batch.cells / (k_ms * 1e-3) / 1e12
-        traffic = None
+        traffic_profile = None
         pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                traffic_profile = {"hbm_bytes_per_launch": j.get("hbm_bytes_per_launch"), "profile": j.get("tag", "profiles/latest_pmc.json"),
+                                   "note": "from the committed rocprofv3 --pmc passes of this command (profiles/), not measured in this run"}
             except Exception:
-                traffic = None
+                traffic_profile = None
+        peak = PEAK_FP32_VECTOR_TFLOPS / 2 if a.double else PEAK_FP32_VECTOR_TFLOPS
         res = {
             "metric": "pairhmm_gcups", "value": round(total_cells * a.steps / elapsed / 1e9, 2), "unit": "GCUPS",
             "likelihoods_per_s": round(total_pairs * a.steps / elapsed, 1),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong" if a.strong else "weak",
+            "ms_per_step": round(step_ms, 3), "higher_is_better": True,
+            "scaling": "weak" if (a.weak and world > 1) else "strong",
             "vs_baseline": None, "dtype": "f64" if a.double else "f32", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {a.reads} reads x {a.haps} haps {'in total' if a.strong else 'per GPU'} (reads 50-250 bp, haps "
+            "config": {"workload": f"{a.workload}: {a.reads} reads x {a.haps} haps {'per GPU' if (a.weak and world > 1) else 'in total'} (reads 50-250 bp, haps "
                                    f"100-500 bp), {'fp64 all pairs' if a.double else 'fp32 + fp64 fallback policy'}, "
                                    f"inputs and log10 outputs resident in HBM",
                        "pairs_per_gpu": batch.n_pairs, "cells_per_gpu": batch.cells,   # rank 0's share
                        "fallback_fraction": round(st["n_fallback"] / batch.n_pairs, 4),
-                       "parallelism": f"read-range shard x{world}, gather to rank 0 overlapped with the next step" if world > 1 else "single GPU",
+                       "parallelism": (f"one batch cut into {world} read ranges balanced by cells, one per rank; gather to rank 0 over RCCL, "
+                                       f"overlapped with the next step" if strong else
+                                       f"every rank its own reads x{world}; gather to rank 0" if world > 1 else "single GPU"),
+                       "step_overlap": f"{n_ctx} contexts on {n_ctx} streams alternate between consecutive steps" if n_ctx > 1 else "none",
                        "finalize": "device log10 in double"},
             # "mfma" = the compute roofline of the bench contract, priced at the dense MFMA peak of the dtype (which
             # for fp32/fp64 equals the vector peak); the kernel itself is vector-ALU code, see `note`
             "roofline": {"bound": "mfma", "limiter": "valu-fp64 issue" if a.double else "valu-fp32 issue",
                          "kernel": "pairhmm_fwd_stream_kernel",
-                         "achieved": round(achieved, 2),
-                         "peak": PEAK_FP32_VECTOR_TFLOPS / 2 if a.double else PEAK_FP32_VECTOR_TFLOPS,
-                         "unit": "TFLOP/s",
-                         "frac": round(achieved / (PEAK_FP32_VECTOR_TFLOPS / 2 if a.double else PEAK_FP32_VECTOR_TFLOPS), 4),
-                         "traffic": traffic, "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(k_ms, 3),
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4),
+                         "traffic": None, "traffic_from_profile": traffic_profile,
+                         "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(k_ms, 3),
                          "kernel_gcups": round(batch.cells / k_ms / 1e6, 1),
                          "note": "compute-bound recurrence priced at the dense fp32 (fp64 with --double) MFMA peak = the vector "
                                  "peak; it has no contraction, so it runs on the vector ALUs and issues no MFMA; that peak is "
                                  "reachable only by packed FMA-only code. The recurrence needs 4 mul + 4 fma per cell "
                                  "(1.5 flop per instruction) and a SIMD retires one plain VALU op per ~2.7 cycles (measured), "
                                  "so its issue-bound ceiling is ~7 TCUPS = 0.53 of peak (DESIGN.md section 3)"},
-            "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(float(np.mean(ms_fb)), 3),
+            "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(fb_ms, 3),
                            "device_total": round(float(np.mean(ms_dev)), 3)},
+            # what a step costs beyond its two forward kernels (planning, policy, log10, launches, gaps); with
+            # overlapping steps it can be negative (the other step's kernels fill the gaps)
+            "fixed_cost_ms": round(step_ms - k_ms - fb_ms, 3),
+            "single_call": {"ms_per_call": round(single_ms, 3), "gcups": round(batch.cells / single_ms / 1e6, 1),
+                            "kernels_ms": {"fwd_main": round(pst["ms_fwd_main"], 3), "fwd_fp64_fallback": round(pst["ms_fwd_fallback"], 3)},
+                            "fixed_cost_ms": round(single_ms - pst["ms_fwd_main"] - pst["ms_fwd_fallback"], 3),
+                            "note": "one device-resident call, synchronised before and after (host planning included)"},
             "plan": {"chunks": st["n_chunks"], "hap_groups": st["n_hap_groups"], "rows_per_lane": st["rows_per_lane"],
                      "lane_fill": round(st["lane_fill"], 4)},
         }
+        if world == 1 and not a.no_extras and not a.double:
+            try:
+                # end to end through gklhip_compute (H2D, D2H, reference-exact host log10)
+                res["host_path"] = {
+                    "max_threads_1": host_call_record(native, batch, dev_index, calls=6, warm=2, max_threads=1),
+                    "max_threads_16": host_call_record(native, batch, dev_index, calls=6, warm=2, max_threads=16),
+                    "note": "gklhip_compute on host arrays = what computeLikelihoodsNative runs after marshalling; "
+                            "maxNumberOfThreads <= 1 means 'not set' to the finaliser (min(cores, 8) host threads)"}
+                # per-call cost on the sizes GATK and an 8-GPU shard really send
+                c1 = make_batch(a.workload, 100, 10, seed=DEFAULT_SEED)
+                eighth = whole.read_slice(0, whole.n_reads // 8)
+                res["small_batch"] = {"c1_100x10": host_call_record(native, c1, dev_index, calls=60, warm=30),
+                                      f"eighth_{eighth.n_reads}x{eighth.n_haps}": host_call_record(native, eighth, dev_index, calls=20, warm=10),
+                                      "note": "through gklhip_compute, back-to-back single calls, median"}
+                # the same shape without fallback pairs (one real active region)
+                reg = make_batch("region", a.reads, a.haps, seed=DEFAULT_SEED)
+                dreg = native.DeviceBatch.upload(reg, dev)
+                rout = torch.empty(reg.n_pairs, dtype=torch.float64, device=dev)
+                with native.PairHmmContext(device=dev_index, record_events=1) as rc:
+                    def reg_call():
+                        rc.compute_device(dreg, rout)
+                        torch.cuda.synchronize(dev)
+                    rms = _median_ms(reg_call, 5, 2)
+                    rst = rc.stats()
+                res["no_fallback"] = {"workload": f"region: {a.reads} x {a.haps}", "ms_per_call": round(rms, 3),
+                                      "gcups": round(reg.cells / rms / 1e6, 1), "kernel_ms": round(rst["ms_fwd_main"], 3),
+                                      "kernel_gcups": round(reg.cells / rst["ms_fwd_main"] / 1e6, 1),
+                                      "fallback_fraction": round(rst["n_fallback"] / reg.n_pairs, 5)}
+            except Exception as e:  # never lose the headline line to a sub-record
+                res["extras_error"] = repr(e)
         if world == 1 and not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(batch)
             except Exception as e:  # never lose the GPU line to a baseline problem
                 res["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
+        if world > 1 and not a.no_extras and not same_device:
+            # The same batch through the LIBRARY's own multi-device path (one process, GKL_HIP_DEVICES-style context,
+            # RCCL gather inside the C ABI) -- what a JVM gets.  Child process with a time limit: the other ranks are
+            # idle at the barrier below, and a problem there must not cost the line above.
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-library-probe", str(world), "--reads", str(a.reads),
+                                    "--haps", str(a.haps), "--workload", a.workload, "--steps", str(a.steps), "--warmup", str(a.warmup)],
+                                   capture_output=True, text=True, timeout=240,
+                                   env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+                line = next((ln for ln in reversed(p.stdout.splitlines()) if ln.startswith("{")), None)
+                res["in_library"] = json.loads(line) if line else {"error": (p.stderr or p.stdout)[-300:]}
+            except Exception as e:
+                res["in_library"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

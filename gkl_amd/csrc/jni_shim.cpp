@@ -83,6 +83,7 @@ struct Slot {
   std::vector<int64_t> hap_off, read_off;
   std::vector<double> out;
   bool busy = false;
+  int gen = 0;  // configuration generation (initNative with other arguments starts a new one)
   ~Slot() { if (ctx) gklhip_done(ctx); }
 };
 
@@ -94,7 +95,8 @@ struct State {
   std::vector<std::unique_ptr<Slot>> slots;
   int max_slots = 4;
   int creating = 0;  // slots being initialised outside the lock
-  bool ready = false;
+  bool ready = false;  // initNative has run: configuration and field IDs are valid (stays true after doneNative)
+  int gen = 0;         // current configuration generation; slots of older generations die when they come back
   gklhip_config cfg;
   jfieldID readBases = nullptr, readQuals = nullptr, insertionGOP = nullptr, deletionGOP = nullptr,
            overallGCP = nullptr, haplotypeBases = nullptr;
@@ -153,8 +155,8 @@ jobject holder_at(JNIEnv* env, jobjectArray arr, jsize i) {
   return holder;
 }
 
-// A free slot, creating one (context + stream) while fewer than max_slots exist; blocks otherwise.
-// Returns NULL after throwing.
+// A free slot of the current configuration, creating one (context + stream) while fewer than max_slots exist;
+// blocks otherwise.  Returns NULL after throwing.
 Slot* acquire_slot(JNIEnv* env) {
   std::unique_lock<std::mutex> lock(g.mu);
   for (;;) {
@@ -164,10 +166,13 @@ Slot* acquire_slot(JNIEnv* env) {
       return nullptr;
     }
     for (auto& s : g.slots)
-      if (!s->busy) { s->busy = true; return s.get(); }
-    if ((int)g.slots.size() + g.creating < g.max_slots) {
+      if (!s->busy && s->gen == g.gen) { s->busy = true; return s.get(); }
+    int live = g.creating;
+    for (auto& s : g.slots) live += s->gen == g.gen;
+    if (live < g.max_slots) {
       g.creating++;
       const gklhip_config cfg = g.cfg;
+      const int gen = g.gen;
       lock.unlock();
       std::unique_ptr<Slot> s(new (std::nothrow) Slot());
       const int st = s ? gklhip_init(&cfg, &s->ctx) : GKLHIP_ERR_OOM;
@@ -175,10 +180,14 @@ Slot* acquire_slot(JNIEnv* env) {
       g.creating--;
       if (st != GKLHIP_OK) {
         // could not add a slot (e.g. out of device memory): share the existing ones instead
-        g.max_slots = std::max<int>(1, (int)g.slots.size());
-        if (g.slots.empty()) { lock.unlock(); throw_status(env, st); return nullptr; }
+        int have = 0;
+        for (auto& o : g.slots) have += o->gen == g.gen;
+        g.max_slots = std::max<int>(1, have);
+        if (have == 0) { lock.unlock(); g.slot_free.notify_all(); throw_status(env, st); return nullptr; }
         continue;
       }
+      s->gen = gen;
+      if (gen != g.gen) continue;  // re-configured meanwhile: the new slot (old arguments) is dropped
       s->busy = true;
       g.slots.push_back(std::move(s));
       return g.slots.back().get();
@@ -191,23 +200,25 @@ struct SlotLease {
   Slot* s;
   ~SlotLease() {
     if (!s) return;
+    std::unique_ptr<Slot> dead;
     {
       std::lock_guard<std::mutex> lock(g.mu);
       s->busy = false;
+      if (s->gen != g.gen)  // initNative changed the configuration while this call ran: the slot is not reused
+        for (auto it = g.slots.begin(); it != g.slots.end(); ++it)
+          if (it->get() == s) { dead = std::move(*it); g.slots.erase(it); break; }
     }
-    g.slot_free.notify_one();
+    g.slot_free.notify_all();  // waiters differ (a caller that wants a slot, any number of them): wake all
   }
 };
 
-// Waits until no call is in flight, then drops every slot.
-void drop_slots(std::unique_lock<std::mutex>& lock) {
-  g.ready = false;
-  g.slot_free.wait(lock, [] {
-    if (g.creating) return false;
-    for (auto& s : g.slots) if (s->busy) return false;
-    return true;
-  });
-  g.slots.clear();
+// Frees the slots no call is using (their device memory, streams, pinned arenas).  Busy ones are left alone.
+void trim_idle_slots(bool only_old_generations) {
+  std::vector<std::unique_ptr<Slot>> dead;
+  for (auto it = g.slots.begin(); it != g.slots.end();) {
+    if (!(*it)->busy && (!only_old_generations || (*it)->gen != g.gen)) { dead.push_back(std::move(*it)); it = g.slots.erase(it); }
+    else ++it;
+  }
 }
 
 }  // namespace
@@ -231,8 +242,10 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
     }
     *f.dst = id;
   }
-  drop_slots(lock);
-  gklhip_config& cfg = g.cfg;
+  // The reference's initNative only re-sets globals (IntelPairHmm.cc:70-116) and other threads may be inside
+  // computeLikelihoodsNative right now: nothing is torn down here.  Same arguments: nothing to do.  Other
+  // arguments: a new generation of slots; calls in flight finish on theirs, which then retire.
+  gklhip_config cfg;
   memset(&cfg, 0, sizeof cfg);
   cfg.abi_version = GKLHIP_ABI_VERSION;
   cfg.device = env_int("GKL_HIP_DEVICE", -1);
@@ -242,13 +255,22 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
   cfg.finalize = env_int("GKL_HIP_FINALIZE", GKLHIP_FINALIZE_REFERENCE_HOST);
   cfg.record_events = 0;
   cfg.rows_per_lane = 0;
-  g.max_slots = std::max(1, env_int("GKL_HIP_SLOTS", 4));
+  const int max_slots = std::max(1, env_int("GKL_HIP_SLOTS", 4));
+  bool have_slot = false;
+  for (auto& sl : g.slots) have_slot |= sl->gen == g.gen;
+  if (g.ready && memcmp(&cfg, &g.cfg, sizeof cfg) == 0 && have_slot) { g.max_slots = max_slots; return; }
   // the first slot is created here so that "no GPU" surfaces from initNative, like a failed dlopen would
   std::unique_ptr<Slot> first(new (std::nothrow) Slot());
   const int st = first ? gklhip_init(&cfg, &first->ctx) : GKLHIP_ERR_OOM;
   if (st != GKLHIP_OK) { lock.unlock(); throw_status(env, st); return; }
+  g.cfg = cfg;
+  g.max_slots = max_slots;
+  first->gen = ++g.gen;
   g.slots.push_back(std::move(first));
   g.ready = true;
+  trim_idle_slots(/*only_old_generations=*/true);
+  lock.unlock();
+  g.slot_free.notify_all();
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative(
@@ -309,8 +331,11 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv*, jobject) {
-  std::unique_lock<std::mutex> lock(g.mu);
-  drop_slots(lock);
+  // The reference's doneNative is empty (IntelPairHmm.cc:189-192): other IntelPairHmm instances of the JVM keep
+  // working after one of them closes.  Here it releases what no call is using (device memory, pinned arenas) and
+  // keeps the configuration, so a later call simply gets a fresh slot.
+  std::lock_guard<std::mutex> lock(g.mu);
+  trim_idle_slots(/*only_old_generations=*/false);
 }
 
 }  // extern "C"

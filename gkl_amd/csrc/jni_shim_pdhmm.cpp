@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -39,9 +40,13 @@ constexpr const char* kIAE = "java/lang/IllegalArgumentException";
 constexpr const char* kOOM = "java/lang/OutOfMemoryError";
 constexpr const char* kRTE = "java/lang/RuntimeException";
 
+// The context is shared by reference count: a call holds its own reference for as long as it runs, so a second
+// IntelPDHMM.initialize() or a close() on another thread can never free a context under a running call (the
+// reference has no such state at all: it re-allocates its DP table on every call, IntelPDHMM.cc:101-120).
 struct State {
   std::mutex mu;
-  gklhip_pdhmm_ctx* ctx = nullptr;
+  std::shared_ptr<gklhip_pdhmm_ctx> ctx;
+  bool initialised = false;  // initNative has cached the field IDs: a context can be (re)created on demand
   int max_memory_mb = 512;
   jfieldID readBases = nullptr, readQuals = nullptr, insertionGOP = nullptr, deletionGOP = nullptr,
            overallGCP = nullptr, haplotypeBases = nullptr, haplotypePDBases = nullptr;
@@ -60,8 +65,34 @@ void throw_status(JNIEnv* env, int st) {
   throw_java(env, st == GKLHIP_ERR_INVALID_ARG ? kIAE : st == GKLHIP_ERR_OOM ? kOOM : kRTE, msg);
 }
 
-gklhip_pdhmm_ctx* context() {
+// New context on the configured device; NULL after throwing.  Called with g.mu held.
+std::shared_ptr<gklhip_pdhmm_ctx> make_context(JNIEnv* env) {
+  const char* dev = getenv("GKL_HIP_DEVICE");
+  gklhip_pdhmm_ctx* raw = nullptr;
+  const int st = gklhip_pdhmm_init((dev && *dev) ? atoi(dev) : -1, &raw);
+  if (st != GKLHIP_OK) { throw_status(env, st); return nullptr; }
+  std::shared_ptr<gklhip_pdhmm_ctx> c(raw, [](gklhip_pdhmm_ctx* p) { gklhip_pdhmm_done(p); });
+  const char* fm = getenv("GKL_HIP_FMA_MODE");  // 1 (default): GKL's AVX-512 arithmetic, 0: its AVX2 arithmetic
+  if (fm && *fm) {
+    const int st2 = gklhip_pdhmm_set_fma_mode(raw, atoi(fm));
+    if (st2 != GKLHIP_OK) { throw_status(env, st2); return nullptr; }
+  }
+  return c;
+}
+
+// The caller's own reference to the context.  After doneNative the reference keeps working (it holds no state),
+// so a compute call then gets a fresh context here; before any initNative it throws.  NULL after throwing.
+std::shared_ptr<gklhip_pdhmm_ctx> context(JNIEnv* env, const char* who) {
   std::lock_guard<std::mutex> lock(g.mu);
+  if (!g.ctx) {
+    if (!g.initialised) {
+      char msg[128];
+      snprintf(msg, sizeof msg, "GKL-HIP PDHMM: %s before initNative", who);
+      throw_java(env, kRTE, msg);
+      return nullptr;
+    }
+    g.ctx = make_context(env);
+  }
   return g.ctx;
 }
 
@@ -98,22 +129,23 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_initNative(JNIEnv* en
     *f.dst = id;
   }
   g.max_memory_mb = maxMemoryInMB > 0 ? maxMemoryInMB : 512;
-  if (g.ctx) { gklhip_pdhmm_done(g.ctx); g.ctx = nullptr; }
-  const char* dev = getenv("GKL_HIP_DEVICE");
-  const int st = gklhip_pdhmm_init((dev && *dev) ? atoi(dev) : -1, &g.ctx);
-  if (st != GKLHIP_OK) { g.ctx = nullptr; throw_status(env, st); return; }
-  const char* fm = getenv("GKL_HIP_FMA_MODE");  // 1 (default): GKL's AVX-512 arithmetic, 0: its AVX2 arithmetic
-  if (fm && *fm) {
-    const int st2 = gklhip_pdhmm_set_fma_mode(g.ctx, atoi(fm));
-    if (st2 != GKLHIP_OK) throw_status(env, st2);
-  }
+  g.initialised = true;
+  // a second initialize() keeps the context (calls of other threads may be running on it); the first one creates it
+  // here so that "no GPU" surfaces from initNative
+  if (!g.ctx) g.ctx = make_context(env);
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNative(
     JNIEnv* env, jobject, jobjectArray readDataArray, jobjectArray haplotypeDataArray, jdoubleArray likelihoodArray) {
   if (!readDataArray || !haplotypeDataArray || !likelihoodArray) { throw_java(env, kIAE, "null argument"); return; }
-  gklhip_pdhmm_ctx* ctx = context();
-  if (!ctx) { throw_java(env, kRTE, "GKL-HIP PDHMM: computeLikelihoodsNative before initNative"); return; }
+  const std::shared_ptr<gklhip_pdhmm_ctx> ctx_ref = context(env, "computeLikelihoodsNative");
+  gklhip_pdhmm_ctx* ctx = ctx_ref.get();
+  if (!ctx) return;
+  int max_memory_mb;
+  {
+    std::lock_guard<std::mutex> lock(g.mu);
+    max_memory_mb = g.max_memory_mb;
+  }
   try {
     const jsize n_reads = gkljni::GetArrayLength(env, readDataArray);
     const jsize n_haps = gkljni::GetArrayLength(env, haplotypeDataArray);
@@ -152,7 +184,7 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNat
     // staged once and the device walks the cross product itself; maxMemoryInMB then only has to cover
     // reads + haplotypes + results, and the same "too small" error is raised when it does not.
     const int64_t need = (int64_t)n_reads * max_r * 5 + (int64_t)n_haps * max_h * 2 + total * 8;
-    if (need > (int64_t)g.max_memory_mb * 1024 * 1024) {
+    if (need > (int64_t)max_memory_mb * 1024 * 1024) {
       throw_java(env, kIAE, "Batch size is too small. Please increase the memory limit for PDHMM by using the maxMemoryInMB argument.");
       return;
     }
@@ -187,8 +219,9 @@ JNIEXPORT jdoubleArray JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computePDHMMN
     JNIEnv* env, jobject, jbyteArray jhap_bases, jbyteArray jhap_pdbases, jbyteArray jread_bases, jbyteArray jread_qual,
     jbyteArray jread_ins_qual, jbyteArray jread_del_qual, jbyteArray jgcp, jlongArray jhap_lengths,
     jlongArray jread_lengths, jint testcase, jint maxHapLength, jint maxReadLength) {
-  gklhip_pdhmm_ctx* ctx = context();
-  if (!ctx) { throw_java(env, kRTE, "GKL-HIP PDHMM: computePDHMMNative before initNative"); return nullptr; }
+  const std::shared_ptr<gklhip_pdhmm_ctx> ctx_ref = context(env, "computePDHMMNative");
+  gklhip_pdhmm_ctx* ctx = ctx_ref.get();
+  if (!ctx) return nullptr;
   if (!jhap_bases || !jhap_pdbases || !jread_bases || !jread_qual || !jread_ins_qual || !jread_del_qual || !jgcp ||
       !jhap_lengths || !jread_lengths || testcase <= 0 || maxHapLength <= 0 || maxReadLength <= 0) {
     throw_java(env, kIAE, "Input arrays aren't valid.");  // IntelPDHMM.cc:165-189
@@ -228,8 +261,10 @@ JNIEXPORT jdoubleArray JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computePDHMMN
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_doneNative(JNIEnv*, jclass) {
+  // drops the library's reference: device memory goes when the last running call has returned; a later compute call
+  // gets a fresh context (the reference's doneNative frees its DP table and the next call re-allocates it)
   std::lock_guard<std::mutex> lock(g.mu);
-  if (g.ctx) { gklhip_pdhmm_done(g.ctx); g.ctx = nullptr; }
+  g.ctx.reset();
 }
 
 }  // extern "C"

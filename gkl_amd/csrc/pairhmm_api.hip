@@ -114,8 +114,8 @@ struct DevCtx {
   DevBuf raw32, raw64, used64, counters, stream_buf, out_dev;
   DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist, hap_flags;
   // host-API device copies of the batch, packed results (device + pinned), finalisation workers
-  DevBuf batch_dev, res_dev;
-  PinBuf res_pin, res_pin2;
+  DevBuf batch_dev;
+  PinBuf res_pin;
   WorkerPool workers;
   hipStream_t copy_stream = nullptr;  // early D2H of the fp32 results / device log10 of the kept pairs while the fp64 pass runs
   hipEvent_t policy_done = nullptr, early_copy_done = nullptr;
@@ -538,7 +538,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     // the policy pass itself; reads of up to 127 bases then run two rows per lane.
     const bool direct = n_pairs <= kDirectPairs && n_long64 == 0;
     const bool direct2 = direct && plan.max_read_len <= 2 * kLanes - 1;
-    if ((rc = c->fail_order.reserve((size_t)n_reads * 4))) return rc;
+    if ((rc = c->fail_order.reserve(((size_t)n_reads + (size_t)n_long64) * 4))) return rc;
     if ((rc = c->lanes2.reserve((size_t)n_reads * kLanes * sizeof(LaneSlot)))) return rc;
     if ((rc = c->jobs.reserve(2 * max_jobs * sizeof(FwdJob)))) return rc;  // as built + sorted by length
     if (n_long64 > 0 && (rc = c->jobs_long.reserve((size_t)n_long64 * jobs_per_chunk * sizeof(FwdJob)))) return rc;
@@ -564,6 +564,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       pa.long_lanes = pl + (size_t)n_long_main * kLanes;
       pa.n_long = n_long64;
       pa.jobs_long = c->jobs_long.as<FwdJob>();
+      pa.long_chunk_jobs = c->fail_order.as<int32_t>() + n_reads;
       pa.direct = direct ? 1 : 0;
       pa.hap_sidx = reinterpret_cast<const int32_t*>(dp + L.hap_sidx);
       pa.total_cols = (int32_t)std::min<int64_t>((int64_t)hl + n_haps, 0x7fffffff);
@@ -594,6 +595,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     d.chunk_lanes = c->lanes2.as<LaneSlot>();
     d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
     d.jobs = c->jobs.as<FwdJob>() + max_jobs;
+    const bool jobs_finalize = direct && finalize_mode == kModePacked;  // solo jobs write their packed words themselves
+    d.packed_out = jobs_finalize ? reinterpret_cast<uint64_t*>(out_dev) : nullptr;
     if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
     if (direct2)                                          launch_jobs<double, 2>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
     else if (direct && plan.max_read_len <= 4 * kLanes - 1) launch_jobs<double, 4>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
@@ -608,7 +611,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       launch_long<double, kRplF64>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
-    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
+    if (!jobs_finalize) hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
     if (side_finalize) HIP_TRY(hipStreamWaitEvent(s, c->early_copy_done, 0));  // join the side stream
   }
   if (ev) HIP_TRY(hipEventRecord(c->ev[5], s));
@@ -635,8 +638,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       int32_t k[32];
       HIP_TRY(hipMemcpy(k, c->counters.p, sizeof k, hipMemcpyDeviceToHost));
       fprintf(stderr, "[gklhip] policy+plan phases after the policy (us): hist %.1f scan %.1f scatter %.1f pack %.1f jobs %.1f sort %.1f | "
-              "%d affected reads, %d chunks, %d jobs\n", k[16] * 0.01, k[17] * 0.01, k[18] * 0.01, k[19] * 0.01, k[20] * 0.01, k[21] * 0.01,
-              k[4], k[5], k[2]);
+              "%d affected reads, %d chunks, %d jobs | window 0: loaded %.1f ranked %.1f fitted %.1f cleared %.1f written %.1f\n",
+              k[16] * 0.01, k[17] * 0.01, k[18] * 0.01, k[19] * 0.01, k[20] * 0.01, k[21] * 0.01,
+              k[4], k[5], k[2], k[22] * 0.01, k[23] * 0.01, k[24] * 0.01, k[25] * 0.01, k[26] * 0.01);
     }
   } else {
     st.n_fallback = use_double ? n_pairs : -1;  // unknown without a sync; gklhip_get_raw fills it in
@@ -652,12 +656,11 @@ void dev_done(DevCtx* c) {
   if (c->last_stream && c->have_last) (void)hipStreamSynchronize(c->last_stream);
   for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev_slot[0], &c->plan_dev_slot[1], &c->raw32, &c->raw64, &c->used64,
                     &c->counters, &c->stream_buf, &c->out_dev, &c->batch_dev, &c->read_fail,
-                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->res_dev, &c->hap_flags})
+                    &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->hap_flags})
     b->release();
   c->stage_slot[0].release();
   c->stage_slot[1].release();
   c->res_pin.release();
-  c->res_pin2.release();
   if (c->policy_done) (void)hipEventDestroy(c->policy_done);
   if (c->early_copy_done) (void)hipEventDestroy(c->early_copy_done);
   if (c->call_done) (void)hipEventDestroy(c->call_done);
@@ -752,64 +755,40 @@ int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
   }
   const int mode = c->cfg.finalize;
   const bool on_device = (mode == GKLHIP_FINALIZE_DEVICE_F64 || mode == GKLHIP_FINALIZE_DEVICE_REF32);
-  // Small calls: the kernels store their results straight into pinned host memory (posted writes over PCIe,
-  // 8 bytes per pair) -- a copy-engine transfer behind the last kernel costs ~15 us of queue hand-offs.
-  const bool direct_out = n_pairs <= kOnePassPairs;
+  // The kernels store their results straight into pinned host memory (posted writes over PCIe, 8 bytes per pair):
+  // a copy-engine transfer behind the last kernel costs a small call ~15 us of queue hand-offs, and in a big call
+  // the runtime's copy kernel for the early results slowed the fp64 pass it was meant to overlap with by a third.
+  if ((rc = c->res_pin.reserve((size_t)n_pairs * 8))) return rc;
   double* pin_out = nullptr;
-  if (direct_out) {
-    if ((rc = c->res_pin.reserve((size_t)n_pairs * 8))) return rc;
+  {
     void* p = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&p, c->res_pin.p, 0));
     pin_out = static_cast<double*>(p);
   }
   if (on_device) {
-    if (direct_out) {
-      if ((rc = run_device(c, &db, pin_out, mode, s, inline_inputs))) return rc;
-      HIP_TRY(hipStreamSynchronize(s));
-      memcpy(out_host, c->res_pin.p, (size_t)n_pairs * 8);
-      return GKLHIP_OK;
-    }
-    if ((rc = c->out_dev.reserve((size_t)n_pairs * 8))) return rc;
-    if ((rc = run_device(c, &db, c->out_dev.as<double>(), mode, s, inline_inputs))) return rc;
-    HIP_TRY(hipMemcpyAsync(out_host, c->out_dev.p, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, s));
+    if ((rc = run_device(c, &db, pin_out, mode, s, inline_inputs))) return rc;
     HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out_host, c->res_pin.p, (size_t)n_pairs * 8);
     return GKLHIP_OK;
   }
-  // reference-exact finalisation on the host: one packed 8-byte word per pair comes back through pinned
-  // memory.  The fp32 results are final as soon as the policy has run, so in a big call they are copied out
-  // on a second stream and finalised by the host WHILE the fp64 recomputation pass runs; only the recomputed
-  // pairs are left for after the last kernel.
+  // Reference-exact finalisation on the host: one packed 8-byte word per pair.  The fp32 results are final as soon
+  // as the policy has run, so in a big call the host finalises them WHILE the fp64 recomputation pass runs; only the
+  // recomputed pairs are left for after the last kernel (their words are rewritten in place by finalize64_kernel;
+  // the early pass skips every word that is not fp32-tagged, whatever it holds at that moment).
   const int threads = finalize_threads(c);
-  const size_t bytes = (size_t)n_pairs * 8;
   HostFinalizer fin;
-  if (direct_out) {
-    // a GATK-sized call (the fp64 stage of a region without underflowed pairs -- the usual case -- is two launches
-    // that find nothing to do): one pass over the words once the last kernel is done
-    if ((rc = run_device(c, &db, pin_out, kModePacked, s, inline_inputs))) return rc;
+  if ((rc = run_device(c, &db, pin_out, kModePacked, s, inline_inputs))) return rc;  // records policy_done
+  if (c->cfg.use_double || n_pairs <= kOnePassPairs) {
+    // all-fp64 mode, or a GATK-sized call (the fp64 stage of a region without underflowed pairs -- the usual case --
+    // is two launches that find nothing to do): one pass over the words once the last kernel is done
     HIP_TRY(hipStreamSynchronize(s));
     c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
     return GKLHIP_OK;
   }
-  if ((rc = c->res_dev.reserve(bytes))) return rc;
-  if ((rc = c->res_pin.reserve(bytes))) return rc;
-  if (c->cfg.use_double) {
-    // all-fp64 mode: one D2H, one pass over the words
-    if ((rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s, inline_inputs))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
-    return GKLHIP_OK;
-  }
-  if ((rc = c->res_pin2.reserve(bytes))) return rc;
-  if ((rc = run_device(c, &db, c->res_dev.as<double>(), kModePacked, s, inline_inputs))) return rc;  // records policy_done
-  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->policy_done, 0));
-  HIP_TRY(hipMemcpyAsync(c->res_pin.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, c->copy_stream));
-  HIP_TRY(hipEventRecord(c->early_copy_done, c->copy_stream));
-  HIP_TRY(hipMemcpyAsync(c->res_pin2.p, c->res_dev.p, bytes, hipMemcpyDeviceToHost, s));  // after the last kernel
-  HIP_TRY(hipEventSynchronize(c->early_copy_done));
+  HIP_TRY(hipEventSynchronize(c->policy_done));
   fin.early(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
   HIP_TRY(hipStreamSynchronize(s));
-  c->stats.n_fallback = fin.late(&c->workers, c->res_pin2.as<uint64_t>(), out_host, threads);
+  c->stats.n_fallback = fin.late(&c->workers, c->res_pin.as<uint64_t>(), out_host, threads);
   return GKLHIP_OK;
 }
 

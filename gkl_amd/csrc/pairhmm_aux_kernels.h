@@ -66,12 +66,7 @@ __global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
   if (__ballot(has_n) != 0 && lane == 0) a.hap_has_n[k] = 1;
 }
 
-// Host finalisation (reference-exact log10f / log10 of the host libm) needs, per pair, either the raw
-// fp32 sum or the raw fp64 sum: one 8-byte word carries both cases -- the double's bits, or
-// 0xFFFFFFFF:float bits (a double whose high word is all ones is a NaN no computation here produces; if
-// one ever does it is replaced by the default NaN, which finalises to NaN all the same).
-constexpr int kModePacked = -2;
-constexpr uint64_t kPackedF32Tag = 0xFFFFFFFF00000000ull;
+constexpr int kModePacked = -2;  // FinalizeArgs::mode: `out` receives packed raw sums (kPackedF32Tag, pairhmm_fwd_kernel.h)
 
 struct FinalizeArgs {
   const float* raw32;
@@ -105,11 +100,7 @@ __global__ void finalize64_kernel(FinalizeArgs a, int all_pairs) {
   if (all_pairs) a.used64[p] = 1;
   else if (!a.used64[p]) return;
   if (a.mode >= 0) a.out[p] = log10(a.raw64[p]) - a.log10_init_d;
-  if (a.mode == kModePacked) {
-    uint64_t bits = (uint64_t)__double_as_longlong(a.raw64[p]);
-    if ((bits & kPackedF32Tag) == kPackedF32Tag) bits = 0x7FF8000000000000ull;
-    reinterpret_cast<uint64_t*>(a.out)[p] = bits;
-  }
+  if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[p] = packed_word(a.raw64[p]);
 }
 
 // ---- precision policy + planning of the packed fp64 recomputation pass: ONE launch -------------------------
@@ -154,7 +145,8 @@ struct PlanArgs {
   FwdJob* sorted;        // by decreasing length
   const LaneSlot* long_lanes;  // pseudo-chunks (lane 0 names the read) of reads too long for a chunk
   int32_t n_long;
-  FwdJob* jobs_long;
+  FwdJob* jobs_long;     // [n_long * n_haps]
+  int32_t* long_chunk_jobs;  // [n_long]
   // direct mode (small calls, chosen by the host): every flagged pair becomes its own job -- the read alone in a
   // wavefront against that one haplotype -- straight from the policy pass: no packing, no barriers.  Lane use is
   // poor (a 100-base read fills a quarter of the lanes) and irrelevant: such a call leaves most of the chip idle
@@ -196,9 +188,13 @@ __device__ __forceinline__ int job_class(const FwdJob& j, const int32_t* hap_pos
 // cut_cols-wide window of the stream (jobs are cut on a fixed grid of stream positions -- no prefix sums), or if it is
 // the first of its 64-haplotype segment; the job ends at the next start or the next haplotype that is not needed.
 // Everything is ballots and bit tricks on the two masks; one atomic on the job counter per segment.
+// The jobs of chunk c go to jobs[c * n_haps ...] (a job holds at least one haplotype), their number to chunk_jobs[c]:
+// no atomics at all (thousands of atomics on ONE job counter retire one per ~7 ns and were most of this phase).
 __device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const LaneSlot* lanes, int c, FwdJob* jobs,
-                                                     int32_t* job_count, int cut_cols, int lane) {
+                                                     int32_t* chunk_jobs, int cut_cols, int lane) {
   const LaneSlot sl = lanes[(int64_t)c * kLanes + lane];
+  jobs += (int64_t)c * a.n_haps;
+  int n_jobs = 0;
   uint64_t reads = __ballot(sl.read >= 0 && sl.block == 0);  // lanes that name a read of the chunk
   for (int k0 = 0; k0 < a.n_haps; k0 += kLanes) {
     const int k = k0 + lane;
@@ -217,18 +213,19 @@ __device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const La
               a.hap_pos[k - 1] / cut_cols != a.hap_pos[k] / cut_cols;
     }
     const uint64_t starts = __ballot(start);
-    int32_t base = 0;
-    if (lane == 0) base = atomicAdd(job_count, __builtin_popcountll(starts));
-    base = __builtin_amdgcn_readfirstlane(base);
+    const int base = n_jobs;
+    n_jobs += __builtin_popcountll(starts);
     if (start) {
       const uint64_t after = lane == kLanes - 1 ? 0ull : (~0ull << (lane + 1));
       const uint64_t stop = (starts | ~need) & after;
       const int e = stop ? __builtin_ctzll(stop) : kLanes;
       FwdJob j;
-      j.chunk = c; j.hap_begin = k; j.hap_end = min(k0 + e, a.n_haps); j.solo = 0;
+      j.chunk = c; j.hap_begin = k; j.hap_end = min(k0 + e, a.n_haps);
+      j.solo = job_class(j, a.hap_pos, a.hap_len) << 8;  // bit 0 clear: a packed chunk; the length class rides along for phase O
       jobs[base + __builtin_popcountll(starts & ((1ull << lane) - 1ull))] = j;
     }
   }
+  if (lane == 0) chunk_jobs[c] = n_jobs;
 }
 
 __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
@@ -314,7 +311,9 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
     __syncthreads();
     if (tid == 0) {
       int acc = 0;
-      for (int t = 0; t < kPlanBlock; t++) { const int v = s_scan[t]; s_scan[t] = acc; acc += v; }
+      const int used = min(kPlanBlock, (n + per - 1) / per);  // threads that own a non-empty segment
+      for (int t = 0; t < used; t++) { const int v = s_scan[t]; s_scan[t] = acc; acc += v; }
+      for (int t = used; t < kPlanBlock; t++) s_scan[t] = acc;
       __hip_atomic_store(a.cnts + 4, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -336,10 +335,9 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
   {
     // One wavefront per window of <= kPackWindow reads: rank sort by lanes needed (descending, stable), then best fit.
     static_assert(kPackWindow <= 2 * kLanes, "the window's lane counts sit in two registers per lane");
-    __shared__ int32_t s_pack[kPlanBlock / 64][7][kPackWindow];
+    __shared__ int32_t s_pack[kPlanBlock / 64][4][kPackWindow];
     int32_t* s_read = s_pack[wave][0]; int32_t* s_needl = s_pack[wave][1]; int32_t* s_sread = s_pack[wave][2];
-    int32_t* s_sneed = s_pack[wave][3]; int32_t* s_bin = s_pack[wave][4]; int32_t* s_off = s_pack[wave][5];
-    int32_t* s_next = s_pack[wave][6];
+    int32_t* s_sneed = s_pack[wave][3];
     const int n = ld_cnt(a.cnts + 4);
     const int n_win = (n + kPackWindow - 1) / kPackWindow;
     for (int w = blk * (kPlanBlock / 64) + wave; w < n_win; w += nblk * (kPlanBlock / 64)) {
@@ -351,6 +349,7 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
         s_needl[i] = (int)((a.read_off[r + 1] - a.read_off[r] + a.rpl) / a.rpl);  // blocks_for()
       }
       __builtin_amdgcn_wave_barrier();
+      if (w == 0 && lane == 0) a.cnts[22] = (int32_t)(wall_clock64() - clk0);
       for (int i = lane; i < cnt; i += kLanes) {
         const int ni = s_needl[i];
         int rank = 0;
@@ -362,9 +361,12 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
         s_sneed[rank] = ni;
       }
       __builtin_amdgcn_wave_barrier();
-      // best fit: lane f owns the stack of open bins with exactly f free lanes (linked through s_next), a wave-uniform
-      // bit mask says which stacks are non-empty -- the smallest free size that fits is one ctz away
-      int head = -1;
+      if (w == 0 && lane == 0) a.cnts[23] = (int32_t)(wall_clock64() - clk0);
+      // best fit: lane f owns the stack of open bins with exactly f free lanes; the stacks are linked through
+      // next_lo/next_hi (lane b holds the successor of bins b and b + 64), a wave-uniform bit mask says which stacks
+      // are non-empty -- the smallest free size that fits is one ctz away.  All in registers: readlane/select only.
+      int head = -1, next_lo = -1, next_hi = -1;
+      int bin_lo = 0, off_lo = 0, bin_hi = 0, off_hi = 0;  // where reads `lane` and `lane + 64` (sorted order) went
       uint64_t avail = 0;
       int nb = 0;  // bins opened so far
       const int need_lo = lane < cnt ? s_sneed[lane] : 0, need_hi = lane + kLanes < cnt ? s_sneed[lane + kLanes] : 0;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
         if (fits) {
           f = __builtin_ctzll(fits);
           bin = __builtin_amdgcn_readlane(head, f);
-          const int nxt = __builtin_amdgcn_readfirstlane(s_next[bin]);
+          const int nxt = __builtin_amdgcn_readlane(bin < kLanes ? next_lo : next_hi, bin & 63);
           if (lane == f) head = nxt;
           if (nxt < 0) avail &= ~(1ull << f);
         } else {
@@ -385,26 +387,34 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
         const int left = f - nn;
         if (left > 0) {
           const int old = __builtin_amdgcn_readlane(head, left);
-          if (lane == 0) s_next[bin] = old;
+          if (lane == (bin & 63)) { if (bin < kLanes) next_lo = old; else next_hi = old; }
           if (lane == left) head = bin;
           avail |= 1ull << left;
         }
-        if (lane == 0) { s_bin[i] = bin; s_off[i] = kLanes - f; }
+        if (lane == (i & 63)) { if (i < kLanes) { bin_lo = bin; off_lo = kLanes - f; } else { bin_hi = bin; off_hi = kLanes - f; } }
       }
+      if (w == 0 && lane == 0) a.cnts[24] = (int32_t)(wall_clock64() - clk0);
       int base = 0;
       if (lane == 0) base = atomicAdd(a.cnts + 5, nb);
       base = __shfl(base, 0, kLanes);
-      __builtin_amdgcn_wave_barrier();
       LaneSlot idle; idle.read = -1; idle.block = 0;
       for (int i = lane; i < nb * kLanes; i += kLanes) a.lanes2[(int64_t)base * kLanes + i] = idle;
-      __builtin_amdgcn_wave_barrier();  // (same wavefront wrote the idle slots: program order per lane is not enough across lanes)
-      __threadfence_block();
-      for (int i = 0; i < cnt; i++)
-        for (int b = lane; b < s_sneed[i]; b += kLanes) {
-          LaneSlot sl; sl.read = s_sread[i]; sl.block = b;
-          a.lanes2[(int64_t)(base + s_bin[i]) * kLanes + s_off[i] + b] = sl;
-        }
       __builtin_amdgcn_wave_barrier();
+      __threadfence_block();  // the idle slots before the real ones (other lanes of this wavefront wrote them)
+      if (w == 0 && lane == 0) a.cnts[25] = (int32_t)(wall_clock64() - clk0);
+      // every lane writes the slots of its (up to two) reads
+      if (lane < cnt) {
+        LaneSlot sl; sl.read = s_sread[lane];
+        LaneSlot* dst = a.lanes2 + (int64_t)(base + bin_lo) * kLanes + off_lo;
+        for (int b = 0; b < need_lo; b++) { sl.block = b; dst[b] = sl; }
+      }
+      if (lane + kLanes < cnt) {
+        LaneSlot sl; sl.read = s_sread[lane + kLanes];
+        LaneSlot* dst = a.lanes2 + (int64_t)(base + bin_hi) * kLanes + off_hi;
+        for (int b = 0; b < need_hi; b++) { sl.block = b; dst[b] = sl; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (w == 0 && lane == 0) a.cnts[26] = (int32_t)(wall_clock64() - clk0);
     }
   }
   grid_barrier(bar, target);
@@ -423,31 +433,50 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
     const double est_steps = (double)max(total, 1) * (double)a.total_cols * fmin(density, 1.0);
     const int cut_cols = max(a.min_job_cols, (int)fmin(est_steps / (double)a.wanted_jobs, 1e9));
     const int n_waves = nblk * (kPlanBlock / 64), w = blk * (kPlanBlock / 64) + wave;
-    for (int c = w; c < total; c += n_waves) build_jobs_for_chunk(a, a.lanes2, c, a.jobs, a.cnts + 2, cut_cols, lane);
-    for (int c = w; c < a.n_long; c += n_waves) build_jobs_for_chunk(a, a.long_lanes, c, a.jobs_long, a.cnts + 8, 0x7fffffff, lane);
+    // (`order` has done its duty in phase W: it now takes the job count of every chunk)
+    for (int c = w; c < total; c += n_waves) build_jobs_for_chunk(a, a.lanes2, c, a.jobs, a.order, cut_cols, lane);
+    for (int c = w; c < a.n_long; c += n_waves) build_jobs_for_chunk(a, a.long_lanes, c, a.jobs_long, a.long_chunk_jobs, 0x7fffffff, lane);
   }
   grid_barrier(bar, target);
   stamp(4);
 
-  // ---- O: order the jobs longest first (block 0) ----
+  // ---- O: order the jobs longest first (block 0): counting sort over the chunks' job lists ----
   if (blk != 0) return;
   {
     int32_t* cnt = s_i32;                // [kJobClasses]
     int32_t* base = s_i32 + kJobClasses; // [kJobClasses]
-    const int n = ld_cnt(a.cnts + 2);
+    const int total = ld_cnt(a.cnts + 5);
     __syncthreads();
     if (tid < kJobClasses) cnt[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += kPlanBlock) atomicAdd(&cnt[job_class(a.jobs[i], a.hap_pos, a.hap_len)], 1);
+    for (int c = tid; c < total; c += kPlanBlock) {
+      const FwdJob* mine = a.jobs + (int64_t)c * a.n_haps;
+      const int n = a.order[c];
+      for (int i = 0; i < n; i++) atomicAdd(&cnt[mine[i].solo >> 8], 1);
+    }
     __syncthreads();
     if (tid == 0) {
       int acc = 0;
       for (int c = 0; c < kJobClasses; c++) { base[c] = acc; acc += cnt[c]; }
+      a.cnts[2] = acc;  // read by the next kernel
     }
     __syncthreads();
-    for (int i = tid; i < n; i += kPlanBlock) {
-      const FwdJob j = a.jobs[i];
-      a.sorted[atomicAdd(&base[job_class(j, a.hap_pos, a.hap_len)], 1)] = j;
+    for (int c = tid; c < total; c += kPlanBlock) {
+      const FwdJob* mine = a.jobs + (int64_t)c * a.n_haps;
+      const int n = a.order[c];
+      for (int i = 0; i < n; i++) {
+        const FwdJob j = mine[i];
+        a.sorted[atomicAdd(&base[j.solo >> 8], 1)] = j;
+      }
+    }
+    // the striped long-read kernel takes its jobs in one list: compact the pseudo-chunks' lists in place
+    if (tid == 0 && a.n_long > 0) {
+      int at = 0;
+      for (int c = 0; c < a.n_long; c++) {
+        const int n = a.long_chunk_jobs[c];
+        for (int i = 0; i < n; i++) a.jobs_long[at++] = a.jobs_long[(int64_t)c * a.n_haps + i];  // at <= c * n_haps + i
+      }
+      a.cnts[8] = at;
     }
   }
   stamp(5);

@@ -76,7 +76,7 @@ struct LaneSlot {  // one lane of a chunk: which read it holds, and which RPL-ro
 
 struct FwdJob {  // one wave job of the job-list pass: stream haps [hap_begin, hap_end) through a chunk
   int32_t chunk, hap_begin, hap_end;
-  int32_t solo;  // != 0: `chunk` is a READ index and the wavefront holds that read alone (no lane table)
+  int32_t solo;  // bit 0: `chunk` is a READ index and the wavefront holds that read alone (no lane table); bits 8..: planner's length class
 };
 
 template <typename T>
@@ -98,7 +98,20 @@ struct FwdArgs {
   const FwdJob* jobs;
   const int32_t* job_count;
   int32_t* job_next;
+  // solo jobs of a call whose results go back as packed words (see kPackedF32Tag): the wavefront that recomputed a
+  // pair also writes its word, so that such a (small) call needs no finalisation launch.  NULL otherwise.
+  uint64_t* packed_out;
 };
+
+// Host finalisation (reference-exact log10f / log10 of the host libm) needs, per pair, either the raw
+// fp32 sum or the raw fp64 sum: one 8-byte word carries both cases -- the double's bits, or
+// 0xFFFFFFFF:float bits (a double whose high word is all ones is a NaN no computation here produces; if
+// one ever does it is replaced by the default NaN, which finalises to NaN all the same).
+constexpr uint64_t kPackedF32Tag = 0xFFFFFFFF00000000ull;
+__device__ __forceinline__ uint64_t packed_word(double raw) {
+  const uint64_t bits = (uint64_t)__double_as_longlong(raw);
+  return (bits & kPackedF32Tag) == kPackedF32Tag ? 0x7FF8000000000000ull : bits;
+}
 
 // ---- cross-lane helpers -----------------------------------------------------
 // wave_shr:1 (DPP ctrl 0x138): lane L reads lane L-1 across the whole wavefront; lane 0 reads 0
@@ -553,10 +566,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     idx = __builtin_amdgcn_readfirstlane(idx);
     if (idx >= n) break;
     const FwdJob j = a.jobs[idx];
-    const int chunk_id = j.solo ? ~j.chunk : j.chunk;
+    const bool solo = (j.solo & 1) != 0;
+    const int chunk_id = solo ? ~j.chunk : j.chunk;
     if (chunk_id != loaded_chunk) {
       LaneSlot slot;
-      if (j.solo) {  // the read alone in the wavefront: lanes 0 .. ceil((R+1)/RPL)-1 hold its row blocks
+      if (solo) {  // the read alone in the wavefront: lanes 0 .. ceil((R+1)/RPL)-1 hold its row blocks
         const int R = (int)(a.b.read_off[j.chunk + 1] - a.b.read_off[j.chunk]);
         slot.read = lane < (R + RPL) / RPL ? j.chunk : -1;
         slot.block = lane;
@@ -569,6 +583,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
       loaded_chunk = chunk_id;
     }
     job.run(a, lane, j.hap_begin, j.hap_end);
+    if (sizeof(T) == 8 && solo && a.packed_out && job.out_read >= 0) {  // the lane that stored the pair's sum
+      const int64_t p = (int64_t)j.chunk * a.b.n_haps + a.hap_orig[j.hap_begin];
+      a.packed_out[p] = packed_word((double)a.raw[p]);
+    }
   }
 }
 

@@ -155,6 +155,40 @@ class DeviceBatch:
                       self.hap_off.ctypes.data_as(_i64p), *[x.data_ptr() for x in t])
 
 
+class PinnedBatch:
+    """A FlatBatch whose six byte arrays live in page-locked memory from gklhip_host_alloc -- what the JNI shim's
+    marshalling arenas are (jni_shim.cpp), so that gklhip_compute's host-to-device copies are plain DMA."""
+
+    def __init__(self, batch: FlatBatch):
+        import dataclasses
+        lib = load_library()
+        lib.gklhip_host_alloc.restype = C.c_void_p
+        lib.gklhip_host_alloc.argtypes = [C.c_size_t]
+        lib.gklhip_host_free.argtypes = [C.c_void_p]
+        self._lib, self._ptrs, arrays = lib, [], {}
+        for name in ("read_bases", "read_quals", "ins_gop", "del_gop", "gcp", "hap_bases"):
+            src = np.ascontiguousarray(getattr(batch, name), np.uint8)
+            p = lib.gklhip_host_alloc(max(1, src.size))
+            if not p:
+                raise OutOfMemoryError("gklhip_host_alloc failed")
+            self._ptrs.append(p)
+            dst = np.ctypeslib.as_array((C.c_uint8 * max(1, src.size)).from_address(p))[:src.size]
+            dst[:] = src
+            arrays[name] = dst
+        self.batch = dataclasses.replace(batch, **arrays)
+
+    def close(self):
+        for p in self._ptrs:
+            self._lib.gklhip_host_free(p)
+        self._ptrs = []
+
+    def __enter__(self):
+        return self.batch
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def partition_reads(read_off, n_parts: int):
     """The library's sharding rule (gklhip_partition_reads): boundaries of contiguous read ranges balanced by cells."""
     lib = load_library()

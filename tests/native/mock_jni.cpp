@@ -46,6 +46,20 @@ struct Mock {
   bool pending = false;
   std::string exc_class, exc_msg;
   long refs_created = 0, refs_deleted = 0, unimplemented_calls = 0;
+  // What -Xcheck:jni enforces (the reference's test JVMs run with it, build.gradle:101-104):
+  //  * no JNI call with an exception pending, except the handful the specification allows;
+  //  * at most 16 live local references without EnsureLocalCapacity;
+  //  * DeleteLocalRef only of references that are live.
+  long violations = 0, max_live_refs = 0;
+  std::string first_violation;
+  std::multiset<const void*> live;
+  void violation(const std::string& what) { if (!violations++) first_violation = what; }
+  void check_no_pending(const char* fn) { if (pending) violation(std::string(fn) + " called with an exception pending (" + exc_class + ")"); }
+  void hand_out(const void* ref) {
+    refs_created++;
+    live.insert(ref);
+    max_live_refs = std::max<long>(max_live_refs, (long)live.size());
+  }
   Obj* make(Obj::Kind k) { heap.emplace_back(new Obj()); heap.back()->kind = k; return heap.back().get(); }
   void raise(const char* cls, const std::string& msg) { pending = true; exc_class = cls; exc_msg = msg; }
 };
@@ -59,19 +73,27 @@ void unimplemented() {
 }
 
 jclass m_FindClass(JNIEnv* e, const char* name) {
+  M(e)->check_no_pending("FindClass");
   Obj* c = M(e)->make(Obj::CLASS);
   c->name = name;
-  M(e)->refs_created++;
+  M(e)->hand_out(c);
   return reinterpret_cast<jclass>(c);
 }
 jint m_ThrowNew(JNIEnv* e, jclass c, const char* msg) {
+  M(e)->check_no_pending("ThrowNew");
   M(e)->raise(O(c)->name.c_str(), msg ? msg : "");
   return 0;
 }
 void m_ExceptionClear(JNIEnv* e) { M(e)->pending = false; }
 jboolean m_ExceptionCheck(JNIEnv* e) { return M(e)->pending ? JNI_TRUE : JNI_FALSE; }
-void m_DeleteLocalRef(JNIEnv* e, jobject) { M(e)->refs_deleted++; }
+void m_DeleteLocalRef(JNIEnv* e, jobject o) {  // allowed with an exception pending
+  M(e)->refs_deleted++;
+  auto it = M(e)->live.find(o);
+  if (it == M(e)->live.end()) M(e)->violation("DeleteLocalRef of a reference that is not live");
+  else M(e)->live.erase(it);
+}
 jfieldID m_GetFieldID(JNIEnv* e, jclass c, const char* name, const char* sig) {
+  M(e)->check_no_pending("GetFieldID");
   if (strcmp(sig, "[B") != 0 || !O(c)->class_fields.count(name)) {
     M(e)->raise("java/lang/NoSuchFieldError", name);
     return nullptr;
@@ -80,24 +102,28 @@ jfieldID m_GetFieldID(JNIEnv* e, jclass c, const char* name, const char* sig) {
   return reinterpret_cast<jfieldID>(const_cast<std::string*>(&*it));
 }
 jobject m_GetObjectField(JNIEnv* e, jobject o, jfieldID f) {
+  M(e)->check_no_pending("GetObjectField");
   const std::string& name = *reinterpret_cast<std::string*>(f);
   auto it = O(o)->fields.find(name);
   if (it == O(o)->fields.end() || !it->second) return nullptr;
-  M(e)->refs_created++;
+  M(e)->hand_out(it->second);
   return reinterpret_cast<jobject>(it->second);
 }
-jsize m_GetArrayLength(JNIEnv*, jarray a) {
+jsize m_GetArrayLength(JNIEnv* e, jarray a) {
+  M(e)->check_no_pending("GetArrayLength");
   Obj* o = O(a);
   return (jsize)(o->kind == Obj::BYTES ? o->bytes.size() : o->kind == Obj::DOUBLES ? o->doubles.size()
                  : o->kind == Obj::LONGS ? o->longs.size() : o->kind == Obj::INTS ? o->ints.size() : o->elems.size());
 }
 jobject m_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) {
+  M(e)->check_no_pending("GetObjectArrayElement");
   Obj* o = O(a);
   if (i < 0 || (size_t)i >= o->elems.size()) { M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "element"); return nullptr; }
-  if (o->elems[i]) M(e)->refs_created++;
+  if (o->elems[i]) M(e)->hand_out(o->elems[i]);
   return reinterpret_cast<jobject>(o->elems[i]);
 }
 void m_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, jbyte* buf) {
+  M(e)->check_no_pending("GetByteArrayRegion");
   Obj* o = O(a);
   if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->bytes.size()) {
     M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "byte region");
@@ -106,6 +132,7 @@ void m_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, jbyte
   memcpy(buf, o->bytes.data() + start, (size_t)len);
 }
 void m_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, const jbyte* buf) {
+  M(e)->check_no_pending("SetByteArrayRegion");
   Obj* o = O(a);
   if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->bytes.size()) {
     M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "byte region");
@@ -114,6 +141,7 @@ void m_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, const
   memcpy(o->bytes.data() + start, buf, (size_t)len);
 }
 void m_SetIntArrayRegion(JNIEnv* e, jintArray a, jsize start, jsize len, const jint* buf) {
+  M(e)->check_no_pending("SetIntArrayRegion");
   Obj* o = O(a);
   if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->ints.size()) {
     M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "int region");
@@ -122,6 +150,7 @@ void m_SetIntArrayRegion(JNIEnv* e, jintArray a, jsize start, jsize len, const j
   memcpy(o->ints.data() + start, buf, sizeof(int32_t) * (size_t)len);
 }
 void m_SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
+  M(e)->check_no_pending("SetDoubleArrayRegion");
   Obj* o = O(a);
   if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->doubles.size()) {
     M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "double region");
@@ -131,12 +160,14 @@ void m_SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, c
 }
 
 jdoubleArray m_NewDoubleArray(JNIEnv* e, jsize len) {
+  M(e)->check_no_pending("NewDoubleArray");
   Obj* o = M(e)->make(Obj::DOUBLES);
   o->doubles.assign((size_t)len, 0.0);
-  M(e)->refs_created++;
+  M(e)->hand_out(o);
   return reinterpret_cast<jdoubleArray>(o);
 }
 void m_GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize start, jsize len, jlong* buf) {
+  M(e)->check_no_pending("GetLongArrayRegion");
   Obj* o = O(a);
   if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->longs.size()) {
     M(e)->raise("java/lang/ArrayIndexOutOfBoundsException", "long region");
@@ -186,12 +217,15 @@ enum {
   MOCK_NULL_READQUALS = 2,    // read 0 has readQuals == null
   MOCK_SKIP_INIT = 4,         // call compute without initNative
   MOCK_SHORT_QUALS = 8,       // read 0's insertionGOP is one byte short
-  MOCK_NULL_READ_ELEMENT = 16 // readDataArray[0] == null
+  MOCK_NULL_READ_ELEMENT = 16, // readDataArray[0] == null
+  MOCK_COMPUTE_AFTER_DONE = 32, // initNative, doneNative, THEN computeLikelihoodsNative (the reference keeps working)
+  MOCK_REINIT_TWICE = 64        // initNative again (same arguments, then the other precision and back) before computing
 };
 
 // Returns 0 = ran without a Java exception, 1 = exception pending after initNative,
 // 2 = after computeLikelihoodsNative, -1 = could not load / resolve the library.
-// counters: [0] local refs handed out, [1] DeleteLocalRef calls.
+// counters: [0] local refs handed out, [1] DeleteLocalRef calls, [2] -Xcheck:jni-style violations, [3] most local
+// references live at once.  The first violation's text replaces the exception message when there is no exception.
 int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_reads, int n_haps,
                 const int64_t* read_off, const int64_t* hap_off, const uint8_t* rb, const uint8_t* rq,
                 const uint8_t* ri, const uint8_t* rd, const uint8_t* rc, const uint8_t* hb, double* out,
@@ -241,19 +275,29 @@ int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_rea
     f_init(env, nullptr, reinterpret_cast<jclass>(read_cls), reinterpret_cast<jclass>(hap_cls),
            use_double ? JNI_TRUE : JNI_FALSE, max_threads);
     if (m.pending) rc_ = 1;
+    if (rc_ == 0 && (flags & MOCK_REINIT_TWICE)) {
+      f_init(env, nullptr, reinterpret_cast<jclass>(read_cls), reinterpret_cast<jclass>(hap_cls), use_double ? JNI_TRUE : JNI_FALSE, max_threads);
+      f_init(env, nullptr, reinterpret_cast<jclass>(read_cls), reinterpret_cast<jclass>(hap_cls), use_double ? JNI_FALSE : JNI_TRUE, max_threads);
+      f_init(env, nullptr, reinterpret_cast<jclass>(read_cls), reinterpret_cast<jclass>(hap_cls), use_double ? JNI_TRUE : JNI_FALSE, max_threads);
+      if (m.pending) rc_ = 1;
+    }
   }
+  if (rc_ == 0 && (flags & MOCK_COMPUTE_AFTER_DONE)) f_done(env, nullptr);
   if (rc_ == 0) {
     f_compute(env, nullptr, reinterpret_cast<jobjectArray>(reads), reinterpret_cast<jobjectArray>(haps),
               reinterpret_cast<jdoubleArray>(likelihoods));
     if (m.pending) rc_ = 2;
   }
+  // (a JVM would have the exception pending on return to Java; doneNative takes no JNI calls)
   f_done(env, nullptr);
   memcpy(out, likelihoods->doubles.data(), sizeof(double) * (size_t)out_len);
   if (m.pending) {
     snprintf(exc_class, 256, "%s", m.exc_class.c_str());
     snprintf(exc_msg, 512, "%s", m.exc_msg.c_str());
+  } else if (m.violations) {
+    snprintf(exc_msg, 512, "%s", m.first_violation.c_str());
   }
-  if (counters) { counters[0] = m.refs_created; counters[1] = m.refs_deleted; }
+  if (counters) { counters[0] = m.refs_created; counters[1] = m.refs_deleted; counters[2] = m.violations; counters[3] = m.max_live_refs; }
   return rc_;
 }
 

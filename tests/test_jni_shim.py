@@ -75,6 +75,39 @@ def test_jni_full_path_matches_oracle_bit_for_bit(oracle):
         exp = oracle.batch(b, use_double=use_double, n_threads=8)
         assert out.tobytes() == exp.tobytes()
         assert refs[0] == refs[1] > 0  # every local ref handed out was deleted
+        # what the reference's test JVMs check with -Xcheck:jni (build.gradle:101-104): no JNI call with an exception
+        # pending, no DeleteLocalRef of a dead reference, never more than 16 local references alive
+        assert refs[2] == 0, msg
+        assert refs[3] <= 16
+
+
+def test_shims_compile_against_a_specification_shaped_jni_header():
+    # the real-JDK path (GKL_USE_SYSTEM_JNI) of all four shims: distinct jobject/jclass/jbyteArray... classes and the
+    # struct-of-function-pointers table, at least type-checked here (no JDK in the image)
+    mockjni.typecheck_sysjni()
+
+
+@pytest.mark.gpu
+def test_system_jni_build_of_the_shim_runs_bit_exact(oracle):
+    mockjni.build_sysjni()
+    b = make_batch("hc", 40, 8, seed=35)
+    rc, out, cls, msg, refs = mockjni.run(b, lib_path=mockjni.SYSJNI_LIB)
+    assert rc == 0, (cls, msg)
+    assert out.tobytes() == oracle.batch(b, n_threads=8).tobytes()
+    assert refs[0] == refs[1] > 0 and refs[2] == 0 and refs[3] <= 16
+
+
+@pytest.mark.gpu
+def test_jni_lifecycle_follows_the_reference(oracle):
+    """initNative only re-sets globals and doneNative is empty in the reference (IntelPairHmm.cc:70-116,189-192):
+    calling initNative again (same or other arguments) or computing after doneNative must keep working."""
+    b = make_batch("hc", 30, 6, seed=34)
+    exp = oracle.batch(b, n_threads=4)
+    for flags in (mockjni.REINIT_TWICE, mockjni.COMPUTE_AFTER_DONE, mockjni.REINIT_TWICE | mockjni.COMPUTE_AFTER_DONE):
+        rc, out, cls, msg, refs = mockjni.run(b, flags=flags)
+        assert rc == 0, (cls, msg)
+        assert out.tobytes() == exp.tobytes()
+        assert refs[2] == 0, msg
 
 
 @pytest.mark.gpu
@@ -96,8 +129,9 @@ def test_jni_argument_errors():
     assert rc == 2 and cls == "java/lang/IllegalArgumentException"
     rc, _, cls, msg, _ = mockjni.run(b, flags=mockjni.SHORT_QUALS)
     assert rc == 2 and cls == "java/lang/IllegalArgumentException"
-    rc, _, cls, msg, _ = mockjni.run(b, flags=mockjni.NULL_READ_ELEMENT)
+    rc, _, cls, msg, refs = mockjni.run(b, flags=mockjni.NULL_READ_ELEMENT)
     assert rc == 2 and cls == "java/lang/IllegalArgumentException"
+    assert refs[2] == 0 and refs[3] <= 16   # the error paths, too, make no JNI call with the exception pending
     rc, out, cls, msg, _ = mockjni.run(b, out_len=b.n_pairs - 1)
     assert rc == 2 and cls == "java/lang/IllegalArgumentException" and np.all(out == -12345.0)
 
