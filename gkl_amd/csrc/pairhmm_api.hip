@@ -167,7 +167,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // appends its six input arrays (`batch`: 5 read arrays at `batch_stride`, then the haplotype bases), so that plan
 // and inputs travel in ONE copy.
 struct PlanLayout {
-  size_t lanes, groups, hap_len, hap_pos, hap_orig, hap_sidx, hap_group, hap_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count,
+  size_t lanes, groups, hap_len, hap_pos, hap_pos_flat, hap_orig, hap_sidx, hap_group, hap_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count,
       batch, batch_stride, total;
 };
 PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lanes, size_t n_long_jobs, size_t inline_read_bytes,
@@ -178,6 +178,7 @@ PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lane
   l.groups = o; o = align_up(o + p.groups.size() * sizeof(PlanGroup));
   l.hap_len = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_pos = o; o = align_up(o + (size_t)n_haps * 4);
+  l.hap_pos_flat = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_orig = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_sidx = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_group = o; o = align_up(o + (size_t)n_haps * 4);
@@ -245,7 +246,7 @@ constexpr int kRplF64 = GKL_RPL_F64;
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block
 constexpr int64_t kDirectPairs = 4096;         // calls up to this many pairs: one fp64 job per flagged pair, no packing
 constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the policy + planning kernel (a grid barrier costs ~50 ns per block)
-constexpr int kFallbackWantedJobs = 6144;      // the packed fp64 pass is cut into about this many jobs (2 per wavefront slot)
+constexpr int kFallbackWantedJobs = 12288;     // the packed fp64 pass is cut into about this many jobs (4 per wavefront slot)
 constexpr int64_t kOnePassPairs = 65536;      // host-buffer calls up to this many pairs finalise in one pass after the last kernel
 constexpr int kTargetCols = 2048;  // columns of a full-size haplotype group (sweep 1024..4096: flat within 2 %, optimum 1800..2600)
 #ifndef GKL_RPL_F32
@@ -344,6 +345,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   memcpy(hs + L.groups, plan.groups.data(), plan.groups.size() * sizeof(PlanGroup));
   memcpy(hs + L.hap_len, plan.hap_len.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_pos, plan.hap_pos.data(), (size_t)n_haps * 4);
+  memcpy(hs + L.hap_pos_flat, plan.hap_pos_flat.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_orig, plan.hap_orig.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_sidx, plan.hap_sidx.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_group, plan.hap_group.data(), (size_t)n_haps * 4);
@@ -405,7 +407,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   if ((rc = c->used64.reserve((size_t)n_pairs))) return rc;
   if ((rc = c->counters.reserve(128))) return rc;
   if ((rc = c->read_fail.reserve((size_t)n_reads * 4))) return rc;
-  if ((rc = c->stream_buf.reserve((size_t)plan.n_stream * 4))) return rc;
+  if ((rc = c->stream_buf.reserve(((size_t)plan.n_stream + (size_t)plan.n_stream_flat) * 4))) return rc;
   const int n_hist = use_double ? 0 : 2 * (n_haps + 2);
   if (!use_double && (rc = c->fail_hist.reserve((size_t)n_hist * 4))) return rc;
   if ((rc = c->hap_flags.reserve((size_t)n_haps))) return rc;
@@ -429,6 +431,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     pa.hap_pos = reinterpret_cast<const int32_t*>(pb + L.hap_pos);
     pa.hap_group = reinterpret_cast<const int32_t*>(pb + L.hap_group);
     pa.stream = c->stream_buf.as<uint32_t>();
+    // the flat stream (no gaps between groups): the fp64 recomputation's jobs are arbitrary runs of it
+    pa.hap_pos_flat = use_double ? nullptr : reinterpret_cast<const int32_t*>(pb + L.hap_pos_flat);
+    pa.stream_flat = c->stream_buf.as<uint32_t>() + plan.n_stream;
     pa.hap_has_n = c->hap_flags.as<uint8_t>();
     pa.n_haps = n_haps;
     pa.clear_a = c->counters.as<int32_t>(); pa.n_a = 32;
@@ -557,7 +562,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       pa.lanes2 = c->lanes2.as<LaneSlot>();
       pa.hap_orig = reinterpret_cast<const int32_t*>(dp + L.hap_orig);
       pa.hap_group = reinterpret_cast<const int32_t*>(dp + L.hap_group);
-      pa.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos);
+      pa.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos_flat);
       pa.hap_len = reinterpret_cast<const int32_t*>(dp + L.hap_len);
       pa.jobs = c->jobs.as<FwdJob>();
       pa.sorted = c->jobs.as<FwdJob>() + max_jobs;
@@ -592,6 +597,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     d.tab = c->dt64;
     d.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
     d.raw = c->raw64.as<double>();
+    d.stream = c->stream_buf.as<uint32_t>() + plan.n_stream;  // the flat stream: a job may run across stream groups
+    d.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos_flat);
     d.chunk_lanes = c->lanes2.as<LaneSlot>();
     d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
     d.jobs = c->jobs.as<FwdJob>() + max_jobs;

@@ -22,6 +22,8 @@ struct PrepArgs {
   const int32_t* hap_len;    // [n_haps] stream order
   const int32_t* hap_pos;    // [n_haps] stream order: stream index of column 1
   const int32_t* hap_group;  // [n_haps] stream order
+  const int32_t* hap_pos_flat;  // [n_haps] stream order: position in the flat stream (NULL: none)
+  uint32_t* stream_flat;     // all haplotypes back to back (the fp64 recomputation's jobs are runs of it), 64 idle entries at the end
   uint32_t* stream;
   uint8_t* hap_has_n;        // [n_haps] stream order (every entry written: no clear needed)
   int32_t n_haps;
@@ -50,19 +52,24 @@ __global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
   const int k = blockIdx.x * (kPrepBlock / 64) + (threadIdx.x >> 6);
   if (k >= a.n_haps) return;
   const int len = a.hap_len[k], pos = a.hap_pos[k];
+  const int posf = a.hap_pos_flat ? a.hap_pos_flat[k] : 0;
   const uint8_t* src = a.hap_bases + a.hap_src[k];
   bool has_n = false;
   for (int c = lane; c < len; c += 64) {
     const uint8_t b = src[c];  // pairhmm_common.h:57-61: A0 C1 T2 G3 N4, anything else 0
-    a.stream[pos + c] = b == 'C' ? 1u : b == 'T' ? 2u : b == 'G' ? 3u : b == 'N' ? 4u : 0u;
+    const uint32_t e = b == 'C' ? 1u : b == 'T' ? 2u : b == 'G' ? 3u : b == 'N' ? 4u : 0u;
+    a.stream[pos + c] = e;
+    if (a.hap_pos_flat) a.stream_flat[posf + c] = e;
     has_n |= b == 'N';
   }
   const bool group_ends = k + 1 == a.n_haps || a.hap_group[k + 1] != a.hap_group[k];
   if (lane == 0) {
     a.stream[pos + len] = kEntSep | (uint32_t)k;
+    if (a.hap_pos_flat) a.stream_flat[posf + len] = kEntSep | (uint32_t)k;
     a.hap_has_n[k] = 0;
   }
   if (group_ends) a.stream[pos + len + 1 + lane] = kEntIdle;
+  if (a.hap_pos_flat && k + 1 == a.n_haps) a.stream_flat[posf + len + 1 + lane] = kEntIdle;
   if (__ballot(has_n) != 0 && lane == 0) a.hap_has_n[k] = 1;
 }
 
@@ -139,7 +146,7 @@ struct PlanArgs {
   LaneSlot* lanes2;      // [n_reads * 64] worst case
   const int32_t* hap_orig;
   const int32_t* hap_group;
-  const int32_t* hap_pos;
+  const int32_t* hap_pos;   // positions in the FLAT stream (the one the fp64 kernels read)
   const int32_t* hap_len;
   FwdJob* jobs;          // as built
   FwdJob* sorted;        // by decreasing length
@@ -184,17 +191,19 @@ __device__ __forceinline__ int job_class(const FwdJob& j, const int32_t* hap_pos
 }
 
 // Run detection for one (pseudo-)chunk by ONE wavefront, 64 haplotypes (stream order) at a time: lane = haplotype.
-// A needed haplotype starts a job if its predecessor is not needed, lies in another stream group, or lies in another
-// cut_cols-wide window of the stream (jobs are cut on a fixed grid of stream positions -- no prefix sums), or if it is
-// the first of its 64-haplotype segment; the job ends at the next start or the next haplotype that is not needed.
-// Everything is ballots and bit tricks on the two masks; one atomic on the job counter per segment.
+// A needed haplotype starts a job if its predecessor is not needed, or lies in another cut_cols-wide window of the
+// flat stream (jobs are cut on a fixed grid of stream positions -- no prefix sums), or -- `by_group`, the striped
+// long-read kernel whose carry rows are sized for one stream group -- in another stream group; the job ends at the
+// next start or the next haplotype that is not needed.  Everything is ballots and bit tricks on the two masks.  A run
+// that continues from one 64-haplotype segment into the next extends the job it already has.
 // The jobs of chunk c go to jobs[c * n_haps ...] (a job holds at least one haplotype), their number to chunk_jobs[c]:
 // no atomics at all (thousands of atomics on ONE job counter retire one per ~7 ns and were most of this phase).
 __device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const LaneSlot* lanes, int c, FwdJob* jobs,
-                                                     int32_t* chunk_jobs, int cut_cols, int lane) {
+                                                     int32_t* chunk_jobs, int cut_cols, bool by_group, int lane) {
   const LaneSlot sl = lanes[(int64_t)c * kLanes + lane];
   jobs += (int64_t)c * a.n_haps;
   int n_jobs = 0;
+  bool prev_need = false;  // the last haplotype of the previous segment is needed (wave-uniform)
   uint64_t reads = __ballot(sl.read >= 0 && sl.block == 0);  // lanes that name a read of the chunk
   for (int k0 = 0; k0 < a.n_haps; k0 += kLanes) {
     const int k = k0 + lane;
@@ -206,13 +215,20 @@ __device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const La
       if (in) nd |= a.fa.used64[(int64_t)r * a.n_haps + h];
     }
     const uint64_t need = __ballot(in && nd != 0);
-    if (!need) continue;
+    if (!need) { prev_need = false; continue; }
     bool start = false;
     if (in && nd) {
-      start = lane == 0 || !((need >> (lane - 1)) & 1ull) || a.hap_group[k - 1] != a.hap_group[k] ||
-              a.hap_pos[k - 1] / cut_cols != a.hap_pos[k] / cut_cols;
+      const bool pred_needed = lane == 0 ? prev_need : ((need >> (lane - 1)) & 1ull) != 0;
+      start = !pred_needed || a.hap_pos[k - 1] / cut_cols != a.hap_pos[k] / cut_cols ||
+              (by_group && a.hap_group[k - 1] != a.hap_group[k]);
     }
     const uint64_t starts = __ballot(start);
+    if ((need & 1ull) && !(starts & 1ull)) {
+      // the run at the head of this segment continues the previous segment's last job: extend it
+      const uint64_t stop = starts | ~need;  // bit 0 is clear in both
+      const int e = stop ? __builtin_ctzll(stop) : kLanes;
+      if (lane == 0) jobs[n_jobs - 1].hap_end = min(k0 + e, a.n_haps);
+    }
     const int base = n_jobs;
     n_jobs += __builtin_popcountll(starts);
     if (start) {
@@ -221,9 +237,17 @@ __device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const La
       const int e = stop ? __builtin_ctzll(stop) : kLanes;
       FwdJob j;
       j.chunk = c; j.hap_begin = k; j.hap_end = min(k0 + e, a.n_haps);
-      j.solo = job_class(j, a.hap_pos, a.hap_len) << 8;  // bit 0 clear: a packed chunk; the length class rides along for phase O
+      j.solo = 0;
       jobs[base + __builtin_popcountll(starts & ((1ull << lane) - 1ull))] = j;
     }
+    prev_need = ((need >> (kLanes - 1)) & 1ull) != 0;
+  }
+  // the length class of every job rides along for phase O (bit 0 clear: a packed chunk); only now are the ends final
+  __threadfence_block();
+  for (int i = lane; i < n_jobs; i += kLanes) {
+    FwdJob j = jobs[i];
+    j.solo = job_class(j, a.hap_pos, a.hap_len) << 8;
+    jobs[i].solo = j.solo;
   }
   if (lane == 0) chunk_jobs[c] = n_jobs;
 }
@@ -434,8 +458,8 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
     const int cut_cols = max(a.min_job_cols, (int)fmin(est_steps / (double)a.wanted_jobs, 1e9));
     const int n_waves = nblk * (kPlanBlock / 64), w = blk * (kPlanBlock / 64) + wave;
     // (`order` has done its duty in phase W: it now takes the job count of every chunk)
-    for (int c = w; c < total; c += n_waves) build_jobs_for_chunk(a, a.lanes2, c, a.jobs, a.order, cut_cols, lane);
-    for (int c = w; c < a.n_long; c += n_waves) build_jobs_for_chunk(a, a.long_lanes, c, a.jobs_long, a.long_chunk_jobs, 0x7fffffff, lane);
+    for (int c = w; c < total; c += n_waves) build_jobs_for_chunk(a, a.lanes2, c, a.jobs, a.order, cut_cols, false, lane);
+    for (int c = w; c < a.n_long; c += n_waves) build_jobs_for_chunk(a, a.long_lanes, c, a.jobs_long, a.long_chunk_jobs, 0x7fffffff, true, lane);
   }
   grid_barrier(bar, target);
   stamp(4);

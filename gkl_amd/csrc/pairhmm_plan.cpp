@@ -20,6 +20,7 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   // ---- haplotype streams: caller order, cut into groups of ~target_cols columns ----
   p.hap_len.resize(n_haps);
   p.hap_pos.resize(n_haps);
+  p.hap_pos_flat.resize(n_haps);
   p.hap_orig.resize(n_haps);
   p.hap_sidx.resize(n_haps);
   p.hap_group.resize(n_haps);
@@ -85,6 +86,8 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
       // at least one haplotype per group; stop once the group reached its share (the last group takes the rest)
       do {  // h is a stream-order index here
         p.hap_pos[h] = p.n_stream;
+        p.hap_pos_flat[h] = p.n_stream_flat;
+        p.n_stream_flat += p.hap_len[h] + 1;
         p.hap_group[h] = (int32_t)p.groups.size();
         p.hap_src[h] = (int32_t)hap_off[p.hap_orig[h]];
         p.n_stream += p.hap_len[h] + 1;  // columns + separator
@@ -97,6 +100,8 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
       gi++;
     }
   }
+
+  p.n_stream_flat += kLanes;  // drain room behind the last haplotype
 
   // ---- read packing: best-fit decreasing into 64-lane chunks (one window = all reads) ----
   for (int r = 0; r < n_reads; r++)

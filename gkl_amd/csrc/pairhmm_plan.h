@@ -26,6 +26,7 @@ struct Plan {
   std::vector<PlanGroup> groups;
   std::vector<int32_t> hap_len;     // stream order
   std::vector<int32_t> hap_pos;     // stream index of column 1
+  std::vector<int32_t> hap_pos_flat;// same in the FLAT stream: all haplotypes back to back, one drain gap at the end
   std::vector<int32_t> hap_orig;    // stream order -> caller index
   std::vector<int32_t> hap_sidx;    // caller index -> stream order
   std::vector<int32_t> hap_group;   // stream order -> index into groups
@@ -33,6 +34,7 @@ struct Plan {
   // Stream layout (built on the device by prep_kernel): per group, for each of its haplotypes hap_len column
   // entries + 1 separator, then 64 idle entries of drain room.
   int32_t n_stream = 0;             // total stream entries
+  int32_t n_stream_flat = 0;        // entries of the flat stream (columns + separators + 64 idle)
   std::vector<int32_t> long_reads;  // reads with more than 64*rows_per_lane-1 bases: striped kernel
   int64_t useful_rows = 0;
   int max_read_len = 0;

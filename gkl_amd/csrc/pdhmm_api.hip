@@ -197,8 +197,23 @@ int pd_validate(const PdProblem& q, const double* out_host) {
   return GKLHIP_OK;
 }
 
+int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host);
+
+// An error return must not leave asynchronous copies from this call's host vectors (or the caller's arrays) in
+// flight when those go out of scope: drain the stream first.
 int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   std::lock_guard<std::mutex> lock(c->mu);
+  const int rc = pd_run_locked(c, q, out_host);
+  if (rc != GKLHIP_OK) {
+    const std::string keep = g_pd_err;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+    g_pd_err = keep;
+  }
+  return rc;
+}
+
+int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   PD_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   const size_t n = (size_t)q.n_pairs;

@@ -85,7 +85,7 @@ class PipelinedGather:
     """
 
     def __init__(self, rows_per_rank: Sequence[int], n_haps: int, device, dist_module=None, root: int = 0,
-                 depth: int = 2):
+                 depth: int = 2, always_collective: bool = False):
         import torch
         self.dist = dist_module
         if self.dist is None:
@@ -97,8 +97,10 @@ class PipelinedGather:
         self.max_n = max(self.rows) * n_haps
         # local buffers are allocated at the padded size; the compute writes the first n_local entries
         self.local = [torch.zeros(self.max_n, dtype=torch.float64, device=device) for _ in range(depth)]
+        # always_collective: issue the gather even in a one-rank group (tests of the real backend on a one-GPU box)
+        self.collective = self.world > 1 or always_collective
         self.parts = None
-        if self.rank == root and self.world > 1:
+        if self.rank == root and self.collective:
             self.parts = [[torch.empty(self.max_n, dtype=torch.float64, device=device) for _ in range(self.world)]
                           for _ in range(depth)]
         self.works = [None] * depth
@@ -113,7 +115,7 @@ class PipelinedGather:
 
     def submit(self, k: int) -> None:
         self.last = k
-        if self.world == 1:
+        if not self.collective:
             return
         slot = k % self.depth
         self.works[slot] = self.dist.gather(self.local[slot], gather_list=self.parts[slot] if self.parts else None,
@@ -128,7 +130,7 @@ class PipelinedGather:
         if self.last < 0:
             return None
         slot = self.last % self.depth
-        if self.world == 1:
+        if not self.collective:
             return self.local[slot][: self.n_local]
         if self.rank != self.root:
             return None

@@ -114,3 +114,46 @@ def test_world_size_2_shards_on_the_gpu_match_the_oracle():
     ret = mgr.dict()
     mp.spawn(_gpu_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret.get("ok_gpu") is True
+
+
+def _rccl_worker(rank, world, port, ret):
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+    try:
+        from gkl_amd import native
+        from gkl_amd.shard import PipelinedGather
+        batch = make_batch("hc", 200, 8, seed=12)
+        db = native.DeviceBatch.upload(batch, dev)
+        streams = torch.cuda.Stream(dev)
+        with native.PairHmmContext(device=0) as ctx:
+            g = PipelinedGather([batch.n_reads], batch.n_haps, dev, dist, always_collective=True)
+            for k in range(4):   # more steps than buffers: a buffer is reused only after its gather has completed
+                with torch.cuda.stream(streams):
+                    ctx.compute_device(db, g.buffer(k), streams)
+                    g.submit(k)
+            full = g.finish()
+            torch.cuda.synchronize(dev)
+            ref = ctx.compute_device(db)
+            torch.cuda.synchronize(dev)
+        ret["ok_rccl"] = bool(full is not None and torch.equal(full, ref))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_pipelined_gather_on_the_rccl_backend():
+    # bench.py's exchange step on the REAL backend (torch "nccl" = RCCL): CUDA tensors, asynchronous gather on its own
+    # stream, buffer reuse.  The test box has one GPU and RCCL refuses two ranks on one device, so the group has one
+    # rank; the N-rank case differs only in the number of peers and is covered on CPU with gloo.
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert ret.get("ok_rccl") is True
