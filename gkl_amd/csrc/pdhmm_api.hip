@@ -104,6 +104,7 @@ struct gklhip_pdhmm_ctx {
   Buf tables, inputs, entries, sums, misc, carry, jobs;
   float last_ms = 0.f;
   int fma_mode = 1;  // 1 = arithmetic of GKL's AVX-512 object (default), 0 = of its AVX2 object
+  int tail_mode = 0; // 1 = the last `batch mod SIMD width` pairs of a paired batch take the scalar engine's arithmetic, like the reference
 };
 
 extern "C" {
@@ -145,7 +146,19 @@ int gklhip_pdhmm_init(int device, gklhip_pdhmm_ctx** out_ctx) {
   if (hipMemcpy(c->tables.p, t.q2err.data(), t.q2err.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->tables.as<double>() + t.q2err.size(), t.mm.data(), t.mm.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
     return bail(pd_fail(GKLHIP_ERR_HIP, "table upload failed"));
+  {
+    const char* tm = getenv("GKL_HIP_PDHMM_TAIL");
+    c->tail_mode = (tm && strcmp(tm, "reference") == 0) ? 1 : 0;
+  }
   *out_ctx = c;
+  return GKLHIP_OK;
+}
+
+int gklhip_pdhmm_set_tail_mode(gklhip_pdhmm_ctx* c, int mode) {
+  if (!c) return pd_fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
+  if (mode != 0 && mode != 1) return pd_fail(GKLHIP_ERR_INVALID_ARG, "tail mode %d (0 or 1)", mode);
+  std::lock_guard<std::mutex> lock(c->mu);
+  c->tail_mode = mode;
   return GKLHIP_OK;
 }
 
@@ -245,6 +258,10 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   std::vector<uint8_t> job_striped;
   std::vector<PlanLane> cross_lanes;           // cross layout: [chunk][64] = {read item, block}
   std::vector<int32_t> hap_order, chunk_steps, chunk_rep;
+  size_t n_tail = 0;                           // paired layout, tail mode: the last n_tail pairs
+  std::vector<PlanLane> tail_lanes;
+  std::vector<int32_t> tail_pair, tail_steps;
+  std::vector<uint8_t> tail_striped;
   if (cross) {
     // reads are packed into 64-lane chunks ONCE; every chunk meets every haplotype (longest haplotypes first).
     std::vector<int64_t> read_off(nr + 1, 0);
@@ -277,6 +294,21 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
                      [&](int32_t x, int32_t y) { return q.hap_lengths[x] > q.hap_lengths[y]; });
     lanes.resize(job_pair.size() * kLanes, PlanLane{-1, 0});  // striped jobs do not use their lane rows
   } else {
+    // "Reference tail": GKL finishes the last `batch mod SIMD width` pairs of every vector batch with its SCALAR
+    // engine (pdhmm.h:1264-1270; 8 doubles per AVX-512 vector, 4 per AVX2 vector), whose arithmetic differs in the
+    // last bits (and, with deletions at a haplotype's end, by more).  In that mode those pairs get jobs of their own,
+    // run by the scalar-arithmetic instantiation of the kernel.
+    if (c->tail_mode == 1) n_tail = n % (size_t)(c->fma_mode ? 8 : 4);
+    const size_t n_vec = n - n_tail;
+    for (size_t i = n_vec; i < n; i++) {
+      const int nb = blocks_for(read_len_of(i), kPdRpl);
+      tail_pair.push_back((int32_t)i);
+      tail_striped.push_back(nb > kLanes ? 1 : 0);
+      tail_steps.push_back(hap_len_of(i) + std::min(nb, kLanes) - 1);
+      tail_lanes.resize(tail_lanes.size() + kLanes, PlanLane{-1, 0});
+      if (nb <= kLanes)
+        for (int b = 0; b < nb; b++) tail_lanes[tail_lanes.size() - kLanes + (size_t)b] = PlanLane{(int32_t)i, b};
+    }
     // short pairs, ordered by haplotype length so that wavefront mates finish together, are packed best-fit
     // into 64-lane chunks; a read that needs more than 64 lanes becomes a striped job
     std::vector<int64_t> pair_off(n + 1, 0);  // pack_reads_windowed() addresses reads through offsets
@@ -286,15 +318,15 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     {  // counting sort by haplotype length, longest first (the big jobs start first)
       std::vector<int32_t> cnt((size_t)q.max_hap_len + 2, 0);
       size_t n_short = 0;
-      for (size_t i = 0; i < n; i++)
+      for (size_t i = 0; i < n_vec; i++)
         if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) { cnt[(size_t)hap_len_of(i)]++; n_short++; }
       int32_t acc = 0;
       for (int64_t h = q.max_hap_len; h >= 0; h--) { const int32_t k = cnt[(size_t)h]; cnt[(size_t)h] = acc; acc += k; }
       shorts.resize(n_short);
-      for (size_t i = 0; i < n; i++)
+      for (size_t i = 0; i < n_vec; i++)
         if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) shorts[(size_t)cnt[(size_t)hap_len_of(i)]++] = (int32_t)i;
     }
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = 0; i < n_vec; i++) {
       if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) continue;
       job_pair.push_back((int32_t)i); job_striped.push_back(1); job_steps.push_back(0);
       lanes.resize(lanes.size() + kLanes, PlanLane{-1, 0});  // striped job: its lane row stays unused
@@ -320,7 +352,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const int n_jobs = n_cross_jobs + n_general;
   const int entry_stride = (q.max_hap_len + 2 * kLanes + 4 + 63) / 64 * 64;   // 64 idle, the columns, 63 skew + 4 look-ahead
   const int carry_len = entry_stride;
-  const int n_blocks = std::min(n_jobs, 256 * 8);
+  const int n_blocks = std::max(1, std::min(std::max(n_jobs, (int)n_tail), 256 * 8));
   if ((rc = c->entries.reserve(nh * (size_t)entry_stride * 4))) return rc;
   if ((rc = c->sums.reserve(n * 8))) return rc;
   if ((rc = c->misc.reserve(64))) return rc;
@@ -328,7 +360,9 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const size_t o_jl = 0, o_jp = up(lanes.size() * sizeof(PlanLane)), o_jn = o_jp + up((size_t)n_general * 4),
                o_js = o_jn + up((size_t)n_general * 4), o_cl = o_js + up((size_t)n_general),
                o_ho = o_cl + up(cross_lanes.size() * sizeof(PlanLane)), o_cs = o_ho + up(hap_order.size() * 4),
-               o_cr = o_cs + up(chunk_steps.size() * 4), jobs_total = o_cr + up(chunk_rep.size() * 4);
+               o_cr = o_cs + up(chunk_steps.size() * 4), o_tl = o_cr + up(chunk_rep.size() * 4),
+               o_tp = o_tl + up(tail_lanes.size() * sizeof(PlanLane)), o_tn = o_tp + up(n_tail * 4), o_ts = o_tn + up(n_tail * 4),
+               jobs_total = o_ts + up(n_tail);
   if ((rc = c->jobs.reserve(jobs_total + 256))) return rc;
   unsigned char* dj = c->jobs.as<unsigned char>();
   auto put = [&](size_t off, const void* src, size_t bytes) {
@@ -342,6 +376,10 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   PD_HIP_TRY(put(o_ho, hap_order.data(), hap_order.size() * 4));
   PD_HIP_TRY(put(o_cs, chunk_steps.data(), chunk_steps.size() * 4));
   PD_HIP_TRY(put(o_cr, chunk_rep.data(), chunk_rep.size() * 4));
+  PD_HIP_TRY(put(o_tl, tail_lanes.data(), tail_lanes.size() * sizeof(PlanLane)));
+  PD_HIP_TRY(put(o_tp, tail_pair.data(), n_tail * 4));
+  PD_HIP_TRY(put(o_tn, tail_steps.data(), n_tail * 4));
+  PD_HIP_TRY(put(o_ts, tail_striped.data(), n_tail));
   PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
 
   const PdTables& t = pd_tables();
@@ -379,8 +417,21 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
 
   hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)nh), dim3(kLanes), 0, s, a);   // one wavefront per haplotype item
   PD_HIP_TRY(hipEventRecord(c->ev0, s));
-  if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
-  else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(n_blocks), dim3(64), 0, s, a, t.initial_condition);
+  if (n_jobs > 0) {
+    if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(std::min(n_jobs, n_blocks)), dim3(64), 0, s, a, t.initial_condition);
+    else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(std::min(n_jobs, n_blocks)), dim3(64), 0, s, a, t.initial_condition);
+  }
+  if (n_tail > 0) {
+    PdArgs at = a;  // the tail pairs: jobs of their own, scalar-engine arithmetic (same stream: the carry rows are free again)
+    at.lanes = reinterpret_cast<const LaneSlot*>(dj + o_tl);
+    at.job_pair = reinterpret_cast<const int32_t*>(dj + o_tp);
+    at.job_steps = reinterpret_cast<const int32_t*>(dj + o_tn);
+    at.job_striped = dj + o_ts;
+    at.n_jobs = (int32_t)n_tail;
+    at.n_cross_jobs = 0;
+    at.next = c->misc.as<int32_t>() + 2;
+    hipLaunchKernelGGL((pdhmm_fwd_kernel<false, true>), dim3((unsigned)n_tail), dim3(64), 0, s, at, t.initial_condition);
+  }
   PD_HIP_TRY(hipEventRecord(c->ev1, s));
   PD_HIP_TRY(hipGetLastError());
   std::vector<double> sums(n);

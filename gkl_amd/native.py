@@ -349,6 +349,8 @@ def load_pdhmm_library(path: Optional[str] = None):
     lib.gklhip_pdhmm_init.restype = C.c_int
     lib.gklhip_pdhmm_set_fma_mode.argtypes = [C.c_void_p, C.c_int]
     lib.gklhip_pdhmm_set_fma_mode.restype = C.c_int
+    lib.gklhip_pdhmm_set_tail_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.gklhip_pdhmm_set_tail_mode.restype = C.c_int
     lib.gklhip_pdhmm_compute.argtypes = [C.c_void_p, C.POINTER(CPdhmmBatch), C.c_void_p]
     lib.gklhip_pdhmm_compute.restype = C.c_int
     lib.gklhip_pdhmm_compute_cross.argtypes = [C.c_void_p, C.POINTER(CPdhmmCross), C.c_void_p]
@@ -376,8 +378,9 @@ def pdhmm_host_table(which: int) -> np.ndarray:
 class PdhmmContext:
     """One gklhip_pdhmm context (= IntelPDHMM.initNative)."""
 
-    def __init__(self, device: int = -1, fma_mode: int = 1):
-        """fma_mode 1: bit-identical to GKL's AVX-512 PDHMM object, 0: to its AVX2 object."""
+    def __init__(self, device: int = -1, fma_mode: int = 1, reference_tail: bool = False):
+        """fma_mode 1: bit-identical to GKL's AVX-512 PDHMM object, 0: to its AVX2 object.  reference_tail: the last
+        `batch mod SIMD width` pairs of a paired batch take the scalar engine's arithmetic, as in the reference."""
         self.lib = load_pdhmm_library()
         h = C.c_void_p()
         st = self.lib.gklhip_pdhmm_init(device, C.byref(h))
@@ -385,6 +388,9 @@ class PdhmmContext:
             self._raise(st)
         self.handle = h
         st = self.lib.gklhip_pdhmm_set_fma_mode(self.handle, int(fma_mode))
+        if st != OK:
+            self._raise(st)
+        st = self.lib.gklhip_pdhmm_set_tail_mode(self.handle, 1 if reference_tail else 0)
         if st != OK:
             self._raise(st)
 

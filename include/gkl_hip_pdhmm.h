@@ -64,6 +64,14 @@ int gklhip_pdhmm_init(int device /* -1 = current */, gklhip_pdhmm_ctx** out_ctx)
  * fma(c, d, a*b)); 0 = bit-identical to its AVX2 object (avx2_impl.cc: no FMA).  Same switch as
  * gklhip_config.fma_mode of the PairHMM. */
 int gklhip_pdhmm_set_fma_mode(gklhip_pdhmm_ctx* ctx, int fma_mode);
+/* GKL finishes the last `batch mod SIMD width` pairs of every vector batch with its scalar engine (pdhmm.h:1264-1270 ->
+ * pdhmm-serial.cc:279-412), whose arithmetic differs from its vector kernels': a pair's value depends on its position
+ * in the batch.  mode 0 (default): the vector arithmetic for every pair.  mode 1 ("reference"; also
+ * GKL_HIP_PDHMM_TAIL=reference in the environment at init): gklhip_pdhmm_compute gives the pairs at positions
+ * >= batch - batch mod W (W = 8 with fma_mode 1 = the AVX-512 engine, 4 with fma_mode 0 = AVX2) the scalar engine's
+ * arithmetic, so that EVERY position matches GKL bit for bit.  (The cross entry point is not affected: the positions
+ * at which the reference's computeLikelihoods cuts its cross product into batches depend on maxMemoryInMB.) */
+int gklhip_pdhmm_set_tail_mode(gklhip_pdhmm_ctx* ctx, int mode);
 /* Host buffers in, out_host[batch] = log10 likelihoods. Negative ins/del/gcp quals ->
  * GKLHIP_ERR_INVALID_ARG (PDHMM_INPUT_DATA_ERROR in the reference). */
 int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_batch* batch, double* out_host);

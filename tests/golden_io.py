@@ -82,3 +82,20 @@ def load_pdhmm_holders_file(name="pdhmm_new.txt"):
             else:
                 exp.append(float(c[0]))
     return reads, haps, np.array(exp)
+
+
+def load_pdhmm_tail_vectors():
+    """tests/golden/pdhmm_tail_vectors.json (reference-generated, make_pdhmm_tail_fixtures.py): list of
+    (PdhmmBatch, expected AVX-512-engine doubles, expected AVX2-engine doubles)."""
+    import json
+    from gkl_amd.pdhmm_batch import PdhmmBatch
+    doc = json.load(open(os.path.join(GOLDEN, "pdhmm_tail_vectors.json")))
+    out = []
+    for v in doc["vectors"]:
+        arr = lambda k: np.frombuffer(bytes.fromhex(v[k]), dtype=np.int8).copy()  # noqa: E731
+        b = PdhmmBatch(v["batch"], v["max_hap_len"], v["max_read_len"], arr("hap_bases"), arr("hap_pdbases"), arr("read_bases"),
+                       arr("read_qual"), arr("read_ins_qual"), arr("read_del_qual"), arr("gcp"),
+                       np.asarray(v["hap_lengths"], np.int64), np.asarray(v["read_lengths"], np.int64))
+        bits = lambda k: np.array([int(x, 16) for x in v[k]], dtype=np.uint64).view(np.float64)  # noqa: E731
+        out.append((b, bits("avx512_bits"), bits("avx2_bits")))
+    return out

@@ -142,6 +142,34 @@ def test_pdhmm_no_gpu_fails_loudly():
         native.PdhmmContext()
 
 
+def expected_per_position(pd_oracle, b, sem, width):
+    """What GKL returns for every POSITION of a paired batch: its vector arithmetic (oracle semantics `sem`) for the
+    full groups of `width`, its scalar engine's (semantics 1) for the last batch mod width pairs (pdhmm.h:1264-1270)."""
+    nv = b.batch - b.batch % width
+    st, vec = pd_oracle.compute(b, semantics=sem)
+    if nv == b.batch:
+        return st, vec
+    st1, ser = pd_oracle.compute(b.subset(list(range(nv, b.batch))), semantics=1)   # (its input checks apply to the tail only)
+    return max(st, st1), np.concatenate([vec[:nv], ser])
+
+
+def test_pdhmm_tail_fixtures_pin_the_oracle_per_position(pd_oracle):
+    # reference-generated vectors (tests/golden/make_pdhmm_tail_fixtures.py): batches whose size is not a multiple of
+    # the SIMD width, haplotypes that end inside / right after a deletion
+    from tests.golden_io import load_pdhmm_tail_vectors
+    vectors = load_pdhmm_tail_vectors()
+    assert len(vectors) >= 10 and {b.batch % 8 for b, _, _ in vectors} >= set(range(1, 8))
+    differ = 0
+    for b, e512, e2 in vectors:
+        st, got512 = expected_per_position(pd_oracle, b, 2, 8)
+        assert st == 0 and got512.tobytes() == e512.tobytes()
+        st, got2 = expected_per_position(pd_oracle, b, 0, 4)
+        assert st == 0 and got2.tobytes() == e2.tobytes()
+        _, vec = pd_oracle.compute(b, semantics=2)
+        differ += int((vec.view(np.uint64) != e512.view(np.uint64)).sum())
+    assert differ > 0   # the tail positions really are a different arithmetic
+
+
 # ------------------------------------------------------------------ HIP parity (GPU)
 SEMANTICS_OF_FMA_MODE = {1: 2, 0: 0}  # fma_mode of the HIP path -> oracle semantics (AVX-512 / AVX2 arithmetic)
 
@@ -176,6 +204,41 @@ def test_pdhmm_gpu_random_batches_bit_exact(pd_ctx, pd_oracle, kw):
     assert st == 0 and out.tobytes() == vec.tobytes()
     # (the reference's scalar engine keeps the deletion state across rows and can differ from its own
     #  vector kernels by 0.2 on such random flag patterns; parity is defined against the vector kernels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fma_mode", [1, 0])
+def test_pdhmm_gpu_reference_tail_mode_matches_gkl_at_every_position(pd_oracle, fma_mode):
+    """GKL_HIP_PDHMM_TAIL=reference / gklhip_pdhmm_set_tail_mode(1): the last batch mod 8 (AVX-512 arithmetic) or
+    mod 4 (AVX2) pairs take the scalar engine's arithmetic, so every position is bit-identical to what GKL returns."""
+    from gkl_amd import native
+    from tests.golden_io import load_pdhmm_tail_vectors
+    width = 8 if fma_mode else 4
+    with native.PdhmmContext(fma_mode=fma_mode, reference_tail=True) as c:
+        for b, e512, e2 in load_pdhmm_tail_vectors():        # generated by the reference's own objects
+            exp = e512 if fma_mode else e2
+            assert c.compute(b).tobytes() == exp.tobytes()
+        rng = np.random.RandomState(91)
+        for n, kw in [(37, dict(with_n=False)), (70, dict(with_n=False, flag_rate=0.5)), (6, dict(with_n=False, read_len=(250, 300), hap_len=(10, 60))),
+                      (64, dict(with_n=False)), (5, dict(with_n=False, read_len=(1, 4), hap_len=(1, 3), flag_rate=0.7))]:
+            b = random_pd_batch(rng, n, **kw)
+            st, exp = expected_per_position(pd_oracle, b, SEMANTICS_OF_FMA_MODE[fma_mode], width)
+            assert st == 0 and c.compute(b).tobytes() == exp.tobytes(), (n, kw)
+        # the scalar engine rejects a non-ACGT read base under a SNP column (pdhmm-serial.cc:222-248): only when such a
+        # pair sits in the tail
+        bad = random_pd_batch(rng, 9, with_n=False, read_len=(10, 20), hap_len=(20, 30), flag_rate=0.0)
+        bad.read_bases.reshape(9, bad.max_read_len)[8, 0] = ord("N")
+        bad.hap_pdbases.reshape(9, bad.max_hap_len)[8, 3] = 1 | 8
+        if width == 8:
+            with pytest.raises(native.IllegalArgumentException):
+                c.compute(bad)
+        moved = bad.subset([8, 0, 1, 2, 3, 4, 5, 6, 7])      # the same pair at a vectorised position: fine
+        st, exp = expected_per_position(pd_oracle, moved, SEMANTICS_OF_FMA_MODE[fma_mode], width)
+        assert st == 0 and c.compute(moved).tobytes() == exp.tobytes()
+    # default mode: the vector arithmetic everywhere
+    with native.PdhmmContext(fma_mode=fma_mode) as c:
+        b = random_pd_batch(np.random.RandomState(92), 13, with_n=False)
+        assert c.compute(b).tobytes() == pd_oracle.compute(b, semantics=SEMANTICS_OF_FMA_MODE[fma_mode])[1].tobytes()
 
 
 def cross_product(rng, n_reads, n_haps, read_len, hap_len):
