@@ -1,4 +1,4 @@
-// JNI drop-in layer of libgkl_smithwaterman.so: the three natives of
+// JNI layer of libgkl_smithwaterman_hip.so (built under the reference's name libgkl_smithwaterman.so only by `make dropin-sw`): the three natives of
 // com.intel.gkl.smithwaterman.IntelSmithWaterman (include/gkl_sw_jni.h) over the C ABI of
 // include/gkl_hip_sw.h.  Replaces the reference's IntelSmithWaterman.cc; the arrays are copied with
 // Get/SetByteArrayRegion instead of GetPrimitiveArrayCritical (no JVM critical section is held while the

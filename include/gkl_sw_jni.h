@@ -1,5 +1,5 @@
 /*
- * gkl_sw_jni.h -- the JNI symbols of libgkl_smithwaterman.so: what GKL's
+ * gkl_sw_jni.h -- the JNI symbols of libgkl_smithwaterman_hip.so (= libgkl_smithwaterman.so after `make dropin-sw`): what GKL's
  * com.intel.gkl.smithwaterman.IntelSmithWaterman binds (reference
  * src/main/java/com/intel/gkl/smithwaterman/IntelSmithWaterman.java:188-190; native prototypes
  * src/main/native/smithwaterman/IntelSmithWaterman.h:32-52; bodies IntelSmithWaterman.cc:47-132).

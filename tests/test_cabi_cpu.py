@@ -23,8 +23,8 @@ HEADER_TO_LIBS = {
     "gkl_hip_pdhmm.h": ["libgklhip_pdhmm.so", "libgkl_pdhmm.so"],
     "gkl_pdhmm_jni.h": ["libgkl_pdhmm.so"],
     "gkl_utils_jni.h": ["libgkl_utils.so"],
-    "gkl_hip_sw.h": ["libgklhip_sw.so", "libgkl_smithwaterman.so"],
-    "gkl_sw_jni.h": ["libgkl_smithwaterman.so"],
+    "gkl_hip_sw.h": ["libgklhip_sw.so", "libgkl_smithwaterman_hip.so"],
+    "gkl_sw_jni.h": ["libgkl_smithwaterman_hip.so"],
 }
 
 

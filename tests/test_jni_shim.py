@@ -152,7 +152,7 @@ def test_jni_concurrent_callers_get_their_own_slot(oracle, n_threads, slots, mon
 def _check_jni_onload(monkeypatch, have_gpu):
     # JNI_OnLoad (not in the reference): JNI_ERR without a usable gfx950 device, so that System.load fails and
     # NativeLibraryLoader.load() returns false (GATK then falls back); JNI_VERSION_1_8 with one, or when forced
-    for name in ("libgkl_pairhmm.so", "libgkl_pdhmm.so", "libgkl_smithwaterman.so"):
+    for name in ("libgkl_pairhmm.so", "libgkl_pdhmm.so", "libgkl_smithwaterman_hip.so"):
         lib = C.CDLL(os.path.join(os.path.dirname(mockjni.JNI_LIB), name))
         lib.JNI_OnLoad.restype = C.c_int
         lib.JNI_OnLoad.argtypes = [C.c_void_p, C.c_void_p]
