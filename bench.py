@@ -143,7 +143,9 @@ def in_library_probe(n_dev, reads, haps, workload, steps, warmup):
     from gkl_amd.synth import DEFAULT_SEED, make_batch
     b = make_batch(workload, reads, haps, seed=DEFAULT_SEED)
     res = {"devices": n_dev}
-    with native.PairHmmContext(devices=list(range(n_dev))) as c:
+    # (GKL_BENCH_SAME_DEVICE=1: dry run on a one-GPU box, every shard on device 0)
+    devices = [0] * n_dev if os.environ.get("GKL_BENCH_SAME_DEVICE") == "1" else list(range(n_dev))
+    with native.PairHmmContext(devices=devices) as c:
         res["gather"] = c.gather_backend
         db = native.DeviceBatch.upload(b, "cuda:0")
         out = torch.empty(b.n_pairs, dtype=torch.float64, device="cuda:0")
@@ -392,10 +394,14 @@ def main():
             except Exception as e:  # never lose the GPU line to a baseline problem
                 res["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
-        if world > 1 and not a.no_extras and not same_device:
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and not a.no_extras:
             # The same batch through the LIBRARY's own multi-device path (one process, GKL_HIP_DEVICES-style context,
-            # RCCL gather inside the C ABI) -- what a JVM gets.  Child process with a time limit: the other ranks are
-            # idle at the barrier below, and a problem there must not cost the line above.
+            # RCCL gather inside the C ABI) -- what a JVM gets.  After the process group is gone (the other ranks have
+            # left their GPUs), in a child process with a time limit: a problem there must not cost the line.
             try:
                 p = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-library-probe", str(world), "--reads", str(a.reads),
                                     "--haps", str(a.haps), "--workload", a.workload, "--steps", str(a.steps), "--warmup", str(a.warmup)],
@@ -406,9 +412,6 @@ def main():
             except Exception as e:
                 res["in_library"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -247,6 +247,7 @@ constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this si
 constexpr int64_t kDirectPairs = 4096;         // calls up to this many pairs: one fp64 job per flagged pair, no packing
 constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the policy + planning kernel (a grid barrier costs ~50 ns per block)
 constexpr int kFallbackWantedJobs = 12288;     // the packed fp64 pass is cut into about this many jobs (4 per wavefront slot)
+constexpr int64_t kHostShardPairs = 400000;    // single-device host-buffer calls from this many pairs run as two half-batches (see gklhip_ctx::host_dev)
 constexpr int64_t kOnePassPairs = 65536;      // host-buffer calls up to this many pairs finalise in one pass after the last kernel
 constexpr int kTargetCols = 2048;  // columns of a full-size haplotype group (sweep 1024..4096: flat within 2 %, optimum 1800..2600)
 #ifndef GKL_RPL_F32
@@ -921,7 +922,15 @@ struct gklhip_ctx {
   std::mutex mu;
   gklhip_config cfg;
   std::vector<DevCtx*> dev;                          // dev[0]: where the device-resident entry point gathers
-  std::vector<std::unique_ptr<DevWorker>> workers;   // workers[d-1] drives dev[d]
+  // Engines of the host-buffer path: `dev`, or -- a single-device context serving a BIG host call -- that device's
+  // engine plus a twin on the same GPU: two half-batches whose copies and host-side log10 passes overlap each other's
+  // kernels (15.0 instead of 15.6 ms per 10k x 128 batch; smaller calls are better off whole).  Twins are created on
+  // first use and owned here.
+  std::vector<DevCtx*> host_dev;
+  std::vector<DevCtx*> twins;
+  const std::vector<DevCtx*>* last = nullptr;        // the engine list of the last call (gklhip_get_raw)
+  int host_shards = 2;                               // GKL_HIP_HOST_SHARDS
+  std::vector<std::unique_ptr<DevWorker>> workers;   // workers[d-1] drives shard d
   std::vector<int32_t> bounds;                       // read-range boundaries of the last call, [n_dev + 1]
   std::vector<std::vector<int64_t>> sub_off;         // per device: its read range's offsets rebased to 0
   bool use_rccl = false;
@@ -938,6 +947,7 @@ struct gklhip_ctx {
       if (shard_done[d]) { (void)hipSetDevice(dev[d]->device); (void)hipEventDestroy(shard_done[d]); }
     if (inputs_ready) { (void)hipSetDevice(dev[0]->device); (void)hipEventDestroy(inputs_ready); }
     for (DevCtx* d : dev) dev_done(d);
+    for (DevCtx* d : twins) dev_done(d);
   }
 };
 
@@ -971,13 +981,14 @@ gklhip_batch shard_view(gklhip_ctx* c, const gklhip_batch* b, int d) {
   return v;
 }
 
-void merge_stats(gklhip_ctx* c) {
+void merge_stats(gklhip_ctx* c, const std::vector<DevCtx*>& list) {
   gklhip_stats t;
   memset(&t, 0, sizeof t);
   bool unknown = false;
-  for (size_t d = 0; d < c->dev.size(); d++) {
+  c->last = &list;
+  for (size_t d = 0; d < list.size(); d++) {
     if (c->bounds[d + 1] == c->bounds[d]) continue;
-    const gklhip_stats& s = c->dev[d]->stats;
+    const gklhip_stats& s = list[d]->stats;
     t.n_pairs += s.n_pairs; t.cells += s.cells; t.cells_fp64 += s.cells_fp64;
     if (s.n_fallback < 0) unknown = true; else t.n_fallback += s.n_fallback;
     t.n_chunks += s.n_chunks; t.n_long_pairs += s.n_long_pairs;
@@ -995,8 +1006,8 @@ void merge_stats(gklhip_ctx* c) {
 
 // Run fn(d) for every device with a non-empty shard: device 0 on this thread, the others on their workers.
 template <typename F>
-int for_each_shard(gklhip_ctx* c, F fn) {
-  const int n = (int)c->dev.size();
+int for_each_shard(gklhip_ctx* c, int n, F fn) {
+  while ((int)c->workers.size() < n - 1) c->workers.emplace_back(new DevWorker());
   for (int d = 1; d < n; d++)
     if (c->bounds[d + 1] > c->bounds[d]) c->workers[(size_t)d - 1]->submit([=] { return fn(d); });
   int rc = c->bounds[1] > c->bounds[0] ? fn(0) : GKLHIP_OK;
@@ -1011,17 +1022,19 @@ int for_each_shard(gklhip_ctx* c, F fn) {
   return rc;
 }
 
-int multi_compute_host(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
-  const int n = (int)c->dev.size();
+int multi_compute_host(gklhip_ctx* c, const std::vector<DevCtx*>& list, const gklhip_batch* hb, double* out_host) {
+  const int n = (int)list.size();
+  c->sub_off.resize((size_t)n);
   c->bounds.assign((size_t)n + 1, 0);
   partition_reads(hb->n_reads, hb->read_off, n, c->bounds.data());
   // every device copies its own read range straight from the caller's arrays (its own PCIe link) and its
   // results straight back: the host path needs no device-to-device step at all
-  const int rc = for_each_shard(c, [=](int d) {
+  const std::vector<DevCtx*>* lp = &list;
+  const int rc = for_each_shard(c, n, [=](int d) {
     const gklhip_batch v = shard_view(c, hb, d);
-    return dev_compute_host(c->dev[(size_t)d], &v, out_host + (int64_t)c->bounds[(size_t)d] * hb->n_haps);
+    return dev_compute_host((*lp)[(size_t)d], &v, out_host + (int64_t)c->bounds[(size_t)d] * hb->n_haps);
   });
-  merge_stats(c);
+  merge_stats(c, list);
   return rc;
 }
 
@@ -1038,7 +1051,7 @@ int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev,
   HIP_TRY(hipEventRecord(c->inputs_ready, s));
   const int n_haps = db->n_haps;
   const size_t hl = (size_t)db->hap_off[n_haps];
-  int rc = for_each_shard(c, [=](int d) -> int {
+  int rc = for_each_shard(c, n, [=](int d) -> int {
     DevCtx* dc = c->dev[(size_t)d];
     const gklhip_batch v = shard_view(c, db, d);
     if (d == 0) return run_device(dc, &v, out_dev, mode, s, false);
@@ -1085,7 +1098,7 @@ int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev,
   if (rc == GKLHIP_OK)
     for (int d = 1; d < n; d++)
       if (c->bounds[(size_t)d + 1] > c->bounds[(size_t)d]) HIP_TRY(hipStreamWaitEvent(s, c->shard_done[(size_t)d], 0));
-  merge_stats(c);
+  merge_stats(c, c->dev);
   return rc;
 }
 
@@ -1175,7 +1188,6 @@ int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_
     bool distinct = true;
     for (int i = 0; i < n; i++)
       for (int j = i + 1; j < n; j++) distinct &= list[(size_t)i] != list[(size_t)j];
-    for (int d = 1; d < n; d++) c->workers.emplace_back(new DevWorker());
     c->shard_done.assign((size_t)n, nullptr);
     HIP_TRY(hipSetDevice(c->dev[0]->device));
     HIP_TRY(hipEventCreateWithFlags(&c->inputs_ready, hipEventDisableTiming));
@@ -1208,6 +1220,12 @@ int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_
       }
     }
   }
+  {
+    const char* hs = getenv("GKL_HIP_HOST_SHARDS");
+    c->host_shards = hs && *hs ? std::max(1, std::min(atoi(hs), 8)) : 2;
+  }
+  c->host_dev = c->dev;
+  c->last = &c->dev;
   HIP_TRY(hipSetDevice(c->dev[0]->device));
   *out_ctx = c.release();
   return GKLHIP_OK;
@@ -1256,6 +1274,7 @@ int gklhip_compute_device(gklhip_ctx* c, const gklhip_batch* dev_batch, double* 
     c->bounds[0] = 0;
     rc = run_device(c->dev[0], dev_batch, out_dev, mode, s, false);
     c->stats = c->dev[0]->stats;
+    c->last = &c->dev;
     return rc;
   }
   return multi_compute_device(c, dev_batch, out_dev, mode, s);
@@ -1270,14 +1289,27 @@ int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
   if (!out_host) return fail(GKLHIP_ERR_INVALID_ARG, "output array is NULL");
   std::lock_guard<std::mutex> lock(c->mu);
   c->last_reads = hb->n_reads; c->last_haps = hb->n_haps;
+  if (c->dev.size() == 1 && c->host_shards > 1 && n_pairs >= kHostShardPairs && hb->n_reads >= 2 * c->host_shards) {
+    // a big call on one device: two (GKL_HIP_HOST_SHARDS) half-batches on twin engines
+    while ((int)c->host_dev.size() < c->host_shards) {
+      DevCtx* twin = nullptr;
+      int ndev = 0;
+      HIP_TRY(hipGetDeviceCount(&ndev));
+      if ((rc = dev_init(c->dev[0]->cfg, c->dev[0]->device, ndev, &twin))) { c->host_shards = (int)c->host_dev.size(); break; }  // e.g. out of memory: stay whole
+      c->twins.push_back(twin);
+      c->host_dev.push_back(twin);
+    }
+    if (c->host_dev.size() > 1) return multi_compute_host(c, c->host_dev, hb, out_host);
+  }
   if (c->dev.size() == 1) {
     c->bounds.assign(2, hb->n_reads);
     c->bounds[0] = 0;
     rc = dev_compute_host(c->dev[0], hb, out_host);
     c->stats = c->dev[0]->stats;
+    c->last = &c->dev;
     return rc;
   }
-  return multi_compute_host(c, hb, out_host);
+  return multi_compute_host(c, c->dev, hb, out_host);
 }
 
 void* gklhip_host_alloc(size_t bytes) {
@@ -1324,9 +1356,10 @@ int gklhip_get_raw(gklhip_ctx* ctx, float* raw32, double* raw64, uint8_t* used64
   std::lock_guard<std::mutex> lock(ctx->mu);
   int64_t n_fallback = 0;
   bool any = false;
-  for (size_t d = 0; d < ctx->dev.size(); d++) {
-    DevCtx* c = ctx->dev[d];
-    if (ctx->dev.size() > 1 && ctx->bounds[d + 1] == ctx->bounds[d]) continue;
+  const std::vector<DevCtx*>& list = ctx->last ? *ctx->last : ctx->dev;
+  for (size_t d = 0; d < list.size(); d++) {
+    DevCtx* c = list[d];
+    if (list.size() > 1 && ctx->bounds[d + 1] == ctx->bounds[d]) continue;
     if (!c->have_last) continue;
     any = true;
     HIP_TRY(hipSetDevice(c->device));
