@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--haps", type=int, default=20)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--json", default=None, help="write a bench-style JSON summary of the fixture case here")
+    ap.add_argument("--fixture-x", type=int, default=4, help="how many times the fixture's 276 reads are replicated")
     a = ap.parse_args()
     import json
     from gkl_amd import native
@@ -34,11 +35,11 @@ def main():
     from tests.golden_io import load_pdhmm_holders_file
     reads, haps, _ = load_pdhmm_holders_file()
     pairs = [(h[0], h[1], r[0], r[1], r[2], r[3], r[4]) for r in reads for h in haps]
-    cases["fixture pdhmm_new x4"] = PdhmmBatch.from_pairs(pairs * 4)
+    cases[f"fixture pdhmm_new x{a.fixture_x}"] = PdhmmBatch.from_pairs(pairs * a.fixture_x)
     ctx = native.PdhmmContext()
     # the same fixture through the cross entry point (what computeLikelihoodsNative calls): reads x4, all 48 haplotypes
     one = b"\0"
-    cross_reads = PdhmmBatch.from_pairs([(one, one, r[0], r[1], r[2], r[3], r[4]) for r in reads] * 4)
+    cross_reads = PdhmmBatch.from_pairs([(one, one, r[0], r[1], r[2], r[3], r[4]) for r in reads] * a.fixture_x)
     cross_haps = PdhmmBatch.from_pairs([(h[0], h[1], one, one, one, one, one) for h in haps])
     ctx0 = native.PdhmmContext()
     ctx0.compute_cross(cross_reads, cross_haps)
@@ -55,7 +56,7 @@ def main():
     ctx0.close()
     summary = {"metric": "pdhmm_gcups", "unit": "GCUPS", "dtype": "f64", "data": "the reference's own fixture pdhmm_new.txt",
                "config": {"workload": f"IntelPDHMM.computeLikelihoods: {cross_reads.batch} reads x {cross_haps.batch} PD haplotypes "
-                                      f"(the fixture's 276 reads x4), cross entry point", "cells": cc},
+                                      f"(the fixture's 276 reads x{a.fixture_x}), cross entry point", "cells": cc},
                "kernel_ms": round(best_k, 4), "kernel_gcups": round(cc / best_k / 1e6, 1),
                "host_to_host_ms": round(best_w * 1e3, 3), "value": round(cc / best_w / 1e9, 1),
                # 12 flop per cell: M = prior * fma(.., fma(.., mul)) = 6, D = fma + mul = 3, I = fma + mul = 3 (pdhmm.h:427-443)
