@@ -168,7 +168,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // and inputs travel in ONE copy.
 struct PlanLayout {
   size_t lanes, groups, hap_len, hap_pos, hap_pos_flat, hap_orig, hap_sidx, hap_group, hap_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count,
-      batch, batch_stride, total;
+      batch, batch_stride, stream, stream_flat, has_n, total;
 };
 PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lanes, size_t n_long_jobs, size_t inline_read_bytes,
                       size_t inline_hap_bytes) {
@@ -192,6 +192,12 @@ PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lane
   l.batch = o;
   l.batch_stride = align_up(inline_read_bytes);
   if (inline_read_bytes) o = o + 5 * l.batch_stride + align_up(inline_hap_bytes);
+  // ... and, when the host holds the haplotype bases anyway, the two haplotype streams and the 'N' flags, built on
+  // the host: the first kernel then only pulls the block (its wavefronts would otherwise chase three dependent reads
+  // of pinned host memory per haplotype before the first forward kernel can start)
+  l.stream = o; if (inline_read_bytes) o = align_up(o + (size_t)p.n_stream * 4);
+  l.stream_flat = o; if (inline_read_bytes) o = align_up(o + (size_t)p.n_stream_flat * 4);
+  l.has_n = o; if (inline_read_bytes) o = align_up(o + (size_t)n_haps);
   l.total = o;
   return l;
 }
@@ -244,7 +250,7 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 #endif
 constexpr int kRplF64 = GKL_RPL_F64;
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block
-constexpr int64_t kDirectPairs = 4096;         // calls up to this many pairs: one fp64 job per flagged pair, no packing
+constexpr int64_t kDirectPairs = 16384;        // calls up to this many pairs: policy + fp64 recomputation of one pair per wavefront in one launch
 constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the policy + planning kernel (a grid barrier costs ~50 ns per block)
 constexpr int kFallbackWantedJobs = 12288;     // the packed fp64 pass is cut into about this many jobs (4 per wavefront slot)
 constexpr int64_t kHostShardPairs = 400000;    // single-device host-buffer calls from this many pairs run as two half-batches (see gklhip_ctx::host_dev)
@@ -378,6 +384,28 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     unsigned char* d = dp + L.batch;
     dbi.read_bases = d; dbi.read_quals = d + L.batch_stride; dbi.ins_gop = d + 2 * L.batch_stride;
     dbi.del_gop = d + 3 * L.batch_stride; dbi.gcp = d + 4 * L.batch_stride; dbi.hap_bases = d + 5 * L.batch_stride;
+    // the haplotype streams (what prep_kernel builds on the device for resident batches)
+    uint32_t* sg = reinterpret_cast<uint32_t*>(hs + L.stream);
+    uint32_t* sf = reinterpret_cast<uint32_t*>(hs + L.stream_flat);
+    uint8_t* hn = hs + L.has_n;
+    for (int k = 0; k < n_haps; k++) {
+      const uint8_t* src = db->hap_bases + plan.hap_src[k];
+      const int len = plan.hap_len[k], pg = plan.hap_pos[k], pf = plan.hap_pos_flat[k];
+      bool has_n = false;
+      for (int col = 0; col < len; col++) {
+        const uint8_t bb = src[col];  // pairhmm_common.h:57-61: A0 C1 T2 G3 N4, anything else 0
+        const uint32_t e = bb == 'C' ? 1u : bb == 'T' ? 2u : bb == 'G' ? 3u : bb == 'N' ? 4u : 0u;
+        sg[pg + col] = e; sf[pf + col] = e;
+        has_n |= bb == 'N';
+      }
+      sg[pg + len] = kEntSep | (uint32_t)k;
+      sf[pf + len] = kEntSep | (uint32_t)k;
+      hn[k] = has_n ? 1 : 0;
+      if (k + 1 == n_haps || plan.hap_group[k + 1] != plan.hap_group[k])
+        for (int i = 0; i < kLanes; i++) sg[pg + len + 1 + i] = kEntIdle;
+      if (k + 1 == n_haps)
+        for (int i = 0; i < kLanes; i++) sf[pf + len + 1 + i] = kEntIdle;
+    }
   }
   // scratch is shared by the calls of a context: one on another stream than the last one waits for that one's end
   if (c->have_call_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->call_done, 0));
@@ -423,6 +451,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   if (ev) HIP_TRY(hipEventRecord(c->ev[0], s));
 
   // ---- haplotype streams + clears: one launch ----
+  uint32_t *stream_grouped = nullptr, *stream_flat = nullptr;
+  uint8_t* hap_has_n = nullptr;
   {
     PrepArgs pa;
     const unsigned char* pb = pull ? hs_dev : dp;  // pulling: this kernel reads the HOST copy of the plan
@@ -431,16 +461,21 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     pa.hap_len = reinterpret_cast<const int32_t*>(pb + L.hap_len);
     pa.hap_pos = reinterpret_cast<const int32_t*>(pb + L.hap_pos);
     pa.hap_group = reinterpret_cast<const int32_t*>(pb + L.hap_group);
-    pa.stream = c->stream_buf.as<uint32_t>();
+    // (host-built streams: they arrive with the pulled block; this kernel then only pulls and clears)
+    const bool host_streams = inline_host;
+    stream_grouped = host_streams ? reinterpret_cast<uint32_t*>(dp + L.stream) : c->stream_buf.as<uint32_t>();
+    stream_flat = host_streams ? reinterpret_cast<uint32_t*>(dp + L.stream_flat) : c->stream_buf.as<uint32_t>() + plan.n_stream;
+    hap_has_n = host_streams ? dp + L.has_n : c->hap_flags.as<uint8_t>();
+    pa.stream = stream_grouped;
     // the flat stream (no gaps between groups): the fp64 recomputation's jobs are arbitrary runs of it
     pa.hap_pos_flat = use_double ? nullptr : reinterpret_cast<const int32_t*>(pb + L.hap_pos_flat);
-    pa.stream_flat = c->stream_buf.as<uint32_t>() + plan.n_stream;
-    pa.hap_has_n = c->hap_flags.as<uint8_t>();
-    pa.n_haps = n_haps;
+    pa.stream_flat = stream_flat;
+    pa.hap_has_n = hap_has_n;
+    pa.n_haps = host_streams ? 0 : n_haps;
     pa.clear_a = c->counters.as<int32_t>(); pa.n_a = 32;
     pa.clear_b = c->read_fail.as<int32_t>(); pa.n_b = use_double ? 0 : n_reads;
     pa.clear_c = c->fail_hist.as<int32_t>(); pa.n_c = n_hist;
-    const int threads_needed = std::max({n_haps * 64, 32, pa.n_b, pa.n_c});
+    const int threads_needed = std::max({pa.n_haps * 64, 32, pa.n_b, pa.n_c});
     pa.hap_blocks = (threads_needed + kPrepBlock - 1) / kPrepBlock;
     pa.pull_src = reinterpret_cast<const uint4*>(hs_dev);
     pa.pull_dst = reinterpret_cast<uint4*>(dp);
@@ -458,11 +493,11 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
 
   auto fill_common = [&](auto& a) {
     a.b = b;
-    a.stream = c->stream_buf.as<uint32_t>();
+    a.stream = stream_grouped;
     a.hap_len = reinterpret_cast<const int32_t*>(dp + L.hap_len);
     a.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos);
     a.hap_orig = reinterpret_cast<const int32_t*>(dp + L.hap_orig);
-    a.hap_has_n = c->hap_flags.as<uint8_t>();
+    a.hap_has_n = hap_has_n;
     a.groups = reinterpret_cast<const HapGroup*>(dp + L.groups);
     a.n_groups = (int)plan.groups.size();
     a.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.lanes);
@@ -535,20 +570,46 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
 
+    // fp64 arguments shared by the two ways of recomputing (the flat stream: a job may run across stream groups)
+    FwdArgs<double> d{};
+    fill_common(d);
+    d.tab = c->dt64;
+    d.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
+    d.raw = c->raw64.as<double>();
+    d.stream = stream_flat;
+    d.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos_flat);
+    int32_t* cnts = c->counters.as<int32_t>();
+    // Small calls (one GATK region): policy + fp64 recomputation + finalisation of one pair per wavefront in ONE launch
+    // (pairhmm_pair_policy_kernel); rows per lane by the longest read.
+    const bool per_pair = n_pairs <= kDirectPairs && n_long64 == 0;
+    if (per_pair) {
+      PairPolicyArgs q;
+      q.raw32 = c->raw32.as<float>(); q.out = out_dev; q.used64 = c->used64.as<uint8_t>(); q.count = cnts;
+      q.hap_sidx = reinterpret_cast<const int32_t*>(dp + L.hap_sidx);
+      q.mode = finalize_mode;
+      q.log10_init_f = fa.log10_init_f; q.log10_init32_as_f64 = fa.log10_init32_as_f64; q.log10_init_d = fa.log10_init_d;
+      if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
+      const dim3 grid((unsigned)n_pairs), block(64);
+      const int rows = plan.max_read_len <= 2 * kLanes - 1 ? 2 : plan.max_read_len <= 4 * kLanes - 1 ? 4 : kRplF64;
+      if (fma) {
+        if (rows == 2)      hipLaunchKernelGGL((pairhmm_pair_policy_kernel<2, true>), grid, block, 0, s, d, q);
+        else if (rows == 4) hipLaunchKernelGGL((pairhmm_pair_policy_kernel<4, true>), grid, block, 0, s, d, q);
+        else                hipLaunchKernelGGL((pairhmm_pair_policy_kernel<kRplF64, true>), grid, block, 0, s, d, q);
+      } else {
+        if (rows == 2)      hipLaunchKernelGGL((pairhmm_pair_policy_kernel<2, false>), grid, block, 0, s, d, q);
+        else if (rows == 4) hipLaunchKernelGGL((pairhmm_pair_policy_kernel<4, false>), grid, block, 0, s, d, q);
+        else                hipLaunchKernelGGL((pairhmm_pair_policy_kernel<kRplF64, false>), grid, block, 0, s, d, q);
+      }
+      if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
+      HIP_TRY(hipEventRecord(c->policy_done, s));
+    } else {
     // ---- precision policy + device-side planning of the fp64 recomputation (one launch) ----
-    const size_t n_groups = plan.groups.size();
-    (void)n_groups;
     const size_t jobs_per_chunk = (size_t)n_haps;  // a job holds at least one haplotype and the jobs of a chunk do not overlap
     const size_t max_jobs = (size_t)n_reads * jobs_per_chunk;
-    // Small calls skip the packing: every flagged pair is its own job (the read alone in a wavefront), emitted by
-    // the policy pass itself; reads of up to 127 bases then run two rows per lane.
-    const bool direct = n_pairs <= kDirectPairs && n_long64 == 0;
-    const bool direct2 = direct && plan.max_read_len <= 2 * kLanes - 1;
     if ((rc = c->fail_order.reserve(((size_t)n_reads + (size_t)n_long64) * 4))) return rc;
     if ((rc = c->lanes2.reserve((size_t)n_reads * kLanes * sizeof(LaneSlot)))) return rc;
     if ((rc = c->jobs.reserve(2 * max_jobs * sizeof(FwdJob)))) return rc;  // as built + sorted by length
     if (n_long64 > 0 && (rc = c->jobs_long.reserve((size_t)n_long64 * jobs_per_chunk * sizeof(FwdJob)))) return rc;
-    int32_t* cnts = c->counters.as<int32_t>();
     const LaneSlot* pl = reinterpret_cast<const LaneSlot*>(dp + L.long_lanes);
     {
       PlanArgs pa;
@@ -571,17 +632,13 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       pa.n_long = n_long64;
       pa.jobs_long = c->jobs_long.as<FwdJob>();
       pa.long_chunk_jobs = c->fail_order.as<int32_t>() + n_reads;
-      pa.direct = direct ? 1 : 0;
-      pa.hap_sidx = reinterpret_cast<const int32_t*>(dp + L.hap_sidx);
       pa.total_cols = (int32_t)std::min<int64_t>((int64_t)hl + n_haps, 0x7fffffff);
       static const int wanted_env = [] { const char* v = getenv("GKLHIP_FB_WANTED_JOBS"); return v ? atoi(v) : 0; }();
       pa.wanted_jobs = wanted_env > 0 ? wanted_env : kFallbackWantedJobs;
       pa.min_job_cols = 256;
-      // every block must be resident at once (grid barriers): at most one per CU
-      // (direct mode: by pairs; else one block per CU -- the run detection is one block per chunk)
+      // every block must be resident at once (grid barriers): far fewer than one per CU
       static const int blocks_env = [] { const char* v = getenv("GKLHIP_PLAN_BLOCKS"); return v ? atoi(v) : 0; }();
-      const int grid = direct ? (int)std::max<int64_t>(1, (n_pairs + kPlanBlock * 4 - 1) / (kPlanBlock * 4))
-                              : std::max(1, std::min(c->n_cus, blocks_env > 0 ? blocks_env : kPlanBlocks));
+      const int grid = std::max(1, std::min(c->n_cus, blocks_env > 0 ? blocks_env : kPlanBlocks));
       hipLaunchKernelGGL(policy_plan_kernel, dim3((unsigned)grid), dim3(kPlanBlock), 0, s, pa);
     }
     HIP_TRY(hipEventRecord(c->policy_done, s));
@@ -593,22 +650,11 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     }
     // ---- fp64 recomputation of the underflowed pairs: persistent wavefronts stream the job list -- same WaveJob
     // template as the main pass, T = double (no jobs: the kernel's wavefronts leave at once) ----
-    FwdArgs<double> d{};
-    fill_common(d);
-    d.tab = c->dt64;
-    d.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
-    d.raw = c->raw64.as<double>();
-    d.stream = c->stream_buf.as<uint32_t>() + plan.n_stream;  // the flat stream: a job may run across stream groups
-    d.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos_flat);
     d.chunk_lanes = c->lanes2.as<LaneSlot>();
     d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
     d.jobs = c->jobs.as<FwdJob>() + max_jobs;
-    const bool jobs_finalize = direct && finalize_mode == kModePacked;  // solo jobs write their packed words themselves
-    d.packed_out = jobs_finalize ? reinterpret_cast<uint64_t*>(out_dev) : nullptr;
     if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
-    if (direct2)                                          launch_jobs<double, 2>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
-    else if (direct && plan.max_read_len <= 4 * kLanes - 1) launch_jobs<double, 4>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
-    else         launch_jobs<double, kRplF64>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
+    launch_jobs<double, kRplF64>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
     if (n_long64 > 0) {
       // reads too long for a chunk: one pseudo-chunk each, same run detection, striped kernel
       FwdArgs<double> ld = d;
@@ -619,8 +665,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       launch_long<double, kRplF64>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
-    if (!jobs_finalize) hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
+    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
     if (side_finalize) HIP_TRY(hipStreamWaitEvent(s, c->early_copy_done, 0));  // join the side stream
+    }  // !per_pair
   }
   if (ev) HIP_TRY(hipEventRecord(c->ev[5], s));
   HIP_TRY(hipGetLastError());

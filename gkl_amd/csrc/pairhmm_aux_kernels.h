@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
   if (__ballot(has_n) != 0 && lane == 0) a.hap_has_n[k] = 1;
 }
 
-constexpr int kModePacked = -2;  // FinalizeArgs::mode: `out` receives packed raw sums (kPackedF32Tag, pairhmm_fwd_kernel.h)
+constexpr int kModePacked = kModePackedWords;  // FinalizeArgs::mode: `out` receives packed raw sums (kPackedF32Tag, pairhmm_fwd_kernel.h)
 
 struct FinalizeArgs {
   const float* raw32;
@@ -154,12 +154,6 @@ struct PlanArgs {
   int32_t n_long;
   FwdJob* jobs_long;     // [n_long * n_haps]
   int32_t* long_chunk_jobs;  // [n_long]
-  // direct mode (small calls, chosen by the host): every flagged pair becomes its own job -- the read alone in a
-  // wavefront against that one haplotype -- straight from the policy pass: no packing, no barriers.  Lane use is
-  // poor (a 100-base read fills a quarter of the lanes) and irrelevant: such a call leaves most of the chip idle
-  // and what counts is the length of the longest dependent chain.
-  int32_t direct;
-  const int32_t* hap_sidx;  // caller's haplotype index -> stream order
   // job length: runs are cut after `wanted` columns' worth ... see phase J
   int32_t total_cols;    // columns + separators of all haplotypes
   int32_t wanted_jobs;   // the pass is cut into about this many jobs (when the runs allow it)
@@ -237,17 +231,16 @@ __device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const La
       const int e = stop ? __builtin_ctzll(stop) : kLanes;
       FwdJob j;
       j.chunk = c; j.hap_begin = k; j.hap_end = min(k0 + e, a.n_haps);
-      j.solo = 0;
+      j.klass = 0;
       jobs[base + __builtin_popcountll(starts & ((1ull << lane) - 1ull))] = j;
     }
     prev_need = ((need >> (kLanes - 1)) & 1ull) != 0;
   }
-  // the length class of every job rides along for phase O (bit 0 clear: a packed chunk); only now are the ends final
+  // the length class of every job rides along for phase O; only now are the ends final
   __threadfence_block();
   for (int i = lane; i < n_jobs; i += kLanes) {
     FwdJob j = jobs[i];
-    j.solo = job_class(j, a.hap_pos, a.hap_len) << 8;
-    jobs[i].solo = j.solo;
+    jobs[i].klass = job_class(j, a.hap_pos, a.hap_len);
   }
   if (lane == 0) chunk_jobs[c] = n_jobs;
 }
@@ -279,17 +272,6 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
         if (fails && read != lead_read) atomicAdd(a.fa.read_fail + read, 1);
         if (lane == 0) my_fails += __builtin_popcountll(mask);
       }
-      if (a.direct && mask) {
-        int32_t at = 0;
-        if (lane == 0) at = atomicAdd(a.cnts + 2, __builtin_popcountll(mask));
-        at = __shfl(at, 0, 64) + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        if (fails) {
-          const int32_t r = (int32_t)(i / a.n_haps), k = a.hap_sidx[(int32_t)(i - (int64_t)r * a.n_haps)];
-          FwdJob j;
-          j.chunk = r; j.hap_begin = k; j.hap_end = k + 1; j.solo = 1;
-          a.sorted[at] = j;
-        }
-      }
       if (in_range) {
         a.fa.used64[i] = fails ? 1 : 0;
         // "pending" (0) for the flagged pairs: finalize64_kernel fills them in; the device log10 of the kept pairs
@@ -307,7 +289,6 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
       if (total) atomicAdd(a.cnts + 0, total);
     }
   }
-  if (a.direct) return;
   grid_barrier(bar, target);
   const int n_fail = ld_cnt(a.cnts + 0);
   if (n_fail == 0) return;  // nothing underflowed (uniform across the grid: read after the barrier)
@@ -476,7 +457,7 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
     for (int c = tid; c < total; c += kPlanBlock) {
       const FwdJob* mine = a.jobs + (int64_t)c * a.n_haps;
       const int n = a.order[c];
-      for (int i = 0; i < n; i++) atomicAdd(&cnt[mine[i].solo >> 8], 1);
+      for (int i = 0; i < n; i++) atomicAdd(&cnt[mine[i].klass], 1);
     }
     __syncthreads();
     if (tid == 0) {
@@ -490,7 +471,7 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
       const int n = a.order[c];
       for (int i = 0; i < n; i++) {
         const FwdJob j = mine[i];
-        a.sorted[atomicAdd(&base[j.solo >> 8], 1)] = j;
+        a.sorted[atomicAdd(&base[j.klass], 1)] = j;
       }
     }
     // the striped long-read kernel takes its jobs in one list: compact the pseudo-chunks' lists in place

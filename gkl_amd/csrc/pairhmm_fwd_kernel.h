@@ -76,7 +76,7 @@ struct LaneSlot {  // one lane of a chunk: which read it holds, and which RPL-ro
 
 struct FwdJob {  // one wave job of the job-list pass: stream haps [hap_begin, hap_end) through a chunk
   int32_t chunk, hap_begin, hap_end;
-  int32_t solo;  // bit 0: `chunk` is a READ index and the wavefront holds that read alone (no lane table); bits 8..: planner's length class
+  int32_t klass; // the planner's length class (ordering of the job list)
 };
 
 template <typename T>
@@ -98,9 +98,6 @@ struct FwdArgs {
   const FwdJob* jobs;
   const int32_t* job_count;
   int32_t* job_next;
-  // solo jobs of a call whose results go back as packed words (see kPackedF32Tag): the wavefront that recomputed a
-  // pair also writes its word, so that such a (small) call needs no finalisation launch.  NULL otherwise.
-  uint64_t* packed_out;
 };
 
 // Host finalisation (reference-exact log10f / log10 of the host libm) needs, per pair, either the raw
@@ -566,27 +563,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
     idx = __builtin_amdgcn_readfirstlane(idx);
     if (idx >= n) break;
     const FwdJob j = a.jobs[idx];
-    const bool solo = (j.solo & 1) != 0;
-    const int chunk_id = solo ? ~j.chunk : j.chunk;
-    if (chunk_id != loaded_chunk) {
-      LaneSlot slot;
-      if (solo) {  // the read alone in the wavefront: lanes 0 .. ceil((R+1)/RPL)-1 hold its row blocks
-        const int R = (int)(a.b.read_off[j.chunk + 1] - a.b.read_off[j.chunk]);
-        slot.read = lane < (R + RPL) / RPL ? j.chunk : -1;
-        slot.block = lane;
-      } else {
-        slot = a.chunk_lanes[(int64_t)j.chunk * kLanes + lane];
-      }
+    if (j.chunk != loaded_chunk) {
       __syncthreads();  // previous job's LDS reads are done
-      job.setup(a, lane, slot);
+      job.setup(a, lane, a.chunk_lanes[(int64_t)j.chunk * kLanes + lane]);
       __syncthreads();
-      loaded_chunk = chunk_id;
+      loaded_chunk = j.chunk;
     }
     job.run(a, lane, j.hap_begin, j.hap_end);
-    if (sizeof(T) == 8 && solo && a.packed_out && job.out_read >= 0) {  // the lane that stored the pair's sum
-      const int64_t p = (int64_t)j.chunk * a.b.n_haps + a.hap_orig[j.hap_begin];
-      a.packed_out[p] = packed_word((double)a.raw[p]);
+  }
+}
+
+// Small calls (one GATK active region: at most a few thousand pairs): precision policy, fp64 recomputation and
+// finalisation of ONE pair per wavefront in one launch -- no job list, no packing, no second and third launch.  The
+// wavefront of a pair whose fp32 sum passed the policy writes its result and leaves; the others hold the read alone
+// (lanes 0 .. ceil((R+1)/RPL)-1) and stream that one haplotype.  Lane use is poor (a 100-base read fills a quarter of
+// the lanes at 6 rows each) and irrelevant: such a call leaves most of the chip idle, what counts is the length of
+// the dependent chain.
+struct PairPolicyArgs {
+  const float* raw32;
+  double* out;              // final doubles, or packed words (mode == kModePackedWords)
+  uint8_t* used64;
+  int32_t* count;           // number of pairs recomputed
+  const int32_t* hap_sidx;  // caller's haplotype index -> stream order
+  int32_t mode;             // gklhip_finalize device modes, -1: none, kModePackedWords
+  float log10_init_f;
+  double log10_init32_as_f64, log10_init_d;
+};
+constexpr int kModePackedWords = -2;
+
+template <int RPL, bool FMA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pairhmm_pair_policy_kernel(FwdArgs<double> a, PairPolicyArgs q) {
+  using Job = WaveJob<double, RPL, FMA>;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
+  const int lane = threadIdx.x;
+  const int64_t p = blockIdx.x;
+  const float v = q.raw32[p];
+  const bool fails = v < 1e-28f;  // NaN compares false and stays fp32, like the reference (IntelPairHmm.cc:159)
+  if (lane == 0) q.used64[p] = fails ? 1 : 0;
+  if (!fails) {
+    if (lane == 0) {
+      if (q.mode == kModePackedWords) reinterpret_cast<uint64_t*>(q.out)[p] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
+      else if (q.mode == 1) q.out[p] = log10((double)v) - q.log10_init32_as_f64;                        // GKLHIP_FINALIZE_DEVICE_F64
+      else if (q.mode == 2) q.out[p] = (double)((float)log10((double)v) - q.log10_init_f);             // GKLHIP_FINALIZE_DEVICE_REF32
     }
+    return;
+  }
+  if (lane == 0) atomicAdd(q.count, 1);
+  const int r = (int)(p / a.b.n_haps), k = q.hap_sidx[(int)(p - (int64_t)r * a.b.n_haps)];
+  const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+  LaneSlot slot;
+  slot.read = lane < (R + RPL) / RPL ? r : -1;
+  slot.block = lane;
+  Job job;
+  job.lds = lds;
+  job.setup(a, lane, slot);
+  __syncthreads();
+  job.run(a, lane, k, k + 1);
+  if (job.out_read >= 0) {  // the lane that stored the pair's sum
+    const double sum = a.raw[p];
+    if (q.mode == kModePackedWords) reinterpret_cast<uint64_t*>(q.out)[p] = packed_word(sum);
+    else if (q.mode >= 0) q.out[p] = log10(sum) - q.log10_init_d;
   }
 }
 
