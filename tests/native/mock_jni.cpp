@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -371,8 +372,27 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
         f_compute(&envs[t]->env, nullptr, reinterpret_cast<jobjectArray>(slices[t]),
                   reinterpret_cast<jobjectArray>(haps), reinterpret_cast<jdoubleArray>(results[t]));
     });
+  // MOCKJNI_CHURN=1: meanwhile another IntelPairHmm instance of the same JVM comes and goes -- initNative with the same
+  // arguments and doneNative, over and over (the reference's initNative only re-sets globals, its doneNative is empty)
+  std::atomic<bool> stop{false};
+  std::thread churn;
+  Mock churn_env;
+  install_table(churn_env);
+  const char* ch = getenv("MOCKJNI_CHURN");
+  if (ch && *ch == '1')
+    churn = std::thread([&] {
+      while (!stop.load()) {
+        f_done(&churn_env.env, nullptr);
+        f_init(&churn_env.env, nullptr, reinterpret_cast<jclass>(read_cls), reinterpret_cast<jclass>(hap_cls),
+               use_double ? JNI_TRUE : JNI_FALSE, max_threads);
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+      }
+    });
   for (auto& th : pool) th.join();
+  stop.store(true);
+  if (churn.joinable()) churn.join();
   if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (churn_env.pending) { envs[0]->pending = true; envs[0]->exc_class = churn_env.exc_class; envs[0]->exc_msg = "churn thread: " + churn_env.exc_msg; }
   f_done(&m.env, nullptr);
   int rc_ = 0;
   for (int t = 0; t < n_threads; t++) {

@@ -149,6 +149,17 @@ def test_jni_concurrent_callers_get_their_own_slot(oracle, n_threads, slots, mon
     assert out.tobytes() == oracle.batch(b, n_threads=8).tobytes()
 
 
+@pytest.mark.gpu
+def test_jni_init_and_done_of_another_instance_do_not_disturb_running_calls(oracle, monkeypatch):
+    # closing one IntelPairHmm instance (doneNative) or initialising another must not break the calls other
+    # threads have in flight -- the reference's doneNative is empty and its initNative only re-sets globals
+    monkeypatch.setenv("MOCKJNI_CHURN", "1")
+    b = make_batch("hc", 360, 12, seed=79)
+    rc, out, cls, msg, _ = mockjni.run_concurrent(b, n_threads=5, iters=8, max_threads=2)
+    assert rc == 0, (cls, msg)
+    assert out.tobytes() == oracle.batch(b, n_threads=8).tobytes()
+
+
 def _check_jni_onload(monkeypatch, have_gpu):
     # JNI_OnLoad (not in the reference): JNI_ERR without a usable gfx950 device, so that System.load fails and
     # NativeLibraryLoader.load() returns false (GATK then falls back); JNI_VERSION_1_8 with one, or when forced
