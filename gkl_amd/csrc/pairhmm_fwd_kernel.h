@@ -426,6 +426,62 @@ struct WaveJob {
     fetch_above();
   }
 
+  // fp64 general step (the steps behind a separator, the fill and the drain, haplotypes with an 'N'): the FAST step's
+  // arithmetic for every lane, then two small fix-ups under the EXEC mask instead of selecting every state value
+  // (a 64-bit select is two instructions, a masked 64-bit move is one, and the general step's 36 selects per step made
+  // it 1.9x a fast step on a pass where every fifth step is one):
+  //   * lanes on a separator or idle entry (no haplotype base in the column): their new M and X are zeroed before
+  //     they enter the state and the running sums -- the prior they multiplied with is some plane's, not 0;
+  //   * lanes on a separator: store the pair's sum, return to the column-0 state of the next haplotype.
+  __device__ __forceinline__ void step_win(const FwdArgs<T>& a, uint32_t entry, int lane,
+                                           int hap_begin, int hap_end, int k_cur, int orig_cur, T y0_next) {
+    shift_entry(entry);
+    const bool sep = (int32_t)ent < 0;
+    const bool off = sep || ent == kEntIdle;
+    const bool is_n = ent == 4u;  // haplotype 'N': the row's prior is its own plane (four planes in fp64, see kCodes)
+    T pr[RPL], nM[RPL], nX[RPL], nY[RPL];
+    load_priors((off || is_n) ? 0u : ent, lane, pr);
+    if (__ballot(is_n) != 0) {
+      asm volatile("" ::: "memory");  // a real branch: speculated, its six LDS reads and twelve selects ran in every step
+      T pn[RPL];
+      load_priors_n(lane, pn);
+#pragma unroll
+      for (int s = 0; s < RPL; s++) pr[s] = is_n ? pn[s] : pr[s];
+    }
+    advance(pr, nM, nX, nY);
+    if (off) {
+      asm volatile("" ::: "memory");  // keeps this a masked block of moves (if-converted it is two selects per value again)
+#pragma unroll
+      for (int s = 0; s < RPL; s++) { nM[s] = T(0); nX[s] = T(0); }
+    }
+#pragma unroll
+    for (int s = 0; s < RPL; s++) { M[s] = nM[s]; X[s] = nX[s]; Y[s] = nY[s]; }
+    sM = sM + nM[RPL - 1];
+    sX = sX + nX[RPL - 1];
+    if (sep) {
+      asm volatile("" ::: "memory");
+      const int k = (int)(ent & 0x7fffffffu);
+      T y0n = T(0);
+      if (k == k_cur) {  // k_cur is always inside [hap_begin, hap_end)
+        if (out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + orig_cur] = sM + sX;
+        y0n = y0_next;
+      } else {
+        const bool mine = (k >= hap_begin) && (k < hap_end);
+        if (mine && out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
+        if (mine && k + 1 < hap_end) {
+          y0n = a.y0[k + 1];
+          asm volatile("" :: "v"(y0n));  // consume the load inside this (rare) branch, see step_any
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < RPL; s++) Y[s] = (s == padb_slot) ? y0n : T(0);  // Y0 into the lane's pad row, 0 elsewhere
+      sM = T(0);
+      sX = T(0);
+    }
+    dM = rM; dX = rX; dY = rY;
+    fetch_above();
+  }
+
   // Stream haplotypes [hap_begin, hap_end) (stream order) through the loaded rows.
   __device__ __forceinline__ void run(const FwdArgs<T>& a, int lane, int hap_begin, int hap_end) {
     constexpr int U = 8;
@@ -476,6 +532,17 @@ struct WaveJob {
   __device__ __forceinline__ void run_any(const FwdArgs<T>& a, StreamWord* sp, int& t, int end,
                                           int lane, int hap_begin, int hap_end, int k_cur, int orig_cur, T y0_next) {
     constexpr int V = 4;
+    if (sizeof(T) == 8) {  // (compile time: the fp64 kernels carry one kind of general step only -- two do not fit 168 VGPRs)
+      for (; t + V <= end; t += V) {
+        uint32_t e[V];
+#pragma unroll
+        for (int u = 0; u < V; u++) e[u] = sp[t + u];
+#pragma unroll
+        for (int u = 0; u < V; u++) step_win(a, e[u], lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
+      }
+      for (; t < end; t++) step_win(a, sp[t], lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
+      return;
+    }
     for (; t + V <= end; t += V) {
       uint32_t e[V];
 #pragma unroll
