@@ -119,11 +119,21 @@ __device__ __forceinline__ uint32_t dpp_shr1_keep(uint32_t old, uint32_t src) {
 __device__ __forceinline__ uint32_t dpp_shr1_zero(uint32_t src) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x138, 0xf, 0xf, true);
 }
-// value of the lane above, ANDed with this lane's mask (0 for lanes that start a read or are
-// idle, ~0 otherwise); the compiler folds the AND into the DPP op (v_and_b32_dpp).
-__device__ __forceinline__ float recv_above(float v, uint32_t lmask) {
-  return __uint_as_float(dpp_shr1_zero(__float_as_uint(v)) & lmask);
+// value of the lane above, ANDed with this lane's mask (0 for lanes that start a read or are idle, ~0 otherwise): one
+// v_and_b32_dpp.  Written as asm WITH an s_nop in front: a DPP op issued straight behind another VALU op of the same
+// wavefront costs the SIMD ~5 extra cycles (all its wavefronts wait), behind an s_nop ~2 (tools/ubench_dpp.hip: seven
+// fmac + three DPP ops spread among them take 42.6 cycles per SIMD without and 34.3-34.7 with the nops, 27.2 with
+// plain v_and); the compiler only adds the nops the register hazard rules demand.  Not volatile: it schedules freely.
+__device__ __forceinline__ uint32_t dpp_shr1_and_nop(uint32_t src, uint32_t mask) {
+  uint32_t d;
+  asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(src), "v"(mask));
+  return d;
 }
+__device__ __forceinline__ float recv_above(float v, uint32_t lmask) {
+  return __uint_as_float(dpp_shr1_and_nop(__float_as_uint(v), lmask));   // fp32 kernel: -2.2 % (A/B on one box)
+}
+// (fp64: the two halves through the compiler-scheduled builtin -- with the nops, one per half or one per value, the
+//  fp64 kernels measured the same)
 __device__ __forceinline__ double recv_above(double v, uint32_t lmask) {
   const uint64_t u = (uint64_t)__double_as_longlong(v);
   const uint32_t lo = dpp_shr1_zero((uint32_t)u) & lmask;
