@@ -26,6 +26,32 @@ variants["dpp spread: (2 fmac, nop, dpp) x3 + fmac"] = sum([[f"v_fmac_f32 v{2*i}
 variants["dpp spread no nop: (2 fmac, dpp) x3 + fmac"] = sum([[f"v_fmac_f32 v{2*i}, v{40+2*i}, v{80+2*i}", f"v_fmac_f32 v{2*i+1}, v{41+2*i}, v{81+2*i}", f"v_and_b32_dpp v{20+i}, v{2*i}, v31 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"] for i in range(3)], []) + ["v_fmac_f32 v6, v46, v86"]
 variants["dpp spread s_nop 0: (2 fmac, nop0, dpp) x3 + fmac"] = sum([[f"v_fmac_f32 v{2*i}, v{40+2*i}, v{80+2*i}", f"v_fmac_f32 v{2*i+1}, v{41+2*i}, v{81+2*i}", "s_nop 0", f"v_and_b32_dpp v{20+i}, v{2*i}, v31 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"] for i in range(3)], []) + ["v_fmac_f32 v6, v46, v86"]
 variants["7 fmac + 3 v_and plain (again)"] = fmacs(7) + [f"v_and_b32 v{20+i}, v{4+i}, v31" for i in range(3)]
+variants["4 mul + 4 fmac"] = [f"v_mul_f32 v{20+i}, v{40+i}, v{80+i}" for i in range(4)] + [f"v_fmac_f32 v{20+i}, v{44+i}, v{84+i}" for i in range(4)]
+variants["3 mul + 1 mul_legacy + 4 fmac"] = [f"v_mul_f32 v{20+i}, v{40+i}, v{80+i}" for i in range(3)] + ["v_mul_legacy_f32 v23, v43, v83"] + [f"v_fmac_f32 v{20+i}, v{44+i}, v{84+i}" for i in range(4)]
+variants["8 mul_legacy"] = [f"v_mul_legacy_f32 v{20+i}, v{40+i}, v{80+i}" for i in range(8)]
+variants["8 mul"] = [f"v_mul_f32 v{20+i}, v{40+i}, v{80+i}" for i in range(8)]
+variants["7 fmac + v_and_or_b32"] = fmacs(7) + ["v_and_or_b32 v20, v30, v31, v32"]
+variants["7 fmac + v_lshl_or_b32"] = fmacs(7) + ["v_lshl_or_b32 v20, v30, 11, v31"]
+variants["7 fmac + v_add_f32"] = fmacs(7) + ["v_add_f32 v20, v20, v6"]
+variants["kernel row: mul fmac fmac mul_legacy mul fmac mul fmac (dep)"] = ["v_mul_f32 v20, v40, v80", "v_fmac_f32 v20, v41, v81", "v_fmac_f32 v20, v42, v81", "v_mul_legacy_f32 v21, v20, v82", "v_mul_f32 v22, v43, v83", "v_fmac_f32 v22, v44, v84", "v_mul_f32 v23, v45, v85", "v_fmac_f32 v23, v46, v84"]
+variants["8 fmac e64 (v_fma_f32 d,a,b,d)"] = [f"v_fma_f32 v{i}, v{40+i}, v{80+i}, v{i}" for i in range(8)]
+variants["8 fmac, operands in 3 banks (i, 41+i, 82+i)"] = [f"v_fmac_f32 v{i}, v{41+i}, v{82+i}" for i in range(8)]
+variants["8 fmac, src0/src1 same bank, dst other (i, 41+i, 81+i)"] = [f"v_fmac_f32 v{i}, v{41+i}, v{81+i}" for i in range(8)]
+variants["8 fmac, dst/src1 same bank (i, 41+i, 80+i)"] = [f"v_fmac_f32 v{i}, v{41+i}, v{80+i}" for i in range(8)]
+variants["8 mul, operands in 3 banks (20+i, 41+i, 82+i)"] = [f"v_mul_f32 v{20+i}, v{41+i}, v{82+i}" for i in range(8)]
+variants["8 mul, src same bank (20+i, 41+i, 81+i)"] = [f"v_mul_f32 v{20+i}, v{41+i}, v{81+i}" for i in range(8)]
+variants["8 fmac, src1 = one shared reg (i, 41+i, 90)"] = [f"v_fmac_f32 v{i}, v{41+i}, v90" for i in range(8)]
+variants["8 fmac, src0 sgpr (i, s4, 82+i)"] = [f"v_fmac_f32 v{i}, s4, v{82+i}" for i in range(8)]
+def rows8():
+    out = []
+    for r in range(8):
+        a, b, c, d = 4 * r % 20, (4 * r + 1) % 20, (4 * r + 2) % 20, (4 * r + 3) % 20
+        out += [f"v_mul_f32 v{a}, v40, v80", f"v_fmac_f32 v{a}, v41, v81", f"v_fmac_f32 v{a}, v42, v81", f"v_mul_legacy_f32 v{b}, v{a}, v82", f"v_mul_f32 v{c}, v43, v83", f"v_fmac_f32 v{c}, v44, v84", f"v_mul_f32 v{d}, v45, v85", f"v_fmac_f32 v{d}, v46, v84"]
+    return out
+dpp = lambda d, s_: ["s_nop 1", f"v_and_b32_dpp v{d}, v{s_}, v31 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"]
+variants["STEP now: 64 FP + 4 dpp(nop) + and_or + lshl_or + 2 add + 2 ds_read_b128"] = rows8() + dpp(20, 1) + dpp(21, 2) + dpp(22, 3) + dpp(23, 30) + ["v_and_or_b32 v30, s4, v31, v23", "v_lshl_or_b32 v33, v30, 11, v34", "ds_read_b128 v[24:27], v33", "ds_read_b128 v[50:53], v33 offset:1024", "v_add_f32 v36, v36, v1", "v_add_f32 v37, v37, v2"]
+variants["STEP lds: 64 FP + ds_write_b128 + ds_read_b128 + cndmask + or + 2 add + 2 ds_read_b128"] = rows8() + ["ds_write_b128 v35, v[0:3]", "ds_read_b128 v[20:23], v38", "v_and_b32 v39, s4, v31", "v_or_b32 v30, v39, v23", "v_lshl_or_b32 v33, v30, 11, v34", "ds_read_b128 v[24:27], v33", "ds_read_b128 v[50:53], v33 offset:1024", "v_add_f32 v36, v36, v1", "v_add_f32 v37, v37, v2"]
+variants["STEP FP only: 64 FP"] = rows8()
 variants["7 fmac + cndmask_dpp vcc (cold)"] = fmacs(7) + ["v_cndmask_b32_dpp v20, v30, v31, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"]
 '''
 exec(head + "variants = {}" + new_variants + tail[body_start:])
