@@ -33,7 +33,15 @@ constexpr int kPdSnp = 1, kPdDelStart = 2, kPdDelEnd = 4, kPdA = 8, kPdC = 16, k
 // stream entry: [7:0] haplotype base, [14:8] PD flag bits, [17:16] state on entry to the column,
 // [19:18] the same for the reference's SCALAR engine on rows >= 2 (its state variable survives from one row to the
 // next, pdhmm-serial.cc:306: those rows start in the state the previous row ended in), bit 30 = idle (no column).
-constexpr uint32_t kPdIdle = 1u << 30;
+// [29:20] the column's half of the match predicate (pdhmm.h:256-262): [23:20] one-hot of the base when it is exactly
+// 'A' 'C' 'G' 'T', [27:24] the SNP allele bits, bit 28 = 1, bit 29 = base is 'N'; a read row holds the mirror image
+// (PdJob::xinfo) and the row matches the column iff (entry & xinfo) has a bit above bit 19.  Bit 31 ("odd") marks a
+// base outside ACGTN, where equality of the raw bytes cannot be read off the one-hot bits: such columns take the
+// byte-comparing step.
+constexpr uint32_t kPdIdle = 1u << 30, kPdOdd = 1u << 31, kPdMatchBits = 0xfffffu;
+__device__ __forceinline__ uint32_t pd_onehot_acgt(uint32_t b) {
+  return b == (uint32_t)'A' ? 1u : b == (uint32_t)'C' ? 2u : b == (uint32_t)'G' ? 4u : b == (uint32_t)'T' ? 8u : 0u;
+}
 constexpr int kPdRpl = 4;
 
 struct PdArgs {
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
   e += kLanes;
   int carry = -1;  // key of the last flagged column of the tiles before this one
   int first_flagged = H;  // first column with DEL_START / DEL_END (H: none)
+  bool has_odd = false;
   for (int base = 0; base < H; base += kLanes) {
     const int j = base + lane;
     const bool valid = j < H;
@@ -114,7 +123,14 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
     if (lane == 0) excl = -1;
     if (carry > excl) excl = carry;
     const uint32_t state = excl < 0 ? 0u : ((excl & 1) ? ((excl >> 1) == j - 1 ? 2u : 0u) : 1u);
-    if (valid) e[j] = ((uint32_t)hb[j] & 0xffu) | (flags << 8) | (state << 16) | (state << 18);
+    if (valid) {
+      const uint32_t yb = (uint32_t)hb[j] & 0xffu, hot = pd_onehot_acgt(yb);
+      has_odd |= hot == 0u && yb != (uint32_t)'N';
+      const uint32_t allele = (flags & kPdSnp) ? ((flags >> 3) & 0xfu) : 0u;
+      const bool is_n = yb == (uint32_t)'N';
+      e[j] = yb | (flags << 8) | (state << 16) | (state << 18) | (hot << 20) | (allele << 24) | (1u << 28) |
+             (is_n ? 1u << 29 : 0u) | ((hot == 0u && !is_n) ? kPdOdd : 0u);
+    }
     const uint64_t fl = __ballot(flagged);
     if (fl && first_flagged == H) first_flagged = base + __builtin_ctzll(fl);
     const int last = __shfl(incl, kLanes - 1, kLanes);
@@ -132,6 +148,8 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
     }
   }
   for (int j = H + lane; j < a.entry_stride - kLanes; j += kLanes) e[j] = kPdIdle;
+  // a haplotype with an odd column says so in its first (idle) word: its jobs run the byte-comparing steps throughout
+  if (__ballot(has_odd) != 0 && lane == 0) e[-kLanes] = kPdIdle | kPdOdd;
 }
 
 // _mm256_max_pd / std::max on the values this recurrence produces (finite, non-negative, no -0): one v_max_f64.  Written
@@ -156,7 +174,8 @@ struct PdJob {
   double mm[RPL], im[RPL], dm[RPL], bmm[RPL], bim[RPL], bdm[RPL];
   double tmm[RPL], tim[RPL], tmi[RPL], tii[RPL], tmd[RPL], tdd[RPL];
   double ptrue[RPL], pfalse[RPL];
-  uint32_t xinfo[RPL];  // [7:0] read base, [14:8] its allele bit, bit 15: base is 'N'
+  uint32_t xinfo[RPL];  // [7:0] read base, [14:8] its allele bit, bit 15: base is 'N'; [29:20] mirror of the entry's match bits:
+                        // [23:20] one-hot of the raw base, [27:24] its allele bit, bit 28 = base is 'N', bit 29 = 1
   double d[6], r[6];    // row above: previous column (diagonal) / this column (top)
   double sum;
   uint32_t ent, lmask;
@@ -204,7 +223,8 @@ struct PdJob {
         const int xu = x >= 'a' ? x - 32 : x;  // pdhmm.h:256-262 + toPrime_ :222-232
         uint32_t bit = xu == 'C' ? kPdC : xu == 'G' ? kPdG : xu == 'T' ? kPdT : kPdA;
         if (kSerial && xu != 'A' && xu != 'C' && xu != 'G' && xu != 'T') { bit = 0u; has_non_acgt = true; }  // pdhmm-serial.cc:222-248
-        xinfo[s] = ((uint32_t)x & 0xffu) | (bit << 8) | (x == 'N' ? 0x8000u : 0u);
+        xinfo[s] = ((uint32_t)x & 0xffu) | (bit << 8) | (x == 'N' ? 0x8000u : 0u) | (pd_onehot_acgt((uint32_t)x & 0xffu) << 20) |
+                   ((bit >> 3) << 24) | (x == 'N' ? 1u << 28 : 0u) | (1u << 29);
       } else if (active && v == -1) {
         tdd[s] = 1.0;  // row 0: deletion matrix constant INITIAL_CONDITION / haplen, everything else 0
         dm[s] = init;
@@ -320,10 +340,6 @@ struct PdJob {
   __device__ __forceinline__ void step_plain(uint32_t entry, bool last, bool first) {
     ent = entry;
     const bool off = (ent & kPdIdle) != 0;
-    const uint32_t y = ent & 0xffu;
-    const uint32_t flags = (ent >> 8) & 0x7fu;
-    const uint32_t allele = (flags & kPdSnp) ? (flags & 0x78u) : 0u;
-    const bool y_is_n = y == (uint32_t)'N';
     if (!off) {
       if (last) {
 #pragma unroll
@@ -332,9 +348,7 @@ struct PdJob {
 #pragma unroll
       for (int s = RPL - 1; s >= 0; s--) {
         const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
-        const uint32_t xi = xinfo[s];
-        const bool match = ((xi & 0xffu) == y) || (xi & 0x8000u) || y_is_n || (((xi >> 8) & allele) != 0u);
-        const double pr = match ? ptrue[s] : pfalse[s];
+        const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
         if (FMA) {
           dm[s] = __builtin_fma(dm[s], tdd[s], mm[s] * tmd[s]);
           mm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
@@ -362,6 +376,71 @@ struct PdJob {
     r[2] = recv_above(dm[RPL - 1], lmask);
   }
 
+  // The general step of the vector arithmetic (not kSerial: a lane's rows share the column's state).  The three kinds
+  // of special lane differ from a plain lane only in how INPUTS are merged, so each kind does its extra work under its
+  // own EXEC mask and everything is updated in place, like step_plain:
+  //   AFTER_DEL   left and diagonal cells become max(live, branch copy) (pdhmm.h:452-466) -- merged into the live
+  //               registers before the step, which also makes the new branch copy "the old live value" as on a plain lane;
+  //   INSIDE_DEL  keeps its branch copies; every other lane's become the old live values;
+  //   DEL_END     the cell above becomes max(branch copy, live) of the row above's NEW values (:434-443).
+  // The empty asm statements keep the compiler from turning the masked blocks back into compute-everything-and-select
+  // (that form: 32 v_max_f64 + 64 v_cndmask + 44 v_mov per step).
+  __device__ __forceinline__ void step_general(uint32_t entry) {
+    ent = entry;
+    const bool off = (ent & kPdIdle) != 0;
+    const uint32_t state = (ent >> 16) & 3u;
+    const bool del_end = (ent & ((uint32_t)kPdDelEnd << 8)) != 0;
+    if (!off) {
+      if (state == 2u) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < RPL; s++) {
+          mm[s] = pd_max(mm[s], bmm[s]); im[s] = pd_max(im[s], bim[s]); dm[s] = pd_max(dm[s], bdm[s]);
+        }
+        d[0] = pd_max(d[0], d[3]); d[1] = pd_max(d[1], d[4]); d[2] = pd_max(d[2], d[5]);
+      }
+      if (state != 1u) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < RPL; s++) { bmm[s] = mm[s]; bim[s] = im[s]; bdm[s] = dm[s]; }
+      }
+#pragma unroll
+      for (int s = RPL - 1; s >= 0; s--) {
+        const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
+        const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
+        if (FMA) {
+          dm[s] = __builtin_fma(dm[s], tdd[s], mm[s] * tmd[s]);
+          mm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
+        } else {
+          dm[s] = mm[s] * tmd[s] + dm[s] * tdd[s];                       // pdhmm.h:431
+          mm[s] = pr * (mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]));   // :427-429
+        }
+      }
+      if (del_end) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < RPL; s++) {
+          const double ia = pd_max(s ? bmm[s - 1] : r[3], s ? mm[s - 1] : r[0]);
+          const double ib = pd_max(s ? bim[s - 1] : r[4], s ? im[s - 1] : r[1]);
+          if (FMA) im[s] = __builtin_fma(ib, tii[s], ia * tmi[s]);
+          else im[s] = ia * tmi[s] + ib * tii[s];
+        }
+      } else {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < RPL; s++) {
+          const double ia = s ? mm[s - 1] : r[0], ib = s ? im[s - 1] : r[1];
+          if (FMA) im[s] = __builtin_fma(ib, tii[s], ia * tmi[s]);
+          else im[s] = ia * tmi[s] + ib * tii[s];
+        }
+      }
+      sum = sum + (mm[RPL - 1] + im[RPL - 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) d[k] = r[k];
+    fetch_above();
+  }
+
   // a column is special when it is entered in state INSIDE_DEL / AFTER_DEL or carries DEL_END
   static __device__ __forceinline__ bool any_special(uint32_t e) {
     const bool special = (e & ((3u << 16) | ((uint32_t)kPdDelEnd << 8))) != 0u && (e & kPdIdle) == 0u;
@@ -370,9 +449,10 @@ struct PdJob {
 
   // A packed job (no stripes): alternate between runs of plain steps and runs of general steps, each in its own
   // loop so that neither pays register shuffling for the other at every iteration.
-  __device__ __forceinline__ void run_packed(const uint32_t* __restrict__ ep, int n_steps) {
+  // `bytewise`: some lane's haplotype has a base outside ACGTN (uniform over the wavefront): every step compares bytes.
+  __device__ __forceinline__ void run_packed(const uint32_t* __restrict__ ep, int n_steps, bool bytewise) {
     fetch_above();
-    if (kSerial) {
+    if (kSerial || bytewise) {
       uint32_t cur = ep[0];
       for (int t = 0; t < n_steps; t++) {
         const uint32_t nxt = ep[t + 1];
@@ -397,7 +477,7 @@ struct PdJob {
       }
       while (t < n_steps && any_special(cur)) {
         const uint32_t n3 = ep[t + 3];
-        step<false>(cur);
+        step_general(cur);
         cur = n1; n1 = n2; n2 = n3;
         t++;
       }
@@ -435,7 +515,7 @@ struct PdJob {
           if (lane == 0) r[k] = v;
         }
       }
-      step<false>(cur);   // striped jobs (reads over 255 bases) keep the general step
+      step<false>(cur);   // striped jobs (reads over 255 bases) keep the compute-and-select step
       cur = nxt;
       if (cout) {
         const int p = t - (kLanes - 1);
@@ -481,7 +561,8 @@ __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_con
       const int H = (int)a.hap_len[hi];
       const int n_blocks = ((int)a.read_len[ri] + Job::RPL) / Job::RPL;
       job.setup(a, p, sl.block, n_blocks, active, init_condition / (double)H);
-      job.run_packed(a.entries + (int64_t)hi * a.entry_stride + kLanes - sl.block, H + a.chunk_steps[chunk]);
+      const uint32_t* e0 = a.entries + (int64_t)hi * a.entry_stride;
+      job.run_packed(e0 + kLanes - sl.block, H + a.chunk_steps[chunk], __ballot((e0[0] & kPdOdd) != 0u) != 0);
       if (job.holds_last) a.sums[p] = job.sum;
       continue;
     }
@@ -497,7 +578,8 @@ __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_con
       const double init = init_condition / (double)H;  // pdhmm.h:867-878 (IEEE division, as on the host)
       job.setup(a, p, sl.block, n_blocks, active, init);
       // block k of a pair sees column j at step j + k
-      job.run_packed(a.entries + (int64_t)hi * a.entry_stride + kLanes - sl.block, a.job_steps[j]);
+      const uint32_t* e0 = a.entries + (int64_t)hi * a.entry_stride;
+      job.run_packed(e0 + kLanes - sl.block, a.job_steps[j], __ballot((e0[0] & kPdOdd) != 0u) != 0);
       if (job.holds_last) a.sums[p] = job.sum;
       continue;
     }

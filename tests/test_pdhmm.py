@@ -27,15 +27,22 @@ def pd_reference():
     return PdhmmReference()
 
 
-def random_pd_batch(rng, n, read_len=(1, 60), hap_len=(1, 80), flag_rate=0.15, lower=True, with_n=True):
+def random_pd_batch(rng, n, read_len=(1, 60), hap_len=(1, 80), flag_rate=0.15, lower=True, with_n=True, odd_haps=0.0):
+    """odd_haps: share of the haplotypes that carry bases outside ACGTN (lower case, IUPAC codes, 'n') -- the reference
+    compares raw bytes (pdhmm.h:256-262), so 'a' != 'A' but 'R' == 'R'."""
     pairs = []
-    alpha = np.frombuffer(b"ACGT" + (b"acgt" if lower else b"") + (b"N" if with_n else b""), dtype=np.int8)
+    alpha = np.frombuffer(b"ACGT" + (b"acgt" if lower else b"") + (b"N" if with_n else b"") + (b"RYn" if odd_haps else b""),
+                          dtype=np.int8)
+    odd_alpha = np.frombuffer(b"acgtnRYKM*", dtype=np.int8)
     for _ in range(n):
         H = int(rng.randint(hap_len[0], hap_len[1] + 1))
         R = int(rng.randint(read_len[0], read_len[1] + 1))
         hap = np.frombuffer(b"ACGT", dtype=np.int8)[rng.randint(0, 4, H)].copy()
         if with_n and H > 3 and rng.random_sample() < 0.3:
             hap[rng.randint(0, H)] = ord("N")
+        if odd_haps and rng.random_sample() < odd_haps:
+            k = int(rng.randint(1, 4))
+            hap[rng.randint(0, H, k)] = odd_alpha[rng.randint(0, odd_alpha.size, k)]
         pd = np.zeros(H, np.int8)
         for j in range(H):
             u = rng.random_sample()
@@ -195,7 +202,8 @@ def test_pdhmm_gpu_fixture_files(pd_ctx, pd_oracle, fname):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(), dict(flag_rate=0.5), dict(read_len=(200, 520), hap_len=(100, 400)),
                                 dict(read_len=(1, 8), hap_len=(1, 6), flag_rate=0.6),
-                                dict(read_len=(255, 257), hap_len=(60, 70))])
+                                dict(read_len=(255, 257), hap_len=(60, 70)),
+                                dict(odd_haps=0.3), dict(odd_haps=1.0, flag_rate=0.4, read_len=(20, 120), hap_len=(30, 160))])
 def test_pdhmm_gpu_random_batches_bit_exact(pd_ctx, pd_oracle, kw):
     rng = np.random.RandomState(77)
     b = random_pd_batch(rng, 96, **kw)
@@ -270,6 +278,26 @@ def test_pdhmm_gpu_cross_product_shares_haplotypes(pd_ctx, pd_oracle, shape):
     # permuting the pairs must not change any result (packing must not leak between lanes)
     perm = np.random.RandomState(1).permutation(b.batch)
     assert pd_ctx.compute(b.subset(perm)).tobytes() == vec[perm].tobytes()
+
+
+@pytest.mark.gpu
+def test_pdhmm_gpu_cross_entry_point_with_odd_haplotype_bases(pd_ctx, pd_oracle):
+    # some haplotypes carry bases outside ACGTN: their jobs take the byte-comparing steps, the others the bit-test ones
+    rng = np.random.RandomState(5)
+    reads = random_pd_batch(rng, 70, read_len=(30, 151), hap_len=(1, 2), odd_haps=0.5)
+    haps = random_pd_batch(rng, 9, read_len=(1, 2), hap_len=(100, 260), flag_rate=0.08, odd_haps=0.5)
+    got = pd_ctx.compute_cross(reads, haps)
+    pairs = []
+    for r in range(reads.batch):
+        R = int(reads.read_lengths[r])
+        rr = lambda a: a.reshape(reads.batch, reads.max_read_len)[r, :R]  # noqa: E731
+        for h in range(haps.batch):
+            H = int(haps.hap_lengths[h])
+            hh = lambda a: a.reshape(haps.batch, haps.max_hap_len)[h, :H]  # noqa: E731
+            pairs.append((hh(haps.hap_bases), hh(haps.hap_pdbases), rr(reads.read_bases), rr(reads.read_qual),
+                          rr(reads.read_ins_qual), rr(reads.read_del_qual), rr(reads.gcp)))
+    _, vec = pd_oracle.compute(PdhmmBatch.from_pairs(pairs), semantics=pd_ctx.sem)
+    assert got.tobytes() == vec.tobytes()
 
 
 @pytest.mark.gpu
