@@ -342,6 +342,7 @@ struct PdJob {
     const bool off = (ent & kPdIdle) != 0;
     if (!off) {
       if (last) {
+        asm volatile("" ::: "memory");   // a real (scalar) branch: as selects this is 24 v_cndmask in every plain step
 #pragma unroll
         for (int s = 0; s < RPL; s++) { bmm[s] = mm[s]; bim[s] = im[s]; bdm[s] = dm[s]; }
       }
@@ -366,6 +367,7 @@ struct PdJob {
       sum = sum + (mm[RPL - 1] + im[RPL - 1]);  // finalSum += M + I, ascending columns (:839-846)
     }
     if (last) {
+      asm volatile("" ::: "memory");
       if (!first) { d[3] = d[0]; d[4] = d[1]; d[5] = d[2]; }
       else { d[3] = r[3]; d[4] = r[4]; d[5] = r[5]; }
       r[3] = r[0]; r[4] = r[1]; r[5] = r[2];   // = the new d[0..2]
