@@ -329,26 +329,25 @@ struct PdJob {
     }
   }
 
-  // A plain step (no lane of the wavefront inside or just after a deletion, none on a DEL_END column -- the caller
-  // checked with a ballot; four out of five steps on real PD haplotypes).  The three live matrices are updated IN
-  // PLACE: match and deletion bottom-up (row s reads the OLD rows s-1 and s), then insertion top-down (row s reads
-  // the NEW match/insertion of row s-1) -- no state copies, where the general formulation spends 24 of its 93
-  // instructions on 64-bit moves.  Nothing reads the branch copies (own or the row above's) during a run of plain
-  // steps, so only the LAST step of a run (`last`) rebuilds them: a branch copy after a plain step is the live value
-  // from before it.  `first`: the run is one step long, the row above's copies at the previous column are still the
-  // DPP-fetched ones; otherwise they are its live values of two steps ago = d[0..2].
-  __device__ __forceinline__ void step_plain(uint32_t entry, bool last, bool first) {
+  // A plain step: no lane of the wavefront is inside or just after a deletion, none sits on a DEL_END column, and
+  // none will within the next two steps (the caller checked with ballots) -- four out of five steps on real PD
+  // haplotypes.  The three live matrices are updated IN PLACE: match and deletion bottom-up (row s reads the OLD rows
+  // s-1 and s), then insertion top-down (row s reads the NEW match/insertion of row s-1).  Nothing reads a branch copy
+  // (own or the row above's) during a run of plain steps and the two general steps that follow every run rebuild them
+  // (step_general: a branch copy after a step without events is the live value from before it), so a plain step touches
+  // neither the copies nor d[3..5] / r[3..5].
+  // kSwap: d[0..2] holds the row above at THIS column and r[0..2] at the previous one (the step before left them that
+  // way); either way the set that held the previous column receives the new hand-off, so consecutive plain steps
+  // alternate and move nothing.
+  template <bool kSwap>
+  __device__ __forceinline__ void step_plain(uint32_t entry) {
+    double (&dg)[6] = kSwap ? r : d;
+    double (&tp)[6] = kSwap ? d : r;
     ent = entry;
-    const bool off = (ent & kPdIdle) != 0;
-    if (!off) {
-      if (last) {
-        asm volatile("" ::: "memory");   // a real (scalar) branch: as selects this is 24 v_cndmask in every plain step
-#pragma unroll
-        for (int s = 0; s < RPL; s++) { bmm[s] = mm[s]; bim[s] = im[s]; bdm[s] = dm[s]; }
-      }
+    if ((ent & kPdIdle) == 0u) {
 #pragma unroll
       for (int s = RPL - 1; s >= 0; s--) {
-        const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
+        const double mmD = s ? mm[s - 1] : dg[0], imD = s ? im[s - 1] : dg[1], dmD = s ? dm[s - 1] : dg[2];
         const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
         if (FMA) {
           dm[s] = __builtin_fma(dm[s], tdd[s], mm[s] * tmd[s]);
@@ -360,27 +359,21 @@ struct PdJob {
       }
 #pragma unroll
       for (int s = 0; s < RPL; s++) {
-        const double ia = s ? mm[s - 1] : r[0], ib = s ? im[s - 1] : r[1];
+        const double ia = s ? mm[s - 1] : tp[0], ib = s ? im[s - 1] : tp[1];
         if (FMA) im[s] = __builtin_fma(ib, tii[s], ia * tmi[s]);
         else im[s] = ia * tmi[s] + ib * tii[s];
       }
       sum = sum + (mm[RPL - 1] + im[RPL - 1]);  // finalSum += M + I, ascending columns (:839-846)
     }
-    if (last) {
-      asm volatile("" ::: "memory");
-      if (!first) { d[3] = d[0]; d[4] = d[1]; d[5] = d[2]; }
-      else { d[3] = r[3]; d[4] = r[4]; d[5] = r[5]; }
-      r[3] = r[0]; r[4] = r[1]; r[5] = r[2];   // = the new d[0..2]
-    }
-    d[0] = r[0]; d[1] = r[1]; d[2] = r[2];
-    r[0] = recv_above(mm[RPL - 1], lmask);
-    r[1] = recv_above(im[RPL - 1], lmask);
-    r[2] = recv_above(dm[RPL - 1], lmask);
+    dg[0] = recv_above(mm[RPL - 1], lmask);
+    dg[1] = recv_above(im[RPL - 1], lmask);
+    dg[2] = recv_above(dm[RPL - 1], lmask);
   }
 
   // The general step of the vector arithmetic (not kSerial: a lane's rows share the column's state).  The three kinds
   // of special lane differ from a plain lane only in how INPUTS are merged, so each kind does its extra work under its
-  // own EXEC mask and everything is updated in place, like step_plain:
+  // own EXEC mask and everything is updated in place, like step_plain (it also serves the two steps before a special
+  // column arrives, where no lane is special yet and it just rebuilds the copies):
   //   AFTER_DEL   left and diagonal cells become max(live, branch copy) (pdhmm.h:452-466) -- merged into the live
   //               registers before the step, which also makes the new branch copy "the old live value" as on a plain lane;
   //   INSIDE_DEL  keeps its branch copies; every other lane's become the old live values;
@@ -463,24 +456,28 @@ struct PdJob {
       }
       return;
     }
-    // entries are fetched three steps ahead: the step needs its own and (to know whether a run of plain steps ends)
-    // the next one, and a step is too short to hide a global load (the stream has 4 spare entries behind the last step)
+    // Entries are fetched three steps ahead (a step is too short to hide a global load; the stream has 4 spare idle
+    // entries behind the last step), which is also how far ahead the loop has to look: general steps start two steps
+    // before the first special column reaches a lane, so that the branch copies and both generations of the row above's
+    // copies (d[3..5], r[3..5]) are rebuilt by then.  One ballot per step (for the entry just fetched).
     uint32_t cur = ep[0], n1 = ep[1], n2 = ep[2];
+    bool s0 = any_special(cur), s1 = any_special(n1), s2 = any_special(n2);
     int t = 0;
     while (t < n_steps) {
-      bool first = true;   // of this run of plain steps
-      while (t < n_steps && !any_special(cur)) {
+      while (t < n_steps && !(s0 || s1 || s2)) {
         const uint32_t n3 = ep[t + 3];
-        const bool last = !(t + 1 < n_steps && !any_special(n1));
-        step_plain(cur, last, first);
-        first = false;
+        step_plain<false>(cur);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double x = d[k]; d[k] = r[k]; r[k] = x; }
         cur = n1; n1 = n2; n2 = n3;
+        s0 = s1; s1 = s2; s2 = any_special(n3);
         t++;
       }
-      while (t < n_steps && any_special(cur)) {
+      while (t < n_steps && (s0 || s1 || s2)) {
         const uint32_t n3 = ep[t + 3];
         step_general(cur);
         cur = n1; n1 = n2; n2 = n3;
+        s0 = s1; s1 = s2; s2 = any_special(n3);
         t++;
       }
     }

@@ -42,6 +42,15 @@ variants["8 mul, operands in 3 banks (20+i, 41+i, 82+i)"] = [f"v_mul_f32 v{20+i}
 variants["8 mul, src same bank (20+i, 41+i, 81+i)"] = [f"v_mul_f32 v{20+i}, v{41+i}, v{81+i}" for i in range(8)]
 variants["8 fmac, src1 = one shared reg (i, 41+i, 90)"] = [f"v_fmac_f32 v{i}, v{41+i}, v90" for i in range(8)]
 variants["8 fmac, src0 sgpr (i, s4, 82+i)"] = [f"v_fmac_f32 v{i}, s4, v{82+i}" for i in range(8)]
+variants["8 mul_f64 (same banks)"] = [f"v_mul_f64 v[{2*i}:{2*i+1}], v[{40+2*i}:{41+2*i}], v[{80+2*i}:{81+2*i}]" for i in range(8)]
+variants["8 mul_f64 (srcs in different banks)"] = [f"v_mul_f64 v[{2*i}:{2*i+1}], v[{40+2*i}:{41+2*i}], v[{82+2*i}:{83+2*i}]" for i in range(8)]
+variants["8 fmac_f64 (same banks)"] = [f"v_fmac_f64 v[{2*i}:{2*i+1}], v[{40+2*i}:{41+2*i}], v[{80+2*i}:{81+2*i}]" for i in range(8)]
+variants["8 fmac_f64 (srcs other banks: 2i, 42+2i... )"] = [f"v_fmac_f64 v[{2*i}:{2*i+1}], v[{42+2*i}:{43+2*i}], v[{80+2*i}:{81+2*i}]" for i in range(8)]
+variants["8 add_f64"] = [f"v_add_f64 v[{2*i}:{2*i+1}], v[{40+2*i}:{41+2*i}], v[{80+2*i}:{81+2*i}]" for i in range(8)]
+variants["8 max_f64"] = [f"v_max_f64 v[{2*i}:{2*i+1}], v[{40+2*i}:{41+2*i}], v[{80+2*i}:{81+2*i}]" for i in range(8)]
+variants["8 mov_b64"] = [f"v_mov_b64 v[{2*i}:{2*i+1}], v[{40+2*i}:{41+2*i}]" for i in range(8)]
+variants["4 x (and, cmp_lt vcc, cndmask, cndmask)"] = sum([[f"v_and_b32 v{20+i}, v30, v{40+i}", f"v_cmp_lt_u32 vcc, s4, v{20+i}", f"v_cndmask_b32 v{2*i}, v{50+i}, v{60+i}, vcc", f"v_cndmask_b32 v{2*i+1}, v{70+i}, v{80+i}, vcc"] for i in range(2)], [])
+variants["PD row x2: mul fmac fmac mul mul fmac (f64) + and cmp cnd cnd"] = sum([[f"v_mul_f64 v[{a}:{a+1}], v[40:41], v[80:81]", f"v_fmac_f64 v[{a}:{a+1}], v[42:43], v[82:83]", f"v_fmac_f64 v[{a}:{a+1}], v[44:45], v[82:83]", f"v_and_b32 v30, v31, v{60+a}", "v_cmp_lt_u32 vcc, s4, v30", f"v_cndmask_b32 v32, v50, v52, vcc", f"v_cndmask_b32 v33, v51, v53, vcc", f"v_mul_f64 v[{a+2}:{a+3}], v[{a}:{a+1}], v[32:33]", f"v_mul_f64 v[{a+4}:{a+5}], v[46:47], v[84:85]", f"v_fmac_f64 v[{a+4}:{a+5}], v[48:49], v[86:87]"] for a in (0, 8)], [])
 def rows8():
     out = []
     for r in range(8):
