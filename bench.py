@@ -21,8 +21,14 @@ library's own sharding rule, gklhip_partition_reads), one per rank, haplotypes r
 The timed loop never synchronises inside: the host-side planning of step k+1 overlaps the
 kernels of step k.  `value` = cells of K steps / wall time of K steps.  The latency of ONE call
 (nothing to overlap with) is reported separately under "single_call" and "small_batch".
-(`--overlap` alternates consecutive steps between two contexts on two streams; measured: no
-gain -- one step's kernels already saturate the chip -- so it is not the default.)
+For N>1 every rank alternates consecutive steps between two contexts on two streams: a shard's
+kernels are short, and their fill, drain and last-wave tails plus the planning kernel between the
+passes leave holes that the neighbouring step's kernels fill (an eighth of the batch: 2.09 ->
+1.85 ms per step; `config.step_overlap`, `--no-overlap` turns it off).  The N=1 line stays
+single-stream -- a kernel's event-to-event time must be that of a kernel running alone for the
+roofline -- and reports the two-stream rate of the whole batch as `two_callers` (-3 %);
+`--overlap` makes it the timed region.  With two streams `kernels_ms` and `roofline` come from
+the single-call probe after the timed region (`kernels_ms.from` says which).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the fp32 forward
 kernel): 12 FLOP per cell x cells per launch / its HIP-event duration,
@@ -183,8 +189,11 @@ def main():
                                                         "read range of the one batch")
     ap.add_argument("--config4", action="store_true", help="BASELINE config 4: ONE 8000 x 125 batch (1 M pairs), sharded")
     ap.add_argument("--strong", action="store_true", help="(default for N>1; kept for compatibility)")
-    ap.add_argument("--overlap", action="store_true", help="two contexts on two streams alternate between consecutive steps "
-                                                           "(measured: no gain, the chip is saturated by one step's kernels)")
+    ap.add_argument("--overlap", action="store_true", help="N=1: two contexts on two streams alternate between consecutive steps (the "
+                                                           "default for N>1, where a shard's kernels leave the chip under-filled at "
+                                                           "their ends; at N=1 the default line stays single-stream so that the "
+                                                           "roofline's kernel durations are those of kernels running alone)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: one context, one stream per rank")
     ap.add_argument("--in-library-probe", type=int, default=0, help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.config4:
@@ -234,7 +243,7 @@ def main():
     dbatch = native.DeviceBatch.upload(batch, dev)
     # record_events=2: kernels are bracketed with HIP events but no call synchronises, so the host-side planning of
     # step k+1 overlaps the kernels of step k; the event times are read after the timed region.
-    n_ctx = 2 if a.overlap else 1
+    n_ctx = 2 if (a.overlap or (world > 1 and not a.no_overlap)) else 1
     ctxs = [native.PairHmmContext(use_double=a.double, device=dev_index, record_events=2) for _ in range(n_ctx)]
     streams = [torch.cuda.Stream(dev) for _ in range(n_ctx)]
     # N>1: the gather of step k (RCCL, its own stream) overlaps the kernels of step k+1; result buffers rotate
@@ -303,6 +312,13 @@ def main():
             st["n_fallback"] = pst["n_fallback"]   # needs a synchronising call: outside the timed region
         k_ms = float(np.mean(ms_main))
         fb_ms = float(np.mean(ms_fb))
+        dev_ms = float(np.mean(ms_dev))
+        kernel_times_from = "HIP events of the timed steps"
+        if n_ctx > 1:
+            # consecutive steps share the chip: a kernel's event-to-event time in the timed region includes the other
+            # stream's kernels.  The durations of kernels running ALONE come from the probe call above.
+            k_ms, fb_ms, dev_ms = pst["ms_fwd_main"], pst["ms_fwd_fallback"], pst["ms_total_device"]
+            kernel_times_from = "the single-call probe after the timed region (in it consecutive steps overlap on two streams)"
         step_ms = elapsed / a.steps * 1e3
         achieved = FLOP_PER_CELL * batch.cells / (k_ms * 1e-3) / 1e12
         traffic_profile = None
@@ -347,7 +363,7 @@ def main():
                                  "(1.5 flop per instruction) and a SIMD retires one plain VALU op per ~2.7 cycles (measured), "
                                  "so its issue-bound ceiling is ~7 TCUPS = 0.53 of peak (DESIGN.md section 3)"},
             "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(fb_ms, 3),
-                           "device_total": round(float(np.mean(ms_dev)), 3)},
+                           "device_total": round(dev_ms, 3), "from": kernel_times_from},
             # what a step costs beyond its two forward kernels (planning, policy, log10, launches, gaps); with
             # overlapping steps it can be negative (the other step's kernels fill the gaps)
             "fixed_cost_ms": round(step_ms - k_ms - fb_ms, 3),
@@ -358,7 +374,31 @@ def main():
             "plan": {"chunks": st["n_chunks"], "hap_groups": st["n_hap_groups"], "rows_per_lane": st["rows_per_lane"],
                      "lane_fill": round(st["lane_fill"], 4)},
         }
-        if world == 1 and not a.no_extras and not a.double:
+        if world == 1 and not a.no_extras and not a.double and n_ctx == 1:
+            try:
+                # two callers on one GPU (what the JNI shim's slots give concurrent GATK threads, and what every rank of
+                # an N>1 run does): two contexts on two streams alternate between consecutive steps
+                c2 = [native.PairHmmContext(device=dev_index, record_events=0) for _ in range(2)]
+                s2 = [torch.cuda.Stream(dev) for _ in range(2)]
+                o2 = [torch.empty(batch.n_pairs, dtype=torch.float64, device=dev) for _ in range(2)]
+                def two(k):
+                    with torch.cuda.stream(s2[k % 2]):
+                        c2[k % 2].compute_device(dbatch, o2[k % 2], s2[k % 2])
+                for k in range(4):
+                    two(k)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for k in range(a.steps):
+                    two(k)
+                torch.cuda.synchronize(dev)
+                e2 = time.perf_counter() - t1
+                for c in c2:
+                    c.close()
+                res["two_callers"] = {"ms_per_step": round(e2 / a.steps * 1e3, 3), "gcups": round(batch.cells * a.steps / e2 / 1e9, 1),
+                                      "note": "same batch, two contexts on two streams alternating between consecutive steps: the "
+                                              "tails of one step's kernels and its planning kernel are filled by the other's"}
+            except Exception as e:
+                res["two_callers"] = {"error": repr(e)}
             try:
                 # end to end through gklhip_compute (H2D, D2H, reference-exact host log10)
                 res["host_path"] = {
