@@ -167,6 +167,14 @@ __device__ __forceinline__ double pd_max(double x, double y) {
 // itself runs on the last `batch mod SIMD width` pairs of every vector batch (pdhmm.h:1264-1270): state carried from
 // row to row, M = prior*((Md*tMM + Id*tIM) + Dd*tIM) without FMA, a read base that is not A/C/G/T has no allele bit
 // and is an input error under a SNP column.  General steps only (a handful of pairs per batch).
+// fma with an untied destination: the compiler's v_fmac_f64 accumulates into the product's register, and where that
+// is not the state register (the in-place deletion update) it pays a v_mov_b64 -- as expensive as the fma -- per value.
+__device__ __forceinline__ double pd_fma3(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 template <bool FMA, bool kSerial = false>
 struct PdJob {
   static constexpr int RPL = kPdRpl;
@@ -336,21 +344,15 @@ struct PdJob {
   // (own or the row above's) during a run of plain steps and the two general steps that follow every run rebuild them
   // (step_general: a branch copy after a step without events is the live value from before it), so a plain step touches
   // neither the copies nor d[3..5] / r[3..5].
-  // kSwap: d[0..2] holds the row above at THIS column and r[0..2] at the previous one (the step before left them that
-  // way); either way the set that held the previous column receives the new hand-off, so consecutive plain steps
-  // alternate and move nothing.
-  template <bool kSwap>
   __device__ __forceinline__ void step_plain(uint32_t entry) {
-    double (&dg)[6] = kSwap ? r : d;
-    double (&tp)[6] = kSwap ? d : r;
     ent = entry;
     if ((ent & kPdIdle) == 0u) {
 #pragma unroll
       for (int s = RPL - 1; s >= 0; s--) {
-        const double mmD = s ? mm[s - 1] : dg[0], imD = s ? im[s - 1] : dg[1], dmD = s ? dm[s - 1] : dg[2];
+        const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
         const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
         if (FMA) {
-          dm[s] = __builtin_fma(dm[s], tdd[s], mm[s] * tmd[s]);
+          dm[s] = pd_fma3(dm[s], tdd[s], mm[s] * tmd[s]);
           mm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
         } else {
           dm[s] = mm[s] * tmd[s] + dm[s] * tdd[s];                       // pdhmm.h:431
@@ -359,15 +361,17 @@ struct PdJob {
       }
 #pragma unroll
       for (int s = 0; s < RPL; s++) {
-        const double ia = s ? mm[s - 1] : tp[0], ib = s ? im[s - 1] : tp[1];
+        const double ia = s ? mm[s - 1] : r[0], ib = s ? im[s - 1] : r[1];
         if (FMA) im[s] = __builtin_fma(ib, tii[s], ia * tmi[s]);
         else im[s] = ia * tmi[s] + ib * tii[s];
       }
       sum = sum + (mm[RPL - 1] + im[RPL - 1]);  // finalSum += M + I, ascending columns (:839-846)
     }
-    dg[0] = recv_above(mm[RPL - 1], lmask);
-    dg[1] = recv_above(im[RPL - 1], lmask);
-    dg[2] = recv_above(dm[RPL - 1], lmask);
+    d[0] = r[0]; d[1] = r[1]; d[2] = r[2];
+    asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));  // the copies first: the hand-off can then land in r's registers
+    r[0] = recv_above(mm[RPL - 1], lmask);
+    r[1] = recv_above(im[RPL - 1], lmask);
+    r[2] = recv_above(dm[RPL - 1], lmask);
   }
 
   // The general step of the vector arithmetic (not kSerial: a lane's rows share the column's state).  The three kinds
@@ -404,7 +408,7 @@ struct PdJob {
         const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
         const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
         if (FMA) {
-          dm[s] = __builtin_fma(dm[s], tdd[s], mm[s] * tmd[s]);
+          dm[s] = pd_fma3(dm[s], tdd[s], mm[s] * tmd[s]);
           mm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
         } else {
           dm[s] = mm[s] * tmd[s] + dm[s] * tdd[s];                       // pdhmm.h:431
@@ -466,9 +470,7 @@ struct PdJob {
     while (t < n_steps) {
       while (t < n_steps && !(s0 || s1 || s2)) {
         const uint32_t n3 = ep[t + 3];
-        step_plain<false>(cur);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const double x = d[k]; d[k] = r[k]; r[k] = x; }
+        step_plain(cur);
         cur = n1; n1 = n2; n2 = n3;
         s0 = s1; s1 = s2; s2 = any_special(n3);
         t++;
