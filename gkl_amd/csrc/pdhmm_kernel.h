@@ -38,7 +38,9 @@ constexpr int kPdSnp = 1, kPdDelStart = 2, kPdDelEnd = 4, kPdA = 8, kPdC = 16, k
 // (PdJob::xinfo) and the row matches the column iff (entry & xinfo) has a bit above bit 19.  Bit 31 ("odd") marks a
 // base outside ACGTN, where equality of the raw bytes cannot be read off the one-hot bits: such columns take the
 // byte-comparing step.
-constexpr uint32_t kPdIdle = 1u << 30, kPdOdd = 1u << 31, kPdMatchBits = 0xfffffu;
+// Bit 15 ("special"): the column is entered inside or right after a deletion or carries DEL_END -- the one bit the
+// step loop ballots on.
+constexpr uint32_t kPdIdle = 1u << 30, kPdOdd = 1u << 31, kPdMatchBits = 0xfffffu, kPdSpecial = 1u << 15;
 __device__ __forceinline__ uint32_t pd_onehot_acgt(uint32_t b) {
   return b == (uint32_t)'A' ? 1u : b == (uint32_t)'C' ? 2u : b == (uint32_t)'G' ? 4u : b == (uint32_t)'T' ? 8u : 0u;
 }
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
       const uint32_t allele = (flags & kPdSnp) ? ((flags >> 3) & 0xfu) : 0u;
       const bool is_n = yb == (uint32_t)'N';
       e[j] = yb | (flags << 8) | (state << 16) | (state << 18) | (hot << 20) | (allele << 24) | (1u << 28) |
-             (is_n ? 1u << 29 : 0u) | ((hot == 0u && !is_n) ? kPdOdd : 0u);
+             (is_n ? 1u << 29 : 0u) | ((hot == 0u && !is_n) ? kPdOdd : 0u) |
+             ((state != 0u || (flags & kPdDelEnd) != 0u) ? kPdSpecial : 0u);
     }
     const uint64_t fl = __ballot(flagged);
     if (fl && first_flagged == H) first_flagged = base + __builtin_ctzll(fl);
@@ -442,8 +445,7 @@ struct PdJob {
 
   // a column is special when it is entered in state INSIDE_DEL / AFTER_DEL or carries DEL_END
   static __device__ __forceinline__ bool any_special(uint32_t e) {
-    const bool special = (e & ((3u << 16) | ((uint32_t)kPdDelEnd << 8))) != 0u && (e & kPdIdle) == 0u;
-    return __ballot(special) != 0;
+    return __ballot((int)(e & kPdSpecial)) != 0;   // idle entries never carry the bit
   }
 
   // A packed job (no stripes): alternate between runs of plain steps and runs of general steps, each in its own
@@ -460,26 +462,28 @@ struct PdJob {
       }
       return;
     }
-    // Entries are fetched three steps ahead (a step is too short to hide a global load; the stream has 4 spare idle
-    // entries behind the last step), which is also how far ahead the loop has to look: general steps start two steps
+    // Entries are fetched four steps ahead (a step is too short to hide a global load; the stream has spare idle
+    // entries behind the last step).  The loop has to look three entries ahead anyway: general steps start two steps
     // before the first special column reaches a lane, so that the branch copies and both generations of the row above's
-    // copies (d[3..5], r[3..5]) are rebuilt by then.  One ballot per step (for the entry just fetched).
-    uint32_t cur = ep[0], n1 = ep[1], n2 = ep[2];
+    // copies (d[3..5], r[3..5]) are rebuilt by then.  One ballot per step, on an entry fetched the step before.
+    uint32_t cur = ep[0], n1 = ep[1], n2 = ep[2], n3 = ep[3];
     bool s0 = any_special(cur), s1 = any_special(n1), s2 = any_special(n2);
     int t = 0;
     while (t < n_steps) {
       while (t < n_steps && !(s0 || s1 || s2)) {
-        const uint32_t n3 = ep[t + 3];
+        const uint32_t n4 = ep[t + 4];
+        const bool s3 = any_special(n3);
         step_plain(cur);
-        cur = n1; n1 = n2; n2 = n3;
-        s0 = s1; s1 = s2; s2 = any_special(n3);
+        cur = n1; n1 = n2; n2 = n3; n3 = n4;
+        s0 = s1; s1 = s2; s2 = s3;
         t++;
       }
       while (t < n_steps && (s0 || s1 || s2)) {
-        const uint32_t n3 = ep[t + 3];
+        const uint32_t n4 = ep[t + 4];
+        const bool s3 = any_special(n3);
         step_general(cur);
-        cur = n1; n1 = n2; n2 = n3;
-        s0 = s1; s1 = s2; s2 = any_special(n3);
+        cur = n1; n1 = n2; n2 = n3; n3 = n4;
+        s0 = s1; s1 = s2; s2 = s3;
         t++;
       }
     }
