@@ -313,7 +313,7 @@ class PairHmmContext:
 
 
 # ---------------------------------------------------------------- PDHMM (include/gkl_hip_pdhmm.h)
-PDHMM_LIB_PATH = os.path.join(LIB_DIR, "libgklhip_pdhmm.so")
+PDHMM_LIB_PATH = os.environ.get("GKL_AMD_PDHMM_LIB") or os.path.join(LIB_DIR, "libgklhip_pdhmm.so")   # the variable: A/B of library builds (dev tool)
 
 
 class CPdhmmBatch(C.Structure):
