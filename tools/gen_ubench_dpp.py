@@ -51,6 +51,17 @@ variants["8 max_f64"] = [f"v_max_f64 v[{2*i}:{2*i+1}], v[{40+2*i}:{41+2*i}], v[{
 variants["8 mov_b64"] = [f"v_mov_b64 v[{2*i}:{2*i+1}], v[{40+2*i}:{41+2*i}]" for i in range(8)]
 variants["4 x (and, cmp_lt vcc, cndmask, cndmask)"] = sum([[f"v_and_b32 v{20+i}, v30, v{40+i}", f"v_cmp_lt_u32 vcc, s4, v{20+i}", f"v_cndmask_b32 v{2*i}, v{50+i}, v{60+i}, vcc", f"v_cndmask_b32 v{2*i+1}, v{70+i}, v{80+i}, vcc"] for i in range(2)], [])
 variants["PD row x2: mul fmac fmac mul mul fmac (f64) + and cmp cnd cnd"] = sum([[f"v_mul_f64 v[{a}:{a+1}], v[40:41], v[80:81]", f"v_fmac_f64 v[{a}:{a+1}], v[42:43], v[82:83]", f"v_fmac_f64 v[{a}:{a+1}], v[44:45], v[82:83]", f"v_and_b32 v30, v31, v{60+a}", "v_cmp_lt_u32 vcc, s4, v30", f"v_cndmask_b32 v32, v50, v52, vcc", f"v_cndmask_b32 v33, v51, v53, vcc", f"v_mul_f64 v[{a+2}:{a+3}], v[{a}:{a+1}], v[32:33]", f"v_mul_f64 v[{a+4}:{a+5}], v[46:47], v[84:85]", f"v_fmac_f64 v[{a+4}:{a+5}], v[48:49], v[86:87]"] for a in (0, 8)], [])
+def dppx(ctrl, d, s_, nop=True, op="v_and_b32_dpp", extra="row_mask:0xf bank_mask:0xf bound_ctrl:1"):
+    third = ", v31" if op.startswith("v_and") else ""
+    return (["s_nop 1"] if nop else []) + [f"{op} v{d}, v{s_}{third} {ctrl} {extra}"]
+for name, ctrl in (("wave_shr:1", "wave_shr:1"), ("row_shr:1", "row_shr:1"), ("row_bcast:15", "row_bcast:15"), ("quad_perm", "quad_perm:[0,0,1,2]"), ("row_ror:1", "row_ror:1")):
+    # 3 producers (fmac), 3 dpp of them, 3 consumers of the dpp results, + 16 filler fmacs: the kernel's hand-off in miniature
+    variants[f"handoff {name}: 16 fmac + 3 prod + 3 dpp(nop) + 3 cons"] = fmacs(16, 4) + [f"v_fmac_f32 v{i}, v{60+i}, v{90+i}" for i in range(3)] + sum([dppx(ctrl, 20 + i, i) for i in range(3)], []) + [f"v_fmac_f32 v{24+i}, v{20+i}, v{70+i}" for i in range(3)]
+variants["handoff none: 16 fmac + 3 prod + 3 v_and + 3 cons"] = fmacs(16, 4) + [f"v_fmac_f32 v{i}, v{60+i}, v{90+i}" for i in range(3)] + [f"v_and_b32 v{20+i}, v{i}, v31" for i in range(3)] + [f"v_fmac_f32 v{24+i}, v{20+i}, v{70+i}" for i in range(3)]
+variants["handoff bpermute: 16 fmac + 3 prod + 3 ds_bpermute + 3 cons"] = fmacs(16, 4) + [f"v_fmac_f32 v{i}, v{60+i}, v{90+i}" for i in range(3)] + [f"ds_bpermute_b32 v{20+i}, v34, v{i}" for i in range(3)] + ["s_waitcnt lgkmcnt(0)"] + [f"v_fmac_f32 v{24+i}, v{20+i}, v{70+i}" for i in range(3)]
+variants["handoff lds: 16 fmac + 3 prod + ds_write_b96 + ds_read_b96 + 3 cons"] = fmacs(16, 4) + [f"v_fmac_f32 v{i}, v{60+i}, v{90+i}" for i in range(3)] + ["ds_write_b96 v35, v[0:2]", "ds_read_b96 v[20:22], v38", "s_waitcnt lgkmcnt(0)"] + [f"v_fmac_f32 v{24+i}, v{20+i}, v{70+i}" for i in range(3)]
+variants["handoff wave_shr far: 3 prod + 16 fmac + 3 dpp(nop) + 3 cons"] = [f"v_fmac_f32 v{i}, v{60+i}, v{90+i}" for i in range(3)] + fmacs(16, 4) + sum([dppx("wave_shr:1", 20 + i, i) for i in range(3)], []) + [f"v_fmac_f32 v{24+i}, v{20+i}, v{70+i}" for i in range(3)]
+variants["handoff wave_shr, consumers far: 3 prod + 3 dpp(nop) + 16 fmac + 3 cons"] = [f"v_fmac_f32 v{i}, v{60+i}, v{90+i}" for i in range(3)] + sum([dppx("wave_shr:1", 20 + i, i) for i in range(3)], []) + fmacs(16, 4) + [f"v_fmac_f32 v{24+i}, v{20+i}, v{70+i}" for i in range(3)]
 def rows8():
     out = []
     for r in range(8):
