@@ -13,12 +13,13 @@
 // lane owns RPL read rows in registers, the haplotype's columns stream through the lanes, the
 // row above arrives by DPP wave_shr:1 -- with three differences dictated by the algorithm:
 //   * every pair may have its own haplotype, so each lane reads its OWN column stream (one coalesced
-//     4-byte load per step, prefetched a step ahead) instead of receiving the column from the lane
+//     4-byte load per step, fetched four steps ahead) instead of receiving the column from the lane
 //     above; that lets pairs with different haplotypes sit side by side in one wavefront.  Reads
 //     longer than 64*RPL-1 rows run alone, as consecutive stripes with the boundary row carried
 //     through memory;
 //   * the per-column symbol is (base, SNP allele mask, state, DEL_END flag), too many values for
-//     an LDS prior table, so the match predicate is evaluated per cell (4 integer ops + select);
+//     an LDS prior table, so the match predicate is evaluated per cell (one AND of mirrored bit fields of the
+//     entry and the row, a compare and the 64-bit select);
 //   * six values cross from lane to lane per step instead of three.
 #pragma once
 #include <hip/hip_runtime.h>
