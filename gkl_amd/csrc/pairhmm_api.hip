@@ -249,6 +249,14 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 #define GKL_RPL_F64 6
 #endif
 constexpr int kRplF64 = GKL_RPL_F64;
+// The packed fp64 pass of the precision policy (job-list kernel, two wavefronts per SIMD = 256 VGPRs): 8 rows per lane
+// fit without a spill (233 VGPRs), a quarter fewer hand-offs per cell and shorter general-step windows than 6 -- the pass
+// takes 2.91 instead of 3.23 ms (three A/B pairs on one box).  The all-fp64 streaming kernel stays at 6 (168 VGPRs, three
+// wavefronts per SIMD; at 8 it spills 114-143 registers).
+#ifndef GKL_RPL_F64_JOBS
+#define GKL_RPL_F64_JOBS 8
+#endif
+constexpr int kRplF64Jobs = GKL_RPL_F64_JOBS;
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block
 constexpr int64_t kDirectPairs = 16384;        // calls up to this many pairs: policy + fp64 recomputation of one pair per wavefront in one launch
 constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the policy + planning kernel (a grid barrier costs ~50 ns per block)
@@ -320,9 +328,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   // pseudo-chunk index space: [0, n_long_main) main-pass reads, then [n_long_main, +n_long64) fp64-pass reads
   for (int32_t r : long_main) { long_lanes.resize(long_lanes.size() + kLanes, PlanLane{-1, 0}); long_lanes[long_lanes.size() - kLanes] = PlanLane{r, 0}; }
   int n_long64 = 0;  // reads too long for the packed fp64 pass
-  if (!use_double && plan.max_read_len > kLanes * rpl64 - 1)
+  if (!use_double && plan.max_read_len > kLanes * kRplF64Jobs - 1)
     for (int r = 0; r < n_reads; r++)
-      if (blocks_for((int)(db->read_off[r + 1] - db->read_off[r]), rpl64) > kLanes) {
+      if (blocks_for((int)(db->read_off[r + 1] - db->read_off[r]), kRplF64Jobs) > kLanes) {
         long_lanes.resize(long_lanes.size() + kLanes, PlanLane{-1, 0});
         long_lanes[long_lanes.size() - kLanes] = PlanLane{r, 0};
         n_long64++;
@@ -581,7 +589,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     int32_t* cnts = c->counters.as<int32_t>();
     // Small calls (one GATK region): policy + fp64 recomputation + finalisation of one pair per wavefront in ONE launch
     // (pairhmm_pair_policy_kernel); rows per lane by the longest read.
-    const bool per_pair = n_pairs <= kDirectPairs && n_long64 == 0;
+    // (the one-pair-per-wavefront kernel holds at most 64 x kRplF64 - 1 rows)
+    const bool per_pair = n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
     if (per_pair) {
       PairPolicyArgs q;
       q.raw32 = c->raw32.as<float>(); q.out = out_dev; q.used64 = c->used64.as<uint8_t>(); q.count = cnts;
@@ -616,7 +625,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       pa.fa = fa;
       pa.n_reads = n_reads; pa.n_haps = n_haps; pa.n_pairs_i = (int32_t)n_pairs;
       pa.read_off = b.read_off;
-      pa.rpl = rpl64; pa.max_len = kLanes * rpl64 - 1;
+      pa.rpl = kRplF64Jobs; pa.max_len = kLanes * kRplF64Jobs - 1;
       pa.cnts = cnts;
       pa.hist = c->fail_hist.as<int32_t>();
       pa.pos = pa.hist + (n_haps + 2);
@@ -654,7 +663,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     d.n_chunks = n_reads;  // upper bound; the job list only names packed chunks
     d.jobs = c->jobs.as<FwdJob>() + max_jobs;
     if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
-    launch_jobs<double, kRplF64>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
+    launch_jobs<double, kRplF64Jobs>(d, fma, (int)std::min<int64_t>(n_pairs, (int64_t)c->n_cus * 16), s);
     if (n_long64 > 0) {
       // reads too long for a chunk: one pseudo-chunk each, same run detection, striped kernel
       FwdArgs<double> ld = d;
