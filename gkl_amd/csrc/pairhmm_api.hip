@@ -249,10 +249,11 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 #define GKL_RPL_F64 6
 #endif
 constexpr int kRplF64 = GKL_RPL_F64;
-// The packed fp64 pass of the precision policy (job-list kernel, two wavefronts per SIMD = 256 VGPRs): 8 rows per lane
-// fit without a spill (233 VGPRs), a quarter fewer hand-offs per cell and shorter general-step windows than 6 -- the pass
-// takes 2.91 instead of 3.23 ms (three A/B pairs on one box).  The all-fp64 streaming kernel stays at 6 (168 VGPRs, three
-// wavefronts per SIMD; at 8 it spills 114-143 registers).
+// The streaming and job-list fp64 kernels run two wavefronts per SIMD (256 VGPRs): 8 rows per lane fit without a spill
+// (233 VGPRs), a quarter fewer hand-offs per cell and shorter general-step windows than 6 -- the packed fp64 pass of the
+// precision policy takes 2.91 instead of 3.23 ms, the all-fp64 mode 17.8 instead of 18.2 ms (A/B on one box).  kRplF64
+// (6) remains the row count of the one-pair-per-wavefront kernel (three wavefronts per SIMD) and of the striped
+// long-read kernel.
 #ifndef GKL_RPL_F64_JOBS
 #define GKL_RPL_F64_JOBS 8
 #endif
@@ -314,7 +315,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   // ---- plan (host) ----
   const auto t_plan0 = std::chrono::steady_clock::now();
   Plan& plan = c->plan;
-  const int rpl64 = kRplF64;
+  const int rpl64 = kRplF64Jobs;
   const int rpl_main = use_double ? rpl64 : pick_f32_rpl(c->cfg.rows_per_lane, n_reads, n_haps, db->read_off, db->hap_off);
   static const int target_cols_env = [] { const char* v = getenv("GKLHIP_TARGET_COLS"); return v ? atoi(v) : 0; }();
   build_plan(n_reads, n_haps, db->read_off, db->hap_off, rpl_main, target_cols_env > 0 ? target_cols_env : kTargetCols, &plan);
@@ -543,7 +544,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     a.tab = c->dt64;
     a.y0 = reinterpret_cast<const double*>(dp + L.y0_64);
     a.raw = c->raw64.as<double>();
-    if (n_main_blocks > 0) launch_stream<double, kRplF64>(a, fma, n_main_blocks, s);
+    if (n_main_blocks > 0) launch_stream<double, kRplF64Jobs>(a, fma, n_main_blocks, s);
     if (n_long_main > 0) {
       FwdArgs<double> la = a;
       la.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.long_lanes);

@@ -608,7 +608,7 @@ struct WaveJob {
 // ---- kernels -------------------------------------------------------------------
 // Main pass: block (one wavefront) = (chunk of packed reads) x (haplotype group).
 template <typename T, int RPL, bool FMA>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 3 : 4))) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 2 : 4))) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
   using Job = WaveJob<T, RPL, FMA>;
   __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
@@ -624,9 +624,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
 
 // Job-list pass (packed fp64 recomputation): persistent wavefronts pull (chunk, haplotype run)
 // jobs built on the device from the fallback flags; chunks come from a second read packing
-// that groups reads with similar fallback patterns.  fp64: two wavefronts per SIMD (220-238 VGPRs, no spills) -- at
-// the three of the streaming kernel (168 VGPRs) the general step behind the separators, a fifth of this pass's steps,
-// spills 15-27 registers (measured on one box: 3.45 -> 3.28 ms).
+// that groups reads with similar fallback patterns.  fp64 (here and in the streaming kernel): two wavefronts per SIMD
+// -- at three (168 VGPRs) the general step behind the separators spills 15-27 registers at 6 rows per lane (3.45 ->
+// 3.28 ms), and the 256-VGPR budget then holds 8 rows per lane without a spill (-> 2.91 ms).
 template <typename T, int RPL, bool FMA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 2 : 4))) void pairhmm_fwd_jobs_kernel(FwdArgs<T> a) {
   using Job = WaveJob<T, RPL, FMA>;
