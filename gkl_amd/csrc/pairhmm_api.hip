@@ -249,13 +249,13 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 #define GKL_RPL_F64 6
 #endif
 constexpr int kRplF64 = GKL_RPL_F64;
-// The streaming and job-list fp64 kernels run two wavefronts per SIMD (256 VGPRs): 8 rows per lane fit without a spill
-// (233 VGPRs), a quarter fewer hand-offs per cell and shorter general-step windows than 6 -- the packed fp64 pass of the
-// precision policy takes 2.91 instead of 3.23 ms, the all-fp64 mode 17.8 instead of 18.2 ms (A/B on one box).  kRplF64
-// (6) remains the row count of the one-pair-per-wavefront kernel (three wavefronts per SIMD) and of the striped
-// long-read kernel.
+// The streaming and job-list fp64 kernels run two wavefronts per SIMD (256 VGPRs, 8 x 20 KB of LDS): 10 rows per lane
+// (20 spilled registers, none in the unrolled loop) -- fewer hand-offs per cell and shorter general-step windows than 6
+// or 8: the packed fp64 pass of the precision policy takes 3.23 (6 rows) / 2.91 (8) / 2.77 ms (10), the all-fp64 mode
+// 18.2 / 17.8 / 17.1 ms (A/B on one box; 12 rows would leave LDS for three wavefronts per CU pair only).  kRplF64 (6)
+// remains the row count of the one-pair-per-wavefront kernel (three wavefronts per SIMD) and of the striped long-read kernel.
 #ifndef GKL_RPL_F64_JOBS
-#define GKL_RPL_F64_JOBS 8
+#define GKL_RPL_F64_JOBS 10
 #endif
 constexpr int kRplF64Jobs = GKL_RPL_F64_JOBS;
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) ==
 // jobs built on the device from the fallback flags; chunks come from a second read packing
 // that groups reads with similar fallback patterns.  fp64 (here and in the streaming kernel): two wavefronts per SIMD
 // -- at three (168 VGPRs) the general step behind the separators spills 15-27 registers at 6 rows per lane (3.45 ->
-// 3.28 ms), and the 256-VGPR budget then holds 8 rows per lane without a spill (-> 2.91 ms).
+// 3.28 ms), and the 256-VGPR budget then holds 8 rows per lane without a spill (-> 2.91 ms), 10 with a few (-> 2.77).
 template <typename T, int RPL, bool FMA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 2 : 4))) void pairhmm_fwd_jobs_kernel(FwdArgs<T> a) {
   using Job = WaveJob<T, RPL, FMA>;
