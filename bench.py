@@ -23,8 +23,8 @@ kernels of step k.  `value` = cells of K steps / wall time of K steps.  The late
 (nothing to overlap with) is reported separately under "single_call" and "small_batch".
 For N>1 every rank alternates consecutive steps between two contexts on two streams: a shard's
 kernels are short, and their fill, drain and last-wave tails plus the planning kernel between the
-passes leave holes that the neighbouring step's kernels fill (an eighth of the batch: 2.09 ->
-1.85 ms per step; `config.step_overlap`, `--no-overlap` turns it off).  The N=1 line stays
+passes leave holes that the neighbouring step's kernels fill (an eighth of the batch: 1.96 ->
+1.73 ms per step; `config.step_overlap`, `--no-overlap` turns it off).  The N=1 line stays
 single-stream -- a kernel's event-to-event time must be that of a kernel running alone for the
 roofline -- and reports the two-stream rate of the whole batch as `two_callers` (-3 %);
 `--overlap` makes it the timed region.  With two streams `kernels_ms` and `roofline` come from
