@@ -45,6 +45,12 @@ constexpr int kLanes = 64;
 // space lets every (wave-uniform) entry load be a scalar s_load, also in the job-list kernel whose atomics make the
 // compiler treat plain global memory as clobbered (there the entries came through global_load_dwordx4 + vmcnt waits).
 typedef const uint32_t __attribute__((address_space(4))) StreamWord;
+}  // namespace gklhip
+#include "pairhmm_fwd_fast_asm.h"  // fwd_fast_asm_f32r8: the fp32 / 8-row / FMA fast loop, hand-allocated (generated)
+#ifndef GKLHIP_FAST_ASM
+#define GKLHIP_FAST_ASM 1  // 0: the C++ fast step everywhere (A/B and parity cross-check builds)
+#endif
+namespace gklhip {
 
 template <typename T>
 struct DevTables {
@@ -193,6 +199,8 @@ struct WaveJob {
   // step, which gathers them row by row (haplotypes containing an N never enter the unrolled loop).
   static constexpr int kCodes = sizeof(T) == 8 ? 4 : 5;
   static constexpr int kLdsBytes = kCodes * kRowBytes;  // idle columns are handled in step_any
+  // fp32, 8 rows per lane, the AVX-512 object's FMA pattern (the default arithmetic): the unrolled loop is the generated asm block
+  static constexpr bool kAsmFast = GKLHIP_FAST_ASM && sizeof(T) == 4 && RPL == 8 && FMA;
   static_assert(RPL % kPerVec == 0, "RPL must fill whole 16-byte vectors");
   using Vec = T __attribute__((ext_vector_type(kPerVec)));
 
@@ -507,12 +515,16 @@ struct WaveJob {
       if (kCodes == 4 && a.hap_has_n[k]) fast_from = sep_at;  // an 'N' somewhere in it: general steps throughout
       const int slow_end = fast_from < sep_at ? fast_from : sep_at;
       run_any(a, sp, t, slow_end, lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
-      for (; t + U <= sep_at; t += U) {
-        uint32_t e[U];
+      if constexpr (kAsmFast) {
+        fwd_fast_asm_f32r8(*this, sp, t, sep_at, lane);
+      } else {
+        for (; t + U <= sep_at; t += U) {
+          uint32_t e[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) e[u] = sp[t + u];
+          for (int u = 0; u < U; u++) e[u] = sp[t + u];
 #pragma unroll
-        for (int u = 0; u < U; u++) step_fast(e[u], lane);
+          for (int u = 0; u < U; u++) step_fast(e[u], lane);
+        }
       }
       // < U leftover columns, still all in-haplotype.  fp32: they join the general steps below (unrolled by four with
       // the entries prefetched: measured 1.3 % faster than single fast steps that each wait for their scalar load);

@@ -254,6 +254,39 @@ def test_full_size_batch_properties(native, oracle):
     assert np.array_equal(bits(full[u == 1]), bits(fulld[u == 1]))  # fallback pairs ARE the fp64 path
 
 
+def test_asm_fast_loop_matches_the_cxx_build_and_the_oracle(native, oracle):
+    """The fp32 / 8-row fast loop is a generated asm block (pairhmm_fwd_fast_asm.h); libgklhip_pairhmm_cxxfast.so is the
+    same library with the C++ step in its place.  Both must give the oracle's bits -- long haplotypes so that most
+    columns run in the unrolled loop, N and odd bytes included, one read overflowing next to healthy ones."""
+    import os
+    cxx = os.path.join(os.path.dirname(native.LIB_PATH), "libgklhip_pairhmm_cxxfast.so")
+    assert os.path.exists(cxx), "make -C gkl_amd/csrc builds it"
+    rng = np.random.RandomState(808)
+    batches = [make_batch("hc", 400, 24, seed=9), make_batch("region", 300, 20, seed=10),
+               random_batch(rng, 60, 9, read_len=(1, 500), hap_len=(1, 700), alphabet=b"ACGTNacgtRY"),
+               random_batch(rng, 40, 6, read_len=(100, 511), hap_len=(400, 900), qual_range=(0, 255))]
+    bad = random_batch(rng, 24, 4, read_len=(150, 250), hap_len=(300, 500), qual_range=(20, 40))
+    lo, hi = int(bad.read_off[3]), int(bad.read_off[4])
+    bad.ins_gop[lo:hi] = 0
+    bad.del_gop[lo:hi] = 0
+    bad.gcp[lo:hi] = 60
+    with native.PairHmmContext(rows_per_lane=8) as a, native.PairHmmContext(rows_per_lane=8, lib_path=cxx) as c:
+        for b in batches:
+            check_against_oracle(a, oracle, b)
+            ra = [x.copy() for x in a.raw(b.n_pairs)]
+            c.compute(b)
+            rc = c.raw(b.n_pairs)
+            assert np.array_equal(bits(ra[0]), bits(rc[0])) and np.array_equal(ra[2], rc[2])
+        oa = a.compute(bad)
+        ra32 = a.raw(bad.n_pairs)[0].copy()
+        oc = c.compute(bad)
+        oo, o32, _, _ = oracle.batch(bad, want_raw=True, n_threads=8)
+        others = np.ones(bad.n_pairs, bool)
+        others[3 * bad.n_haps:4 * bad.n_haps] = False
+        assert np.array_equal(bits(ra32[others]), bits(o32[others])) and np.array_equal(bits(oa[others]), bits(oo[others]))
+        assert np.array_equal(bits(oa[others]), bits(oc[others]))
+
+
 def test_region_batch_no_fallback(ctx32, oracle):
     b = make_batch("region", 200, 16, seed=5)
     out, u = check_against_oracle(ctx32, oracle, b)

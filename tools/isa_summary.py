@@ -22,6 +22,8 @@ for line in txt.splitlines():
     if line.startswith("\t.end_amdhsa_kernel") or line.startswith(".Lfunc_end"):
         cur = None
     if cur and line.startswith("\t") and not line.startswith("\t.") and not line.startswith("\t;"):
+        if not line.split():
+            continue
         op = line.split()[0]
         kern[cur][op] += 1
 meta = {}
