@@ -112,6 +112,7 @@ struct DevCtx {
   int plan_slot = 0;
   // per-call device scratch
   DevBuf raw32, raw64, used64, counters, stream_buf, out_dev;
+  DevBuf lanes_main;  // the main pass's lane map, expanded by prep_kernel from the plan's compact read packing
   DevBuf read_fail, lanes2, jobs, jobs_long, fail_order, fail_hist, hap_flags;
   // host-API device copies of the batch, packed results (device + pinned), finalisation workers
   DevBuf batch_dev;
@@ -167,14 +168,16 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // appends its six input arrays (`batch`: 5 read arrays at `batch_stride`, then the haplotype bases), so that plan
 // and inputs travel in ONE copy.
 struct PlanLayout {
-  size_t lanes, groups, hap_len, hap_pos, hap_pos_flat, hap_orig, hap_sidx, hap_group, hap_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count,
+  size_t place_chunk, place_lane, chunk_used, groups, hap_len, hap_pos, hap_pos_flat, hap_orig, hap_sidx, hap_group, hap_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count,
       batch, batch_stride, stream, stream_flat, has_n, total;
 };
 PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lanes, size_t n_long_jobs, size_t inline_read_bytes,
                       size_t inline_hap_bytes) {
   PlanLayout l;
   size_t o = 0;
-  l.lanes = o; o = align_up(o + p.lanes.size() * sizeof(PlanLane));
+  l.place_chunk = o; o = align_up(o + (size_t)n_reads * 4);
+  l.place_lane = o; o = align_up(o + (size_t)n_reads);
+  l.chunk_used = o; o = align_up(o + (size_t)p.n_chunks);
   l.groups = o; o = align_up(o + p.groups.size() * sizeof(PlanGroup));
   l.hap_len = o; o = align_up(o + (size_t)n_haps * 4);
   l.hap_pos = o; o = align_up(o + (size_t)n_haps * 4);
@@ -226,6 +229,28 @@ int validate(const gklhip_batch* b) {
   return GKLHIP_OK;
 }
 
+// policy_plan_kernel synchronises its blocks with hand-rolled grid barriers, so all of them must be resident at once.
+// One launch is kPlanBlocks (64) blocks of 1024 threads and a CU holds one such block: four launches fit the chip's
+// 256 CUs side by side.  Engines are many (JNI slots, twin engines of big host calls, several contexts per process),
+// and five half-resident launches from five queues could wait for each other's CUs for ever -- so at most
+// kPlanInFlight launches per device are in flight at any time, process-wide: a launch first waits (on the host) for
+// the end of the launch kPlanInFlight earlier.  In steady state that one finished long ago and the wait is a query.
+// (Other processes on the same GPU are outside this gate: run one process per GPU, as bench.py and the JNI shim do.)
+constexpr int kPlanInFlight = 3;
+struct PlanGate {
+  std::mutex mu;
+  hipEvent_t done[kPlanInFlight] = {};
+  int next = 0;
+};
+PlanGate* plan_gate(int device) {
+  static std::mutex mu;
+  static std::vector<PlanGate*> gates;
+  std::lock_guard<std::mutex> l(mu);
+  if ((int)gates.size() <= device) gates.resize((size_t)device + 1, nullptr);
+  if (!gates[(size_t)device]) gates[(size_t)device] = new PlanGate();  // lives as long as the process: the events are few
+  return gates[(size_t)device];
+}
+
 template <typename T, int RPL>
 void launch_stream(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
   if (fma) hipLaunchKernelGGL((pairhmm_fwd_stream_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
@@ -243,8 +268,9 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
   else     hipLaunchKernelGGL((pairhmm_fwd_long_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a, carry, carry_len);
 }
 
-// Rows per lane.  fp32 main pass: 8 (4 for small batches).  fp64 passes: 6.  A read of length R needs R+1 rows; reads that exceed
-// 64*RPL rows go to the striped long-read kernel of the same RPL.
+// Rows per lane.  fp32 main pass: 8 (4 or 2 for small batches).  fp64: 10 in the streaming and job-list kernels, 6 (kRplF64) in the
+// one-pair-per-wavefront and striped long-read kernels.  A read of length R needs R+1 rows; reads that exceed 64*RPL rows go to the
+// striped long-read kernel.
 #ifndef GKL_RPL_F64
 #define GKL_RPL_F64 6
 #endif
@@ -357,7 +383,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   if ((rc = stage.reserve(L.total))) return rc;
   if ((rc = plan_dev.reserve(L.total))) return rc;
   unsigned char* hs = stage.as<unsigned char>();
-  memcpy(hs + L.lanes, plan.lanes.data(), plan.lanes.size() * sizeof(PlanLane));
+  memcpy(hs + L.place_chunk, plan.place_chunk.data(), (size_t)n_reads * 4);
+  memcpy(hs + L.place_lane, plan.place_lane.data(), (size_t)n_reads);
+  memcpy(hs + L.chunk_used, plan.chunk_used.data(), (size_t)plan.n_chunks);
   memcpy(hs + L.groups, plan.groups.data(), plan.groups.size() * sizeof(PlanGroup));
   memcpy(hs + L.hap_len, plan.hap_len.data(), (size_t)n_haps * 4);
   memcpy(hs + L.hap_pos, plan.hap_pos.data(), (size_t)n_haps * 4);
@@ -449,6 +477,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   const int n_hist = use_double ? 0 : 2 * (n_haps + 2);
   if (!use_double && (rc = c->fail_hist.reserve((size_t)n_hist * 4))) return rc;
   if ((rc = c->hap_flags.reserve((size_t)n_haps))) return rc;
+  if ((rc = c->lanes_main.reserve((size_t)std::max(plan.n_chunks, 1) * kLanes * sizeof(LaneSlot)))) return rc;
 
   const bool ev = c->cfg.record_events != 0;
   const bool deferred = c->cfg.record_events == 2;
@@ -484,7 +513,13 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     pa.clear_a = c->counters.as<int32_t>(); pa.n_a = 32;
     pa.clear_b = c->read_fail.as<int32_t>(); pa.n_b = use_double ? 0 : n_reads;
     pa.clear_c = c->fail_hist.as<int32_t>(); pa.n_c = n_hist;
-    const int threads_needed = std::max({pa.n_haps * 64, 32, pa.n_b, pa.n_c});
+    pa.place_chunk = reinterpret_cast<const int32_t*>(pb + L.place_chunk);
+    pa.place_lane = pb + L.place_lane;
+    pa.chunk_used = pb + L.chunk_used;
+    pa.read_off = reinterpret_cast<const int64_t*>(pb + L.read_off);
+    pa.lanes_out = c->lanes_main.as<LaneSlot>();
+    pa.n_reads = n_reads; pa.n_chunks = plan.n_chunks; pa.rpl = rpl_main;
+    const int threads_needed = std::max({pa.n_haps * 64, 32, pa.n_b, pa.n_c, n_reads});
     pa.hap_blocks = (threads_needed + kPrepBlock - 1) / kPrepBlock;
     pa.pull_src = reinterpret_cast<const uint4*>(hs_dev);
     pa.pull_dst = reinterpret_cast<uint4*>(dp);
@@ -509,7 +544,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     a.hap_has_n = hap_has_n;
     a.groups = reinterpret_cast<const HapGroup*>(dp + L.groups);
     a.n_groups = (int)plan.groups.size();
-    a.chunk_lanes = reinterpret_cast<const LaneSlot*>(dp + L.lanes);
+    a.chunk_lanes = c->lanes_main.as<LaneSlot>();
     a.n_chunks = plan.n_chunks;
     a.jobs = c->jobs.as<FwdJob>();
     a.job_count = c->counters.as<int32_t>() + 2;
@@ -644,12 +679,23 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       pa.long_chunk_jobs = c->fail_order.as<int32_t>() + n_reads;
       pa.total_cols = (int32_t)std::min<int64_t>((int64_t)hl + n_haps, 0x7fffffff);
       static const int wanted_env = [] { const char* v = getenv("GKLHIP_FB_WANTED_JOBS"); return v ? atoi(v) : 0; }();
-      pa.wanted_jobs = wanted_env > 0 ? wanted_env : kFallbackWantedJobs;
+      // (a shard of the batch wants fewer, longer jobs: 4096 for an eighth, measured on the 1250 x 128 shard)
+      pa.wanted_jobs = wanted_env > 0 ? wanted_env : (int)std::min<int64_t>(kFallbackWantedJobs, std::max<int64_t>(4096, n_pairs / 100));
       pa.min_job_cols = 256;
       // every block must be resident at once (grid barriers): far fewer than one per CU
       static const int blocks_env = [] { const char* v = getenv("GKLHIP_PLAN_BLOCKS"); return v ? atoi(v) : 0; }();
-      const int grid = std::max(1, std::min(c->n_cus, blocks_env > 0 ? blocks_env : kPlanBlocks));
+      // (fewer blocks for smaller calls: the barriers get cheaper and the policy phase has less to share out -- an eighth of
+      //  the batch runs the same with 16 blocks as with 64)
+      const int auto_blocks = (int)std::min<int64_t>(kPlanBlocks, std::max<int64_t>(16, n_pairs / 8192));
+      const int grid = std::max(1, std::min(c->n_cus, blocks_env > 0 ? blocks_env : auto_blocks));
+      PlanGate* gate = plan_gate(c->device);
+      std::lock_guard<std::mutex> gl(gate->mu);
+      hipEvent_t& slot_done = gate->done[gate->next];
+      if (slot_done) HIP_TRY(hipEventSynchronize(slot_done));
+      else HIP_TRY(hipEventCreateWithFlags(&slot_done, hipEventDisableTiming));
       hipLaunchKernelGGL(policy_plan_kernel, dim3((unsigned)grid), dim3(kPlanBlock), 0, s, pa);
+      HIP_TRY(hipEventRecord(slot_done, s));
+      gate->next = (gate->next + 1) % kPlanInFlight;
     }
     HIP_TRY(hipEventRecord(c->policy_done, s));
     const bool side_finalize = finalize_mode == GKLHIP_FINALIZE_DEVICE_F64 || finalize_mode == GKLHIP_FINALIZE_DEVICE_REF32;
@@ -720,7 +766,7 @@ void dev_done(DevCtx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->last_stream && c->have_last) (void)hipStreamSynchronize(c->last_stream);
   for (DevBuf* b : {&c->tab32, &c->tab64, &c->plan_dev_slot[0], &c->plan_dev_slot[1], &c->raw32, &c->raw64, &c->used64,
-                    &c->counters, &c->stream_buf, &c->out_dev, &c->batch_dev, &c->read_fail,
+                    &c->counters, &c->stream_buf, &c->out_dev, &c->batch_dev, &c->read_fail, &c->lanes_main,
                     &c->lanes2, &c->jobs, &c->jobs_long, &c->fail_order, &c->fail_hist, &c->carry, &c->hap_flags})
     b->release();
   c->stage_slot[0].release();
@@ -990,7 +1036,12 @@ struct gklhip_ctx {
   std::vector<std::unique_ptr<DevWorker>> workers;   // workers[d-1] drives shard d
   std::vector<int32_t> bounds;                       // read-range boundaries of the last call, [n_dev + 1]
   std::vector<std::vector<int64_t>> sub_off;         // per device: its read range's offsets rebased to 0
-  bool use_rccl = false;
+  // Gather of the device-resident path: 1 = peer copies, 2 = RCCL, 3 = peer copies after RCCL failed (why: rccl_note).
+  // The communicators are created by the FIRST multi-device gklhip_compute_device call (the host path never gathers,
+  // and every JNI slot is a context of its own: none of them should pay for, or fail on, communicators it never uses).
+  bool want_rccl = false, use_rccl = false, rccl_failed = false;
+  std::string rccl_note;
+  std::vector<int> rccl_devs;
   std::vector<ncclComm_t> comms;
   hipEvent_t inputs_ready = nullptr;                 // device 0: the caller's stream has reached this call
   std::vector<hipEvent_t> shard_done;                // [n_dev]: device d's results have landed on device 0
@@ -1099,8 +1150,44 @@ int multi_compute_host(gklhip_ctx* c, const std::vector<DevCtx*>& list, const gk
 // range and the haplotypes over xGMI (peer copies on its own stream), computes, and its results are gathered into
 // out_dev: RCCL send/recv in one group (distinct devices) or a peer copy.  Nothing synchronises with the host;
 // the caller's stream `s` ends up waiting for every shard.
+// GKL_HIP_RCCL_FAIL=init|group: pretend that RCCL fails there (tests of the fall-back to peer copies on one-GPU boxes).
+bool rccl_forced_failure(const char* where) {
+  const char* v = getenv("GKL_HIP_RCCL_FAIL");
+  return v && strcmp(v, where) == 0;
+}
+
+void rccl_give_up(gklhip_ctx* c, const std::string& why) {
+  c->use_rccl = false;
+  c->rccl_failed = true;
+  c->rccl_note = why;
+  static const bool quiet = getenv("GKL_HIP_QUIET") != nullptr;
+  if (!quiet) fprintf(stderr, "[gklhip] RCCL gather unavailable (%s): gathering with peer copies\n", why.c_str());
+}
+
+// First multi-device device-resident call of a context that wants RCCL: load the library, create the communicators.
+// Any failure (library missing, a device listed twice, ncclCommInitAll error) selects the peer-copy gather.
+void rccl_lazy_init(gklhip_ctx* c) {
+  if (!c->want_rccl || c->use_rccl || c->rccl_failed) return;
+  std::lock_guard<std::mutex> l(g_rccl_mu);
+  if (rccl_forced_failure("init")) return rccl_give_up(c, "forced by GKL_HIP_RCCL_FAIL=init");
+  if (!g_rccl.load()) return rccl_give_up(c, "librccl.so cannot be loaded");
+  const int n = (int)c->dev.size();
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++)
+      if (c->rccl_devs[(size_t)i] == c->rccl_devs[(size_t)j]) return rccl_give_up(c, "a device is listed twice (a communicator holds a device once)");
+  c->comms.assign((size_t)n, nullptr);
+  const ncclResult_t r = g_rccl.CommInitAll(c->comms.data(), n, c->rccl_devs.data());
+  if (r != ncclSuccess) {
+    c->comms.clear();
+    return rccl_give_up(c, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+  }
+  c->use_rccl = true;
+}
+
 int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int mode, hipStream_t s) {
   const int n = (int)c->dev.size();
+  rccl_lazy_init(c);
+  const bool use_rccl = c->use_rccl;
   c->bounds.assign((size_t)n + 1, 0);
   partition_reads(db->n_reads, db->read_off, n, c->bounds.data());
   DevCtx* root = c->dev[0];
@@ -1128,28 +1215,58 @@ int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev,
     lv.read_bases = dst; lv.read_quals = dst + stride; lv.ins_gop = dst + 2 * stride;
     lv.del_gop = dst + 3 * stride; lv.gcp = dst + 4 * stride; lv.hap_bases = dst + 5 * stride;
     if ((r = run_device(dc, &lv, dc->out_dev.as<double>(), mode, sd, false))) return r;
-    if (!c->use_rccl) {
+    if (!use_rccl) {
       HIP_TRY(hipMemcpyPeerAsync(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, root->device, dc->out_dev.p, dc->device,
                                  (size_t)v.n_reads * n_haps * 8, sd));
       HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], sd));
     }
     return GKLHIP_OK;
   });
-  if (rc == GKLHIP_OK && c->use_rccl) {
-    // the one exchange step: every extra device sends its slice, device 0 receives them, all in one group
-    NCCL_TRY(g_rccl.GroupStart());
-    for (int d = 1; d < n; d++) {
-      const size_t cnt = (size_t)(c->bounds[(size_t)d + 1] - c->bounds[(size_t)d]) * n_haps;
-      if (!cnt) continue;
-      NCCL_TRY(g_rccl.Send(c->dev[(size_t)d]->out_dev.p, cnt, ncclDouble, 0, c->comms[(size_t)d], c->dev[(size_t)d]->stream));
-      NCCL_TRY(g_rccl.Recv(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, cnt, ncclDouble, d, c->comms[0], s));
-    }
-    NCCL_TRY(g_rccl.GroupEnd());
-    for (int d = 1; d < n; d++)
-      if (c->bounds[(size_t)d + 1] > c->bounds[(size_t)d]) {
-        HIP_TRY(hipSetDevice(c->dev[(size_t)d]->device));
-        HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], c->dev[(size_t)d]->stream));
+  if (rc == GKLHIP_OK && use_rccl) {
+    // the one exchange step: every extra device sends its slice, device 0 receives them, all in one group.  Group
+    // submission is serialised process-wide (several contexts over the same devices must not interleave their
+    // groups), the group is always closed, and a failure at any point degrades THIS and all later calls of the
+    // context to peer copies -- the shards' results are still sitting in their devices' buffers.
+    std::string why;
+    {
+      std::lock_guard<std::mutex> gl(g_rccl_mu);
+      ncclResult_t bad = rccl_forced_failure("group") ? ncclInternalError : ncclSuccess;
+      const char* what = "forced by GKL_HIP_RCCL_FAIL=group";
+      if (bad == ncclSuccess) {
+        ncclResult_t r = g_rccl.GroupStart();
+        if (r != ncclSuccess) { bad = r; what = "ncclGroupStart"; }
+        else {
+          for (int d = 1; d < n && bad == ncclSuccess; d++) {
+            const size_t cnt = (size_t)(c->bounds[(size_t)d + 1] - c->bounds[(size_t)d]) * n_haps;
+            if (!cnt) continue;
+            r = g_rccl.Send(c->dev[(size_t)d]->out_dev.p, cnt, ncclDouble, 0, c->comms[(size_t)d], c->dev[(size_t)d]->stream);
+            if (r != ncclSuccess) { bad = r; what = "ncclSend"; break; }
+            r = g_rccl.Recv(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, cnt, ncclDouble, d, c->comms[0], s);
+            if (r != ncclSuccess) { bad = r; what = "ncclRecv"; }
+          }
+          r = g_rccl.GroupEnd();  // always: an open group would swallow every later RCCL call of this thread
+          if (r != ncclSuccess && bad == ncclSuccess) { bad = r; what = "ncclGroupEnd"; }
+        }
       }
+      if (bad != ncclSuccess) why = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(bad) : "error");
+    }
+    if (why.empty()) {
+      for (int d = 1; d < n; d++)
+        if (c->bounds[(size_t)d + 1] > c->bounds[(size_t)d]) {
+          HIP_TRY(hipSetDevice(c->dev[(size_t)d]->device));
+          HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], c->dev[(size_t)d]->stream));
+        }
+    } else {
+      rccl_give_up(c, why);
+      for (int d = 1; d < n; d++) {
+        const size_t cnt = (size_t)(c->bounds[(size_t)d + 1] - c->bounds[(size_t)d]) * n_haps;
+        if (!cnt) continue;
+        DevCtx* dc = c->dev[(size_t)d];
+        HIP_TRY(hipSetDevice(dc->device));
+        HIP_TRY(hipMemcpyPeerAsync(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, root->device, dc->out_dev.p, dc->device, cnt * 8, dc->stream));
+        HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], dc->stream));
+      }
+    }
   }
   HIP_TRY(hipSetDevice(root->device));
   if (rc == GKLHIP_OK)
@@ -1262,20 +1379,11 @@ int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_
     }
     // Gather over RCCL when the devices are distinct (a communicator cannot hold a device twice; the 0,0 list of
     // the one-GPU tests gathers with plain copies).  GKL_HIP_GATHER=peer|rccl overrides.
+    // Communicators are created by the first device-resident call (rccl_lazy_init); RCCL that cannot be had there --
+    // library missing, a device listed twice, ncclCommInitAll failing -- degrades to peer copies, never to an error.
     const char* g = getenv("GKL_HIP_GATHER");
-    const bool want_rccl = g ? strcmp(g, "rccl") == 0 : distinct;
-    if (want_rccl) {
-      if (!distinct) return fail(GKLHIP_ERR_INVALID_ARG, "GKL_HIP_GATHER=rccl needs distinct devices");
-      std::lock_guard<std::mutex> l(g_rccl_mu);
-      if (!g_rccl.load()) {
-        if (g) return fail(GKLHIP_ERR_HIP, "GKL_HIP_GATHER=rccl but librccl.so cannot be loaded: %s", dlerror());
-      } else {
-        c->comms.assign((size_t)n, nullptr);
-        std::vector<int> devs(list.begin(), list.end());
-        NCCL_TRY(g_rccl.CommInitAll(c->comms.data(), n, devs.data()));
-        c->use_rccl = true;
-      }
-    }
+    c->want_rccl = g ? strcmp(g, "rccl") == 0 : distinct;
+    c->rccl_devs.assign(list.begin(), list.end());
   }
   {
     const char* hs = getenv("GKL_HIP_HOST_SHARDS");
@@ -1306,7 +1414,18 @@ int gklhip_done(gklhip_ctx* c) {
 
 int gklhip_num_devices(gklhip_ctx* c) { return c ? (int)c->dev.size() : 0; }
 
-int gklhip_gather_backend(gklhip_ctx* c) { return !c || c->dev.size() < 2 ? 0 : c->use_rccl ? 2 : 1; }
+int gklhip_gather_backend(gklhip_ctx* c) {
+  if (!c || c->dev.size() < 2) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  // (before the first device-resident call: what that call will try)
+  return c->rccl_failed ? 3 : (c->use_rccl || c->want_rccl) ? 2 : 1;
+}
+
+const char* gklhip_gather_note(gklhip_ctx* c) {
+  if (!c) return "";
+  std::lock_guard<std::mutex> lock(c->mu);
+  return c->rccl_note.c_str();
+}
 
 int gklhip_partition_reads(int32_t n_reads, const int64_t* read_off, int32_t n_parts, int32_t* bounds_out) {
   if (n_reads < 0 || n_parts <= 0 || !read_off || !bounds_out) return fail(GKLHIP_ERR_INVALID_ARG, "bad arguments to gklhip_partition_reads");
@@ -1444,7 +1563,7 @@ int gklhip_plan_describe(int32_t n_reads, int32_t n_haps, const int64_t* read_of
   if (n_reads < 0 || n_haps < 0 || !read_off || !hap_off || (rows_per_lane != 4 && rows_per_lane != 8))
     return -fail(GKLHIP_ERR_INVALID_ARG, "bad arguments to gklhip_plan_describe");
   Plan p;
-  build_plan(n_reads, n_haps, read_off, hap_off, rows_per_lane, kTargetCols, &p);
+  build_plan(n_reads, n_haps, read_off, hap_off, rows_per_lane, kTargetCols, &p, /*want_lanes=*/true);
   if (n_groups_out) *n_groups_out = (int32_t)p.groups.size();
   if (n_long_out) *n_long_out = (int32_t)p.long_reads.size();
   if (lanes_out) {

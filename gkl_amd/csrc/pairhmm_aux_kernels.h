@@ -36,6 +36,12 @@ struct PrepArgs {
   // (the device copy is complete only when this kernel has finished).
   const uint4* pull_src; uint4* pull_dst; int32_t pull_n16;  // 16-byte words
   int32_t hap_blocks;  // blocks [0, hap_blocks) build the stream, the rest pull
+  // The read packing arrives in compact form (pairhmm_plan.h: chunk and first lane per read, lanes taken per chunk --
+  // 5 bytes per read instead of 8 bytes per lane, 50 KB instead of 1.5 MB for 10k reads) and is expanded here into the
+  // lane map the forward kernels read.
+  const int32_t* place_chunk; const uint8_t* place_lane; const uint8_t* chunk_used; const int64_t* read_off;
+  LaneSlot* lanes_out;
+  int32_t n_reads, n_chunks, rpl;
 };
 constexpr int kPrepBlock = 256;
 __global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
@@ -48,6 +54,18 @@ __global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
   if (i < a.n_a) a.clear_a[i] = 0;
   if (i < a.n_b) a.clear_b[i] = 0;
   if (i < a.n_c) a.clear_c[i] = 0;
+  if (i < a.n_reads) {
+    const int chunk = a.place_chunk[i];
+    if (chunk >= 0) {
+      const int nb = ((int)(a.read_off[i + 1] - a.read_off[i]) + a.rpl) / a.rpl;
+      LaneSlot* dst = a.lanes_out + (int64_t)chunk * kLanes + a.place_lane[i];
+      for (int b = 0; b < nb; b++) dst[b] = LaneSlot{i, b};
+    }
+  }
+  if (i < a.n_chunks) {
+    LaneSlot* dst = a.lanes_out + (int64_t)i * kLanes;
+    for (int l = a.chunk_used[i]; l < kLanes; l++) dst[l] = LaneSlot{-1, 0};
+  }
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * (kPrepBlock / 64) + (threadIdx.x >> 6);
   if (k >= a.n_haps) return;

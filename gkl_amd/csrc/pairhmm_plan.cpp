@@ -12,10 +12,16 @@ constexpr int kWantedJobs = 4096;
 }
 
 void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off,
-                int rows_per_lane, int target_cols, Plan* out) {
+                int rows_per_lane, int target_cols, Plan* out, bool want_lanes) {
   Plan& p = *out;
-  p = Plan();
+  // reset, keeping every vector's capacity (a fresh Plan per call cost more than the planning itself:
+  // 1.5 MB of lane map allocated, filled and freed per 10k-read batch)
   p.rows_per_lane = rows_per_lane;
+  p.n_chunks = 0;
+  p.n_stream = p.n_stream_flat = 0;
+  p.useful_rows = 0;
+  p.max_read_len = p.max_hap_len = 0;
+  p.groups.clear(); p.long_reads.clear(); p.lanes.clear(); p.chunk_used.clear();
 
   // ---- haplotype streams: caller order, cut into groups of ~target_cols columns ----
   p.hap_len.resize(n_haps);
@@ -45,10 +51,17 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
     // Small batches (one active region of GATK is a few hundred reads x a few dozen haplotypes): a job is one
     // (chunk, group) and the chip has 1024 SIMDs x 4 wavefront slots, so cut the stream finer -- down to one
     // haplotype per group -- until there are about that many jobs; the price is 63 fill/drain steps per job.
+    // (lanes needed by all reads that fit a chunk: total rows / rows per lane, + 1 pad row and < 1 lane of rounding each)
     int64_t blocks = 0;
-    for (int r = 0; r < n_reads; r++) {
-      const int nb = blocks_for((int)(read_off[r + 1] - read_off[r]), rows_per_lane);
-      if (nb <= kLanes) blocks += nb;
+    {
+      int shift = -1;
+      for (int b = 0; b < 8; b++) if ((1 << b) == rows_per_lane) shift = b;
+      const int long_from = kLanes * rows_per_lane;
+      for (int r = 0; r < n_reads; r++) {
+        const int R = (int)(read_off[r + 1] - read_off[r]);
+        p.max_read_len = std::max(p.max_read_len, R);
+        if (R < long_from) blocks += shift >= 0 ? (R + rows_per_lane) >> shift : blocks_for(R, rows_per_lane);
+      }
     }
     const int64_t chunks_est = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
     static const int wanted_env = [] { const char* v = getenv("GKLHIP_WANTED_JOBS"); return v ? atoi(v) : 0; }();
@@ -104,17 +117,106 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   p.n_stream_flat += kLanes;  // drain room behind the last haplotype
 
   // ---- read packing: best-fit decreasing into 64-lane chunks (one window = all reads) ----
-  for (int r = 0; r < n_reads; r++)
-    p.max_read_len = std::max(p.max_read_len, (int)(read_off[r + 1] - read_off[r]));
+  if (rows_per_lane <= 0)
+    for (int r = 0; r < n_reads; r++)
+      p.max_read_len = std::max(p.max_read_len, (int)(read_off[r + 1] - read_off[r]));
+  p.place_chunk.resize((size_t)n_reads);
+  p.place_lane.resize((size_t)n_reads);
   if (rows_per_lane <= 0 || n_reads == 0) return;
-  std::vector<int32_t> order;
-  order.reserve(n_reads);
-  for (int r = 0; r < n_reads; r++) {
-    if (blocks_for((int)(read_off[r + 1] - read_off[r]), rows_per_lane) <= kLanes) order.push_back(r);
-    else p.long_reads.push_back(r);
+  static thread_local std::vector<int32_t> order;
+  static thread_local PackScratch scratch;
+  order.clear();
+  const int long_from = kLanes * rows_per_lane;  // reads with this many bases or more need more than 64 lanes
+  if (p.max_read_len < long_from) {
+    order.resize((size_t)n_reads);
+    std::iota(order.begin(), order.end(), 0);
+  } else {
+    for (int r = 0; r < n_reads; r++) {
+      if ((int)(read_off[r + 1] - read_off[r]) < long_from) order.push_back(r);
+      else { p.long_reads.push_back(r); p.place_chunk[r] = -1; p.place_lane[r] = 0; }
+    }
   }
-  p.n_chunks = pack_reads_windowed(order.data(), (int)order.size(), read_off, rows_per_lane,
-                                   (int)std::max<size_t>(order.size(), 1), &p.lanes, &p.useful_rows);
+  p.n_chunks = pack_reads_place(order.data(), (int)order.size(), read_off, rows_per_lane,
+                                (int)std::max<size_t>(order.size(), 1), p.place_chunk.data(), p.place_lane.data(),
+                                &p.chunk_used, &p.useful_rows, &scratch);
+  if (want_lanes) expand_lanes(p, n_reads, read_off, &p.lanes);
+}
+
+void expand_lanes(const Plan& p, int n_reads, const int64_t* read_off, std::vector<PlanLane>* lanes) {
+  lanes->assign((size_t)p.n_chunks * kLanes, PlanLane{-1, 0});
+  for (int r = 0; r < n_reads; r++) {
+    if (p.place_chunk[r] < 0) continue;
+    const int nb = blocks_for((int)(read_off[r + 1] - read_off[r]), p.rows_per_lane);
+    PlanLane* dst = lanes->data() + (size_t)p.place_chunk[r] * kLanes + p.place_lane[r];
+    for (int b = 0; b < nb; b++) dst[b] = PlanLane{r, b};
+  }
+}
+
+int pack_reads_place(const int32_t* order_in, int n, const int64_t* read_off, int rows_per_lane, int window,
+                     int32_t* place_chunk, uint8_t* place_lane, std::vector<uint8_t>* chunk_used,
+                     int64_t* useful_rows, PackScratch* sc) {
+  // counting sort by lanes needed (descending), then best fit through one stack of open chunks per free size
+  const int rpl = rows_per_lane;
+  if (window < 1) window = 1;
+  int shift = -1;
+  for (int b = 0; b < 8; b++) if ((1 << b) == rpl) shift = b;
+  sc->need_of.resize((size_t)n);
+  int64_t rows = 0;
+  for (int i = 0; i < n; i++) {
+    const int32_t r = order_in[i];
+    const int R = (int)(read_off[r + 1] - read_off[r]);
+    sc->need_of[i] = (uint8_t)(shift >= 0 ? (R + rpl) >> shift : blocks_for(R, rpl));
+    rows += R;
+  }
+  if (useful_rows) *useful_rows += rows;
+  const int wcap = std::min(n, window);
+  sc->sorted.resize((size_t)wcap);
+  sc->sorted_need.resize((size_t)wcap);
+  const uint8_t* need_of = sc->need_of.data();
+  int chunks_total = 0;
+  for (int w0 = 0; w0 < n; w0 += window) {
+    const int cnt = std::min(window, n - w0);
+    int32_t bucket[kLanes + 2] = {0};
+    for (int i = 0; i < cnt; i++) bucket[need_of[w0 + i]]++;
+    int32_t start[kLanes + 2];
+    int acc = 0;
+    for (int c = kLanes; c >= 1; c--) { start[c] = acc; acc += bucket[c]; }
+    for (int i = 0; i < cnt; i++) {
+      const int at = start[need_of[w0 + i]]++;
+      sc->sorted[at] = order_in[w0 + i];
+      sc->sorted_need[at] = need_of[w0 + i];
+    }
+    int32_t head[kLanes + 1];
+    for (int c = 0; c <= kLanes; c++) head[c] = -1;
+    uint64_t open_sizes = 0;  // bit c-1: some open chunk has exactly c free lanes (c = 1..63; a fresh chunk has 64)
+    const size_t base = chunk_used->size();  // chunk numbers of this window start here
+    sc->next.clear();
+    for (int i = 0; i < cnt; i++) {
+      const int32_t r = sc->sorted[i];
+      const int nb = sc->sorted_need[i];
+      const uint64_t fits = nb <= 63 ? open_sizes >> (nb - 1) : 0;  // free sizes >= nb
+      int chunk, c;
+      if (!fits) {
+        chunk = (int)sc->next.size();
+        sc->next.push_back(-1);
+        chunk_used->push_back(0);
+        c = kLanes;
+      } else {
+        c = nb + __builtin_ctzll(fits);  // the smallest free size that fits
+        chunk = head[c];
+        head[c] = sc->next[chunk];
+        if (head[c] < 0) open_sizes &= ~(1ull << (c - 1));
+      }
+      uint8_t& used = (*chunk_used)[base + (size_t)chunk];
+      place_chunk[r] = (int32_t)(base + (size_t)chunk);
+      place_lane[r] = used;
+      used = (uint8_t)(used + nb);
+      const int left = c - nb;
+      if (left > 0) { sc->next[chunk] = head[left]; head[left] = chunk; open_sizes |= 1ull << (left - 1); }
+    }
+    chunks_total += (int)sc->next.size();
+  }
+  return chunks_total;
 }
 
 int pack_reads_windowed(const int32_t* order_in, int n, const int64_t* read_off, int rows_per_lane,

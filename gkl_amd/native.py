@@ -81,6 +81,8 @@ def load_library(path: Optional[str] = None):
     lib.gklhip_num_devices.restype = C.c_int
     lib.gklhip_gather_backend.argtypes = [C.c_void_p]
     lib.gklhip_gather_backend.restype = C.c_int
+    lib.gklhip_gather_note.argtypes = [C.c_void_p]
+    lib.gklhip_gather_note.restype = C.c_char_p
     lib.gklhip_partition_reads.argtypes = [C.c_int32, _i64p, C.c_int32, C.POINTER(C.c_int32)]
     lib.gklhip_partition_reads.restype = C.c_int
     lib.gklhip_rccl_selftest.argtypes = [C.c_int32]
@@ -234,7 +236,13 @@ class PairHmmContext:
 
     @property
     def gather_backend(self) -> str:
-        return ("none", "peer", "rccl")[self.lib.gklhip_gather_backend(self.handle)]
+        """none | peer | rccl (lazily created: before the first device-resident call, what it will try) |
+        peer-after-rccl-failure (gather_note says why)"""
+        return ("none", "peer", "rccl", "peer-after-rccl-failure")[self.lib.gklhip_gather_backend(self.handle)]
+
+    @property
+    def gather_note(self) -> str:
+        return (self.lib.gklhip_gather_note(self.handle) or b"").decode()
 
     def close(self):
         if getattr(self, "handle", None):

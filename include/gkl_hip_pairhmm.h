@@ -131,8 +131,13 @@ int gklhip_done(gklhip_ctx* ctx);
  * devices == NULL or n_devices <= 0: cfg->device alone. */
 int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_t n_devices, gklhip_ctx** out_ctx);
 int gklhip_num_devices(gklhip_ctx* ctx);
-/* 0 = single device (no gather), 1 = peer copies, 2 = RCCL. */
+/* 0 = single device (no gather), 1 = peer copies, 2 = RCCL (before the first device-resident call: what that call
+ * will try -- the communicators are created lazily), 3 = peer copies because RCCL failed (library missing, a device
+ * listed twice, ncclCommInitAll or a group call returning an error; gklhip_gather_note says which).  An RCCL failure
+ * never fails a call: the shards' results are gathered with peer copies instead, bit-identically.
+ * GKL_HIP_RCCL_FAIL=init|group forces such a failure (tests). */
 int gklhip_gather_backend(gklhip_ctx* ctx);
+const char* gklhip_gather_note(gklhip_ctx* ctx);
 /* The sharding rule: bounds_out[0] = 0 <= ... <= bounds_out[n_parts] = n_reads, contiguous read ranges whose summed
  * read lengths (= cells, every range meets every haplotype) are as equal as cut points between reads allow. */
 int gklhip_partition_reads(int32_t n_reads, const int64_t* read_off, int32_t n_parts, int32_t* bounds_out);

@@ -85,3 +85,15 @@ def test_smith_waterman_shapes(ctxs, rl, al, seed, strategy, params, related):
         alt = bytes(rng.choice(list(b"ACGT"), size=al).tolist())
     exp = sw_oracle.align(ref, alt, params, strategy)[1:]
     assert sw.align(ref, alt, params, strategy) == exp
+
+
+def test_sixty_second_slice_of_the_randomised_fuzz():
+    """tests/fuzz.py (every kernel variant, both arithmetics, one- and multi-shard contexts, PDHMM paired and cross,
+    Smith-Waterman) for 60 s of wall clock, seed fixed: any mismatch fails."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz.py"), "--seconds", "60", "--seed", "20250418"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

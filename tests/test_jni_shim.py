@@ -113,7 +113,7 @@ def test_jni_lifecycle_follows_the_reference(oracle):
 @pytest.mark.gpu
 def test_jni_golden_file(golden_cases):
     # dataFileTest (PairHmmUnitTest.java:171-234): 1 read x 1 hap per call, abs tol 1e-5
-    for c in golden_cases[::13]:
+    for c in golden_cases:
         b = FlatBatch.from_holders([ReadDataHolder(c["read"], c["q"], c["i"], c["d"], c["c"])],
                                    [HaplotypeDataHolder(c["hap"])])
         for use_double in (False, True):

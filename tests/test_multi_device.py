@@ -78,6 +78,59 @@ def test_two_shards_on_one_gpu_device_resident_path(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("where", ["init", "group", "twice"])
+def test_rccl_failure_falls_back_to_peer_copies_bit_exact(oracle, monkeypatch, where):
+    """RCCL that cannot be had -- communicator creation failing, a group call failing, a device listed twice --
+    must degrade to the peer-copy gather, say so, and change no bit (GKL_HIP_RCCL_FAIL forces the first two; the
+    third is real: ncclCommInitAll cannot hold device 0 twice, which is also all a one-GPU box can offer)."""
+    import torch
+    from gkl_amd import native
+    monkeypatch.setenv("GKL_HIP_GATHER", "rccl")
+    monkeypatch.setenv("GKL_HIP_QUIET", "1")
+    if where != "twice":
+        monkeypatch.setenv("GKL_HIP_RCCL_FAIL", where)
+    b = make_batch("hc", 600, 20, seed=34)
+    db = native.DeviceBatch.upload(b, "cuda:0")
+    with native.PairHmmContext(device=0) as one, native.PairHmmContext(devices=[0, 0, 0]) as three:
+        ref = one.compute_device(db)
+        torch.cuda.synchronize()
+        assert three.gather_backend == "rccl"   # what the first call will try
+        out = torch.full((b.n_pairs,), float("nan"), dtype=torch.float64, device="cuda:0")
+        for _ in range(2):
+            three.compute_device(db, out)
+        torch.cuda.synchronize()
+        assert three.gather_backend == "peer-after-rccl-failure" and three.gather_note
+        # the host path of the same context never gathers and is unaffected
+        host = three.compute(b)
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref.cpu().numpy()))
+    assert np.array_equal(bits(host), bits(oracle.batch(b, n_threads=8)))
+
+
+@pytest.mark.gpu
+def test_config4_batch_through_eight_shards_bit_exact(oracle):
+    """BASELINE config 4's sharding arithmetic at N = 8 on one GPU: the 1M-pair batch (8000 reads x 125 haplotypes)
+    through a device list of eight entries -- eight read ranges, eight engines, eight gathers -- must equal the
+    single-device result bit for bit (device-resident path) and the oracle on a sample (host path)."""
+    import torch
+    from gkl_amd import native
+    b = make_batch("hc", 8000, 125, seed=4)
+    db = native.DeviceBatch.upload(b, "cuda:0")
+    with native.PairHmmContext(device=0) as one, native.PairHmmContext(devices=[0] * 8) as eight:
+        ref = one.compute_device(db)
+        out = eight.compute_device(db)
+        torch.cuda.synchronize()
+        bounds = native.partition_reads(b.read_off, 8)
+        assert len(set(bounds)) == 9, "eight non-empty read ranges"
+        host = eight.compute(b)
+        host1 = one.compute(b)
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref.cpu().numpy()))
+    assert np.array_equal(bits(host), bits(host1))
+    for lo, hi in ((0, 40), (3990, 4030), (7960, 8000)):   # oracle on the first, a middle and the last read range
+        exp = oracle.batch(b.read_slice(lo, hi), n_threads=8)
+        assert np.array_equal(bits(host.reshape(b.n_reads, b.n_haps)[lo:hi].ravel()), bits(exp))
+
+
+@pytest.mark.gpu
 def test_jni_path_shards_over_the_device_list(oracle, monkeypatch):
     # computeLikelihoodsNative itself scales: GKL_HIP_DEVICES is read by initNative
     monkeypatch.setenv("GKL_HIP_DEVICES", "0,0")
