@@ -179,12 +179,12 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNat
       if (hb[h].empty() || hp[h].size() < hb[h].size()) { throw_java(env, kIAE, "empty haplotype or haplotypePDBases shorter than haplotypeBases"); return; }
       max_h = (int)std::max<size_t>(max_h, hb[h].size());
     }
-    // The reference expands the cross product into padded PAIRS, in batches bounded by maxMemoryInMB
-    // (JavaData.h:86-101,177-242), because computePDHMM takes pairs.  Here every read and every haplotype is
-    // staged once and the device walks the cross product itself; maxMemoryInMB then only has to cover
-    // reads + haplotypes + results, and the same "too small" error is raised when it does not.
-    const int64_t need = (int64_t)n_reads * max_r * 5 + (int64_t)n_haps * max_h * 2 + total * 8;
-    if (need > (int64_t)max_memory_mb * 1024 * 1024) {
+    // The reference expands the cross product into padded PAIRS, in batches of min(total, maxMemoryInMB /
+    // memoryPerPair) pairs (JavaData.h:83-101,177-242), because computePDHMM takes pairs; every batch ends in its own
+    // scalar tail.  Here every read and every haplotype is staged once and the device walks the cross product itself;
+    // the batch size is computed the reference's way only to put the tails where GKL puts them (and to raise its error).
+    const int64_t ref_batch = gklhip_pdhmm_reference_batch_pairs(max_memory_mb, max_r, max_h, total);
+    if (ref_batch <= 0) {
       throw_java(env, kIAE, "Batch size is too small. Please increase the memory limit for PDHMM by using the maxMemoryInMB argument.");
       return;
     }
@@ -207,7 +207,7 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNat
     std::vector<double> out((size_t)total);
     gklhip_pdhmm_cross x = {n_reads, n_haps, max_h, max_r, b_hb.data(), b_hp.data(), b_rb.data(), b_rq.data(),
                             b_ri.data(), b_rd.data(), b_rc.data(), hl.data(), rl.data()};
-    const int st = gklhip_pdhmm_compute_cross(ctx, &x, out.data());
+    const int st = gklhip_pdhmm_compute_cross_batched(ctx, &x, ref_batch, out.data());
     if (st != GKLHIP_OK) { throw_status(env, st); return; }
     gkljni::SetDoubleArrayRegion(env, likelihoodArray, 0, (jsize)total, out.data());
   } catch (const std::bad_alloc&) {

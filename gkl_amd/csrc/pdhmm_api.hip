@@ -2,6 +2,7 @@
 // fp64 flush-to-zero flag of the PairHMM translation unit: the reference's PDHMM never touches
 // MXCSR (no _MM_SET_FLUSH_ZERO_MODE anywhere under src/main/native/pdhmm).
 #include <hip/hip_runtime.h>
+#include <sys/sysinfo.h>
 
 #include <algorithm>
 #include <cmath>
@@ -104,7 +105,7 @@ struct gklhip_pdhmm_ctx {
   Buf tables, inputs, entries, sums, misc, carry, jobs;
   float last_ms = 0.f;
   int fma_mode = 1;  // 1 = arithmetic of GKL's AVX-512 object (default), 0 = of its AVX2 object
-  int tail_mode = 0; // 1 = the last `batch mod SIMD width` pairs of a paired batch take the scalar engine's arithmetic, like the reference
+  int tail_mode = 1; // 1 (default) = the last `batch mod SIMD width` pairs of every reference batch take the scalar engine's arithmetic, like GKL; 0 = vector arithmetic everywhere
 };
 
 extern "C" {
@@ -148,7 +149,7 @@ int gklhip_pdhmm_init(int device, gklhip_pdhmm_ctx** out_ctx) {
     return bail(pd_fail(GKLHIP_ERR_HIP, "table upload failed"));
   {
     const char* tm = getenv("GKL_HIP_PDHMM_TAIL");
-    c->tail_mode = (tm && strcmp(tm, "reference") == 0) ? 1 : 0;
+    c->tail_mode = (tm && (strcmp(tm, "vector") == 0 || strcmp(tm, "0") == 0)) ? 0 : 1;  // "reference" (default) | "vector"
   }
   *out_ctx = c;
   return GKLHIP_OK;
@@ -192,6 +193,9 @@ struct PdProblem {
   int32_t n_read_items, n_hap_items, cross_haps, max_hap_len, max_read_len;
   const int8_t *hap_bases, *hap_pdbases, *read_bases, *read_qual, *read_ins_qual, *read_del_qual, *gcp;
   const int64_t *hap_lengths, *read_lengths;
+  // cross layout, reference-tail mode: the reference cuts the read-major pair list into batches of this many pairs
+  // (JavaData.h:83-101) and each batch has its own scalar tail; 0 = the whole cross product is one batch
+  int64_t ref_batch_pairs;
 };
 
 int pd_validate(const PdProblem& q, const double* out_host) {
@@ -293,6 +297,27 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     std::stable_sort(hap_order.begin(), hap_order.end(),
                      [&](int32_t x, int32_t y) { return q.hap_lengths[x] > q.hap_lengths[y]; });
     lanes.resize(job_pair.size() * kLanes, PlanLane{-1, 0});  // striped jobs do not use their lane rows
+    // "Reference tail" of the cross product: computeLikelihoods expands it into read-major pairs, batch by batch
+    // (JavaData.h:177-242), and computePDHMM finishes the last `batch mod SIMD width` pairs of EVERY batch with the
+    // scalar engine (pdhmm.h:1264-1268).  The main launch computes all pairs with the vector arithmetic; the pairs at
+    // those positions are then recomputed by the scalar-arithmetic instantiation and overwrite their sums.
+    if (c->tail_mode == 1) {
+      const size_t width = c->fma_mode ? 8 : 4;
+      const size_t per = q.ref_batch_pairs > 0 ? (size_t)std::min<int64_t>(q.ref_batch_pairs, (int64_t)n) : n;
+      for (size_t start = 0; start < n; start += per) {
+        const size_t nb_pairs = std::min(per, n - start);
+        for (size_t i = start + nb_pairs / width * width; i < start + nb_pairs; i++) {
+          const int nb = blocks_for(read_len_of(i), kPdRpl);
+          tail_pair.push_back((int32_t)i);
+          tail_striped.push_back(nb > kLanes ? 1 : 0);
+          tail_steps.push_back(hap_len_of(i) + std::min(nb, kLanes) - 1);
+          tail_lanes.resize(tail_lanes.size() + kLanes, PlanLane{-1, 0});
+          if (nb <= kLanes)
+            for (int b = 0; b < nb; b++) tail_lanes[tail_lanes.size() - kLanes + (size_t)b] = PlanLane{(int32_t)i, b};
+        }
+      }
+      n_tail = tail_pair.size();
+    }
   } else {
     // "Reference tail": GKL finishes the last `batch mod SIMD width` pairs of every vector batch with its SCALAR
     // engine (pdhmm.h:1264-1270; 8 doubles per AVX-512 vector, 4 per AVX2 vector), whose arithmetic differs in the
@@ -430,7 +455,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     at.n_jobs = (int32_t)n_tail;
     at.n_cross_jobs = 0;
     at.next = c->misc.as<int32_t>() + 2;
-    hipLaunchKernelGGL((pdhmm_fwd_kernel<false, true>), dim3((unsigned)n_tail), dim3(64), 0, s, at, t.initial_condition);
+    hipLaunchKernelGGL((pdhmm_fwd_kernel<false, true>), dim3((unsigned)std::min<size_t>(n_tail, (size_t)n_blocks)), dim3(64), 0, s, at, t.initial_condition);  // persistent: one carry slab per block
   }
   PD_HIP_TRY(hipEventRecord(c->ev1, s));
   PD_HIP_TRY(hipGetLastError());
@@ -453,18 +478,33 @@ int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_batch* b, doubl
   // IntelPDHMM.java:163-173
   if (b->batch <= 0) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batchSize must be greater than 0");
   PdProblem q{b->batch, b->batch, b->batch, 0, b->max_hap_len, b->max_read_len, b->hap_bases, b->hap_pdbases,
-              b->read_bases, b->read_qual, b->read_ins_qual, b->read_del_qual, b->gcp, b->hap_lengths, b->read_lengths};
+              b->read_bases, b->read_qual, b->read_ins_qual, b->read_del_qual, b->gcp, b->hap_lengths, b->read_lengths, 0};
   const int rc = pd_validate(q, out_host);
   return rc ? rc : pd_run(c, q, out_host);
 }
 
 int gklhip_pdhmm_compute_cross(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_cross* x, double* out_host) {
+  return gklhip_pdhmm_compute_cross_batched(c, x, 0, out_host);
+}
+
+int64_t gklhip_pdhmm_reference_batch_pairs(int32_t max_memory_mb, int32_t max_read_len, int32_t max_hap_len, int64_t total_pairs) {
+  // JavaData.h:86-101 + pdhmm-implementation.h:204-235 (the limit is also capped by the free RAM of the host)
+  if (max_memory_mb <= 0 || max_read_len <= 0 || max_hap_len <= 0 || total_pairs <= 0) return 0;
+  int64_t mb = max_memory_mb;
+  struct sysinfo info;
+  if (sysinfo(&info) == 0) mb = std::min<int64_t>(mb, (int64_t)(info.freeram / (1024 * 1024)));
+  const int64_t per_pair = ((int64_t)max_read_len * 5 + (int64_t)max_hap_len * 2) + 8 + 16;
+  return std::min(total_pairs, mb * 1024 * 1024 / per_pair);
+}
+
+int gklhip_pdhmm_compute_cross_batched(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_cross* x, int64_t ref_batch_pairs, double* out_host) {
   if (!c) return pd_fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
+  if (ref_batch_pairs < 0) return pd_fail(GKLHIP_ERR_INVALID_ARG, "ref_batch_pairs must not be negative");
   if (!x) return pd_fail(GKLHIP_ERR_INVALID_ARG, "batch is NULL");
   if (x->n_reads <= 0 || x->n_haps <= 0) return pd_fail(GKLHIP_ERR_INVALID_ARG, "no pairs to process");
   PdProblem q{(int64_t)x->n_reads * x->n_haps, x->n_reads, x->n_haps, x->n_haps, x->max_hap_len, x->max_read_len,
               x->hap_bases, x->hap_pdbases, x->read_bases, x->read_qual, x->read_ins_qual, x->read_del_qual, x->gcp,
-              x->hap_lengths, x->read_lengths};
+              x->hap_lengths, x->read_lengths, ref_batch_pairs};
   const int rc = pd_validate(q, out_host);
   return rc ? rc : pd_run(c, q, out_host);
 }

@@ -363,6 +363,10 @@ def load_pdhmm_library(path: Optional[str] = None):
     lib.gklhip_pdhmm_compute.restype = C.c_int
     lib.gklhip_pdhmm_compute_cross.argtypes = [C.c_void_p, C.POINTER(CPdhmmCross), C.c_void_p]
     lib.gklhip_pdhmm_compute_cross.restype = C.c_int
+    lib.gklhip_pdhmm_compute_cross_batched.argtypes = [C.c_void_p, C.POINTER(CPdhmmCross), C.c_int64, C.c_void_p]
+    lib.gklhip_pdhmm_compute_cross_batched.restype = C.c_int
+    lib.gklhip_pdhmm_reference_batch_pairs.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
+    lib.gklhip_pdhmm_reference_batch_pairs.restype = C.c_int64
     lib.gklhip_pdhmm_done.argtypes = [C.c_void_p]
     lib.gklhip_pdhmm_done.restype = C.c_int
     lib.gklhip_pdhmm_last_kernel_ms.argtypes = [C.c_void_p]
@@ -383,12 +387,18 @@ def pdhmm_host_table(which: int) -> np.ndarray:
     return a
 
 
+def pdhmm_reference_batch_pairs(max_memory_mb: int, max_read_len: int, max_hap_len: int, total_pairs: int) -> int:
+    """Pairs per batch of the reference's computeLikelihoodsNative (pdhmm/JavaData.h:83-101)."""
+    return int(load_pdhmm_library().gklhip_pdhmm_reference_batch_pairs(max_memory_mb, max_read_len, max_hap_len, total_pairs))
+
+
 class PdhmmContext:
     """One gklhip_pdhmm context (= IntelPDHMM.initNative)."""
 
-    def __init__(self, device: int = -1, fma_mode: int = 1, reference_tail: bool = False):
+    def __init__(self, device: int = -1, fma_mode: int = 1, reference_tail: Optional[bool] = None):
         """fma_mode 1: bit-identical to GKL's AVX-512 PDHMM object, 0: to its AVX2 object.  reference_tail: the last
-        `batch mod SIMD width` pairs of a paired batch take the scalar engine's arithmetic, as in the reference."""
+        `batch mod SIMD width` pairs of every reference batch take the scalar engine's arithmetic, as in GKL -- None:
+        the library's setting (default: on; GKL_HIP_PDHMM_TAIL=vector turns it off), True / False: set it."""
         self.lib = load_pdhmm_library()
         h = C.c_void_p()
         st = self.lib.gklhip_pdhmm_init(device, C.byref(h))
@@ -398,9 +408,10 @@ class PdhmmContext:
         st = self.lib.gklhip_pdhmm_set_fma_mode(self.handle, int(fma_mode))
         if st != OK:
             self._raise(st)
-        st = self.lib.gklhip_pdhmm_set_tail_mode(self.handle, 1 if reference_tail else 0)
-        if st != OK:
-            self._raise(st)
+        if reference_tail is not None:
+            st = self.lib.gklhip_pdhmm_set_tail_mode(self.handle, 1 if reference_tail else 0)
+            if st != OK:
+                self._raise(st)
 
     def _raise(self, status):
         msg = (self.lib.gklhip_pdhmm_last_error() or b"").decode()
@@ -423,8 +434,10 @@ class PdhmmContext:
             self._raise(st)
         return out
 
-    def compute_cross(self, reads, haps) -> np.ndarray:
+    def compute_cross(self, reads, haps, ref_batch_pairs: int = 0) -> np.ndarray:
         """Every read against every haplotype (IntelPDHMM.computeLikelihoods), out[r * n_haps + h].
+        ref_batch_pairs: in reference-tail mode, the size of the batches the reference cuts the pair list into
+        (reference_batch_pairs()); 0 = one batch.
         reads: PdhmmBatch-like with the five read arrays [n][max_read_len] + read_lengths (its haplotype side is
         ignored); haps: PdhmmBatch-like with hap_bases / hap_pdbases [n][max_hap_len] + hap_lengths."""
         keep = [np.ascontiguousarray(a, np.int8) for a in (haps.hap_bases, haps.hap_pdbases, reads.read_bases,
@@ -435,7 +448,7 @@ class PdhmmContext:
         cb = CPdhmmCross(reads.batch, haps.batch, haps.max_hap_len, reads.max_read_len, *[a.ctypes.data for a in keep],
                          hl.ctypes.data, rl.ctypes.data)
         out = np.empty(max(reads.batch * haps.batch, 0), np.float64)
-        st = self.lib.gklhip_pdhmm_compute_cross(self.handle, C.byref(cb), out.ctypes.data)
+        st = self.lib.gklhip_pdhmm_compute_cross_batched(self.handle, C.byref(cb), C.c_int64(ref_batch_pairs), out.ctypes.data)
         if st != OK:
             self._raise(st)
         return out

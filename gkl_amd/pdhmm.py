@@ -81,7 +81,11 @@ class IntelPDHMM:
                                             r.overallGCP) for r in readDataArray])
             haps = PdhmmBatch.from_pairs([(h.haplotypeBases, h.haplotypePDBases, one, one, one, one, one)
                                           for h in haplotypeDataArray])
-            likelihoodArray[:] = self._ctx.compute_cross(reads, haps)  # read-major (JavaData.h:190)
+            ref_batch = native.pdhmm_reference_batch_pairs(self._max_memory_mb, reads.max_read_len, haps.max_hap_len,
+                                                           reads.batch * haps.batch)   # JavaData.h:86-101
+            if ref_batch <= 0:
+                raise IllegalArgumentException("Batch size is too small.")
+            likelihoodArray[:] = self._ctx.compute_cross(reads, haps, ref_batch)  # read-major (JavaData.h:190)
         except OutOfMemoryError:
             raise OutOfMemoryError("Memory allocation failed")
         except IllegalArgumentException:

@@ -9,8 +9,8 @@
  *                         (pdhmm.h:1133-1290), on the padded 1:1 batch IntelPDHMM.computePDHMM passes
  *                         (src/main/java/com/intel/gkl/pdhmm/IntelPDHMM.java:147-186)
  *   gklhip_pdhmm_done     doneNative
- * Arithmetic: the reference's vector kernels for every pair -- by default as its AVX-512 object computes
- * (gcc-contracted FMAs), optionally as its AVX2 object does; see gkl_amd/csrc/pdhmm_kernel.h.
+ * Arithmetic: GKL's, position by position -- its vector kernels (by default as its AVX-512 object computes, gcc-contracted
+ * FMAs; optionally as its AVX2 object does) and its scalar engine for the tail of every batch; see gkl_amd/csrc/pdhmm_kernel.h.
  */
 #ifndef GKL_HIP_PDHMM_H
 #define GKL_HIP_PDHMM_H
@@ -66,17 +66,25 @@ int gklhip_pdhmm_init(int device /* -1 = current */, gklhip_pdhmm_ctx** out_ctx)
 int gklhip_pdhmm_set_fma_mode(gklhip_pdhmm_ctx* ctx, int fma_mode);
 /* GKL finishes the last `batch mod SIMD width` pairs of every vector batch with its scalar engine (pdhmm.h:1264-1270 ->
  * pdhmm-serial.cc:279-412), whose arithmetic differs from its vector kernels': a pair's value depends on its position
- * in the batch.  mode 0 (default): the vector arithmetic for every pair.  mode 1 ("reference"; also
- * GKL_HIP_PDHMM_TAIL=reference in the environment at init): gklhip_pdhmm_compute gives the pairs at positions
- * >= batch - batch mod W (W = 8 with fma_mode 1 = the AVX-512 engine, 4 with fma_mode 0 = AVX2) the scalar engine's
- * arithmetic, so that EVERY position matches GKL bit for bit.  (The cross entry point is not affected: the positions
- * at which the reference's computeLikelihoods cuts its cross product into batches depend on maxMemoryInMB.) */
+ * in the batch.  mode 1 ("reference", the DEFAULT; GKL_HIP_PDHMM_TAIL=reference): the pairs at positions
+ * >= batch - batch mod W (W = 8 with fma_mode 1 = the AVX-512 engine, 4 with fma_mode 0 = AVX2) of a paired batch -- and
+ * of every reference batch of a cross product, see gklhip_pdhmm_compute_cross_batched -- take the scalar engine's
+ * arithmetic, so that EVERY position matches GKL bit for bit.  mode 0 ("vector"; GKL_HIP_PDHMM_TAIL=vector in the
+ * environment at init): the vector arithmetic for every pair -- position-independent results. */
 int gklhip_pdhmm_set_tail_mode(gklhip_pdhmm_ctx* ctx, int mode);
 /* Host buffers in, out_host[batch] = log10 likelihoods. Negative ins/del/gcp quals ->
  * GKLHIP_ERR_INVALID_ARG (PDHMM_INPUT_DATA_ERROR in the reference). */
 int gklhip_pdhmm_compute(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_batch* batch, double* out_host);
-/* out_host[n_reads * n_haps], read-major. Same arithmetic, errors and tables as gklhip_pdhmm_compute. */
+/* out_host[n_reads * n_haps], read-major. Same arithmetic, errors and tables as gklhip_pdhmm_compute; in tail mode 1 the
+ * whole cross product counts as ONE reference batch (= gklhip_pdhmm_compute_cross_batched with ref_batch_pairs 0). */
 int gklhip_pdhmm_compute_cross(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_cross* batch, double* out_host);
+/* The reference's computeLikelihoodsNative cuts the read-major pair list into batches of
+ * min(total, maxMemoryInMB / memoryPerPair) pairs (pdhmm/JavaData.h:83-101) and every batch ends in its own scalar tail.
+ * ref_batch_pairs replays that cut in tail mode 1 (0: one batch); gklhip_pdhmm_reference_batch_pairs computes the
+ * reference's number from maxMemoryInMB (capped by the host's free RAM, pdhmm-implementation.h:204-235) and the two
+ * maximum lengths.  What the JNI shim's computeLikelihoodsNative calls. */
+int gklhip_pdhmm_compute_cross_batched(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_cross* batch, int64_t ref_batch_pairs, double* out_host);
+int64_t gklhip_pdhmm_reference_batch_pairs(int32_t max_memory_mb, int32_t max_read_len, int32_t max_hap_len, int64_t total_pairs);
 /* HIP-event time of the forward kernel of the last call, milliseconds. */
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* ctx);
 int gklhip_pdhmm_done(gklhip_pdhmm_ctx* ctx);

@@ -44,6 +44,24 @@ class PdhmmOracle:
                                            C.c_int32(b.max_read_len), C.c_int32(b.max_hap_len), int(semantics), int(threads))
         return st, res
 
+    def compute_reference(self, b, fma_mode=1, ref_batch=0, threads=8):
+        """What GKL returns for every POSITION of a paired batch of pairs (pdhmm.h:1133-1290): the vector arithmetic of
+        the engine (semantics 2 = AVX-512 object, fma_mode 1; 0 = AVX2 object) for the full groups of SIMD width, the
+        scalar engine's (semantics 1) for the last `batch mod width` pairs -- per reference batch of `ref_batch` pairs
+        when the pairs are the expansion of a cross product (pdhmm/JavaData.h:83-101,177-242); 0 = one batch."""
+        width, sem = (8, 2) if fma_mode else (4, 0)
+        st, out = self.compute(b, semantics=sem, threads=threads)
+        per = min(ref_batch, b.batch) if ref_batch > 0 else b.batch
+        tail = []
+        for start in range(0, b.batch, max(per, 1)):
+            nb = min(per, b.batch - start)
+            tail += list(range(start + nb // width * width, start + nb))
+        if tail:
+            st1, ser = self.compute(b.subset(tail), semantics=1, threads=threads)   # (the scalar engine's input checks apply to the tail only)
+            out[tail] = ser
+            st = max(st, st1)
+        return st, out
+
     def table(self, which):
         n = self.lib.pdhmm_oracle_table(which, None, C.c_long(0))
         a = np.empty(n, np.float64)

@@ -48,7 +48,7 @@ def main():
             ctxs[k] = native.PairHmmContext(use_double=use_double, fma_mode=fma, rows_per_lane=rpl, devices=devices)
         return ctxs[k]
 
-    pd_ctx = {m: native.PdhmmContext(fma_mode=m) for m in (1, 0)}
+    pd_ctx = {m: native.PdhmmContext(fma_mode=m, reference_tail=False) for m in (1, 0)}
     sw = native.SwContext()
     alphabets = [b"ACGT", b"ACGTN", b"ACGTNacgtXRY*", b"AC", b"N", bytes(range(1, 256))]
     t_end = time.time() + a.seconds

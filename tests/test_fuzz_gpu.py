@@ -19,7 +19,7 @@ def ctxs():
     from oracle.oracle import Oracle
     from oracle.pdhmm import PdhmmOracle
     from oracle.sw import SwOracle
-    with native.PairHmmContext() as ph, native.PdhmmContext() as pd, native.SwContext() as sw:
+    with native.PairHmmContext() as ph, native.PdhmmContext(reference_tail=False) as pd, native.SwContext() as sw:
         yield ph, pd, sw, Oracle(), PdhmmOracle(), SwOracle()
 
 

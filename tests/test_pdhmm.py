@@ -9,7 +9,7 @@ import pytest
 from gkl_amd.pdhmm_batch import PdhmmBatch
 from tests.golden_io import load_pdhmm_file, load_pdhmm_holders_file
 
-FILES = ["pdhmm_syn_990_1_2.txt", "pdhmm_syn_199_68_51.txt", "pdhmm_syn_1412_129_223.head300.txt"]
+FILES = ["pdhmm_syn_990_1_2.txt", "pdhmm_syn_199_68_51.txt", "pdhmm_syn_1412_129_223.txt.gz"]
 TOL = 1e-4
 
 
@@ -184,7 +184,8 @@ SEMANTICS_OF_FMA_MODE = {1: 2, 0: 0}  # fma_mode of the HIP path -> oracle seman
 @pytest.fixture(scope="module", params=[1, 0], ids=["avx512-arith", "avx2-arith"])
 def pd_ctx(request):
     from gkl_amd import native
-    with native.PdhmmContext(fma_mode=request.param) as c:
+    # the position-independent mode (vector arithmetic for every pair; the default is GKL's position-dependent one)
+    with native.PdhmmContext(fma_mode=request.param, reference_tail=False) as c:
         c.sem = SEMANTICS_OF_FMA_MODE[request.param]
         yield c
 
@@ -197,6 +198,20 @@ def test_pdhmm_gpu_fixture_files(pd_ctx, pd_oracle, fname):
     assert np.max(np.abs(out - exp)) <= TOL                      # the reference's own bar
     _, vec = pd_oracle.compute(b, semantics=pd_ctx.sem)
     assert out.tobytes() == vec.tobytes()                         # and bit-exact vs GKL's AVX-512 / AVX2 arithmetic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", FILES)
+def test_pdhmm_gpu_fixture_files_default_mode_is_gkl_at_every_position(pd_oracle, fname):
+    # the library's default: the AVX-512 object's arithmetic with the scalar engine's tail, i.e. what GKL's
+    # computePDHMMNative returns position by position (all 1412 vectors of the big file included)
+    from gkl_amd import native
+    b, exp = load_pdhmm_file(fname)
+    with native.PdhmmContext() as c:
+        out = c.compute(b)
+    st, ref = pd_oracle.compute_reference(b, fma_mode=1)
+    assert st == 0 and out.tobytes() == ref.tobytes()
+    assert np.max(np.abs(out - exp)) <= TOL
 
 
 @pytest.mark.gpu
@@ -222,7 +237,7 @@ def test_pdhmm_gpu_reference_tail_mode_matches_gkl_at_every_position(pd_oracle, 
     from gkl_amd import native
     from tests.golden_io import load_pdhmm_tail_vectors
     width = 8 if fma_mode else 4
-    with native.PdhmmContext(fma_mode=fma_mode, reference_tail=True) as c:
+    with native.PdhmmContext(fma_mode=fma_mode) as c:         # the default mode
         for b, e512, e2 in load_pdhmm_tail_vectors():        # generated by the reference's own objects
             exp = e512 if fma_mode else e2
             assert c.compute(b).tobytes() == exp.tobytes()
@@ -243,10 +258,44 @@ def test_pdhmm_gpu_reference_tail_mode_matches_gkl_at_every_position(pd_oracle, 
         moved = bad.subset([8, 0, 1, 2, 3, 4, 5, 6, 7])      # the same pair at a vectorised position: fine
         st, exp = expected_per_position(pd_oracle, moved, SEMANTICS_OF_FMA_MODE[fma_mode], width)
         assert st == 0 and c.compute(moved).tobytes() == exp.tobytes()
-    # default mode: the vector arithmetic everywhere
-    with native.PdhmmContext(fma_mode=fma_mode) as c:
+    # opt-in: the vector arithmetic everywhere (position-independent results)
+    with native.PdhmmContext(fma_mode=fma_mode, reference_tail=False) as c:
         b = random_pd_batch(np.random.RandomState(92), 13, with_n=False)
         assert c.compute(b).tobytes() == pd_oracle.compute(b, semantics=SEMANTICS_OF_FMA_MODE[fma_mode])[1].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fma_mode", [1, 0])
+def test_pdhmm_gpu_cross_product_replays_the_reference_batches(pd_oracle, fma_mode, monkeypatch):
+    """computeLikelihoodsNative in the reference expands reads x haplotypes into read-major pairs, in batches of
+    min(total, maxMemoryInMB / memoryPerPair) pairs, and every batch ends in its own scalar tail (JavaData.h:83-101,
+    177-242; pdhmm.h:1264-1268).  The default mode of the cross entry point puts the tails where GKL puts them."""
+    from gkl_amd import native
+    rng = np.random.RandomState(17)
+    reads = random_pd_batch(rng, 37, with_n=False, read_len=(20, 120), hap_len=(1, 2))
+    haps = random_pd_batch(rng, 7, with_n=False, read_len=(1, 2), hap_len=(60, 200), flag_rate=0.1)
+    pairs = []
+    for r in range(reads.batch):
+        R = int(reads.read_lengths[r])
+        rr = lambda a: a.reshape(reads.batch, reads.max_read_len)[r, :R]  # noqa: E731
+        for h in range(haps.batch):
+            H = int(haps.hap_lengths[h])
+            hh = lambda a: a.reshape(haps.batch, haps.max_hap_len)[h, :H]  # noqa: E731
+            pairs.append((hh(haps.hap_bases), hh(haps.hap_pdbases), rr(reads.read_bases), rr(reads.read_qual),
+                          rr(reads.read_ins_qual), rr(reads.read_del_qual), rr(reads.gcp)))
+    expanded = PdhmmBatch.from_pairs(pairs)
+    total = reads.batch * haps.batch   # 259 = 32 * 8 + 3
+    with native.PdhmmContext(fma_mode=fma_mode) as c:
+        for ref_batch in (0, total, 100, 13, 8, 5):
+            st, exp = pd_oracle.compute_reference(expanded, fma_mode=fma_mode, ref_batch=ref_batch)
+            assert st == 0 and c.compute_cross(reads, haps, ref_batch).tobytes() == exp.tobytes(), ref_batch
+        # the same pairs through the paired entry point: one batch, one tail
+        st, exp = pd_oracle.compute_reference(expanded, fma_mode=fma_mode)
+        assert c.compute(expanded).tobytes() == exp.tobytes()
+    # the batch size the JNI shim derives from maxMemoryInMB is the reference's formula
+    per_pair = reads.max_read_len * 5 + haps.max_hap_len * 2 + 8 + 16
+    assert native.pdhmm_reference_batch_pairs(1, reads.max_read_len, haps.max_hap_len, 10**9) == 1024 * 1024 // per_pair
+    assert native.pdhmm_reference_batch_pairs(512, reads.max_read_len, haps.max_hap_len, total) == total
 
 
 def cross_product(rng, n_reads, n_haps, read_len, hap_len):
@@ -378,24 +427,30 @@ def test_pdhmm_jni_flat_and_holder_paths(pd_oracle):
     b, exp = load_pdhmm_file(FILES[1])
     rc, out, cls, msg = mockjni.run_pdhmm(b)
     assert rc == 0, (cls, msg)
-    _, vec = pd_oracle.compute(b, semantics=2)
-    assert out.tobytes() == vec.tobytes() and np.max(np.abs(out - exp)) <= TOL
-    # holders: 7 reads x 5 haplotypes, read-major cross product (staged once each, crossed on the device)
+    _, ref = pd_oracle.compute_reference(b, fma_mode=1)   # GKL's computePDHMMNative, position by position
+    assert out.tobytes() == ref.tobytes() and np.max(np.abs(out - exp)) <= TOL
+    # holders: 61 reads x 41 haplotypes, read-major cross product (staged once each, crossed on the device); with
+    # maxMemoryInMB = 1 the reference cuts the 2501 pairs into two batches, each with its own scalar tail
+    from gkl_amd import native
     rng = np.random.RandomState(9)
-    src = random_pd_batch(rng, 7, read_len=(20, 60), hap_len=(30, 80))
-    haps = random_pd_batch(rng, 5, read_len=(1, 2), hap_len=(30, 80))
+    nr, nh = 61, 41
+    src = random_pd_batch(rng, nr, with_n=False, read_len=(20, 60), hap_len=(30, 80))
+    haps = random_pd_batch(rng, nh, with_n=False, read_len=(1, 2), hap_len=(30, 80))
     rc, out, cls, msg = mockjni.run_pdhmm(None, holders=(src, haps), max_memory_mb=1)
     assert rc == 0, (cls, msg)
     pairs = []
-    for r in range(7):
-        for h in range(5):
+    for r in range(nr):
+        for h in range(nh):
             R, H = int(src.read_lengths[r]), int(haps.hap_lengths[h])
-            rr = lambda a: a.reshape(7, src.max_read_len)[r, :R]  # noqa: E731
-            hh = lambda a: a.reshape(5, haps.max_hap_len)[h, :H]  # noqa: E731
+            rr = lambda a: a.reshape(nr, src.max_read_len)[r, :R]  # noqa: E731
+            hh = lambda a: a.reshape(nh, haps.max_hap_len)[h, :H]  # noqa: E731
             pairs.append((hh(haps.hap_bases), hh(haps.hap_pdbases), rr(src.read_bases), rr(src.read_qual),
                           rr(src.read_ins_qual), rr(src.read_del_qual), rr(src.gcp)))
-    _, vec = pd_oracle.compute(PdhmmBatch.from_pairs(pairs), semantics=2)
-    assert out.tobytes() == vec.tobytes()
+    max_r, max_h = int(src.read_lengths.max()), int(haps.hap_lengths.max())
+    ref_batch = native.pdhmm_reference_batch_pairs(1, max_r, max_h, nr * nh)
+    assert 0 < ref_batch < nr * nh, "two reference batches"
+    _, ref = pd_oracle.compute_reference(PdhmmBatch.from_pairs(pairs), fma_mode=1, ref_batch=ref_batch)
+    assert out.tobytes() == ref.tobytes()
     bad = random_pd_batch(np.random.RandomState(2), 4)
     bad.read_del_qual[1] = -7
     rc, _, cls, msg = mockjni.run_pdhmm(bad)
@@ -423,7 +478,9 @@ def test_pdhmm_mirror_compute_likelihoods_on_holders_fixture(pd_oracle):
     out = np.zeros(len(rd) * len(hd))
     hmm.computeLikelihoods(rd, hd, out)
     hmm.done()
-    _, vec = pd_oracle.compute(b, semantics=2)
+    # 13 248 pairs = 1656 groups of 8: one reference batch at the default 512 MB and no scalar tail at all
+    _, vec = pd_oracle.compute_reference(b, fma_mode=1)
+    assert vec.tobytes() == pd_oracle.compute(b, semantics=2)[1].tobytes()
     assert np.max(np.abs(out - exp)) <= TOL
     assert out.tobytes() == vec.tobytes()
     # the same holders through the JNI symbol computeLikelihoodsNative (mock JNIEnv), default memory budget
