@@ -141,6 +141,52 @@ def host_call_record(native, batch, dev_index, calls=30, warm=15, max_threads=1)
             "pairs": batch.n_pairs, "fallback_fraction": round(st["n_fallback"] / batch.n_pairs, 4)}
 
 
+def jni_records(batch, c1, host_ms):
+    """computeLikelihoodsNative itself, driven through a mock JNIEnv (tests/native/mock_jni.cpp: -Xcheck:jni-style
+    bookkeeping on every call, so its JNI functions cost several times a real JVM's): ms per call for the bench batch
+    (C2) and a GATK-sized region (C1) with the shim's own split -- marshalling on the calling thread, waiting for
+    compute that marshalling did not cover, write-back -- and the aggregate rate of 1 / 4 / 16 concurrent Java threads
+    each sending 100 x 10 regions through their own slot (GKL_HIP_SLOTS raised to the thread count)."""
+    from tests import mockjni
+    rec = {}
+
+    def one(b, iters, warm, threads=1):
+        t = []
+        rc, _, cls, msg, wall = mockjni.run_concurrent(b, threads, iters=iters, warm=warm, timing=t)
+        if rc != 0:
+            raise RuntimeError(f"mock JNI run failed: {cls} {msg}")
+        calls = max(t[4], 1)
+        return wall, t, calls
+    wall, t, calls = one(batch, 6, 2)
+    ms = wall / 6
+    rec["c2"] = {"ms_per_call": round(ms, 3), "gcups": round(batch.cells / ms / 1e6, 1),
+                 "marshal_ms": round(t[0] / calls / 1e6, 3), "compute_wait_ms": round(t[1] / calls / 1e6, 3),
+                 "writeback_ms": round(t[2] / calls / 1e6, 3), "pipelined": bool(t[5]),
+                 "over_host_path": round(ms / host_ms, 3) if host_ms else None}
+    wall, t, calls = one(c1, 200, 30)
+    ms = wall / 200
+    rec["c1"] = {"ms_per_call": round(ms, 4), "gcups": round(c1.cells / ms / 1e6, 1),
+                 "marshal_ms": round(t[0] / calls / 1e6, 4), "compute_wait_ms": round(t[1] / calls / 1e6, 4),
+                 "writeback_ms": round(t[2] / calls / 1e6, 4)}
+    conc = {}
+    os.environ["GKL_HIP_SLOTS"] = "16"
+    try:
+        from gkl_amd.synth import DEFAULT_SEED, make_batch
+        for threads in (1, 4, 16):
+            # every thread its own 100 reads (x 10 haplotypes): run_concurrent slices the reads by thread
+            b = make_batch("hc", 100 * threads, 10, seed=DEFAULT_SEED)
+            iters = 150
+            wall, t, calls = one(b, iters, 20, threads)
+            conc[f"callers_{threads}"] = {"aggregate_gcups": round(b.cells * iters / wall / 1e6, 1),
+                                          "calls_per_s": round(threads * iters / wall * 1e3, 1),
+                                          "ms_per_call": round(t[3] / calls / 1e6, 4)}
+    finally:
+        os.environ.pop("GKL_HIP_SLOTS", None)
+    rec["note"] = ("through Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative with a mock JNIEnv; big calls are "
+                   "pipelined (read ranges marshalled while earlier ranges compute on the slot's two engines)")
+    return rec, conc
+
+
 def in_library_probe(n_dev, reads, haps, workload, steps, warmup):
     """Child-process mode: ONE process drives n_dev devices through a multi-device context (GKL_HIP_DEVICES),
     i.e. what a JVM calling computeLikelihoodsNative gets.  Prints one JSON object."""
@@ -412,6 +458,12 @@ def main():
                 res["small_batch"] = {"c1_100x10": host_call_record(native, c1, dev_index, calls=60, warm=30),
                                       f"eighth_{eighth.n_reads}x{eighth.n_haps}": host_call_record(native, eighth, dev_index, calls=20, warm=10),
                                       "note": "through gklhip_compute, back-to-back single calls, median"}
+                try:
+                    jrec, conc = jni_records(batch, c1, res["host_path"]["max_threads_1"]["ms_per_call"])
+                    res["jni_path"] = jrec
+                    res["small_batch"]["concurrent"] = conc
+                except Exception as e:
+                    res["jni_path"] = {"error": repr(e)}
                 # the same shape without fallback pairs (one real active region)
                 reg = make_batch("region", a.reads, a.haps, seed=DEFAULT_SEED)
                 dreg = native.DeviceBatch.upload(reg, dev)

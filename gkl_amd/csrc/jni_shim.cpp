@@ -10,6 +10,10 @@
 //     the host-to-device copies are plain DMA, and every concurrent caller gets its own slot
 //     (context + stream + arenas, up to GKL_HIP_SLOTS, default 4): one Java thread marshals or
 //     finalises while another one's kernels run;
+//   * a BIG call is pipelined: the reads are marshalled range by range on the calling thread (the only one that may
+//     use its JNIEnv) while two engines of the slot compute the ranges already marshalled and the finished ranges
+//     are written back to the Java array -- the 250 000 JNI calls of a 10k-read batch then hide behind the kernels
+//     (the reference pins everything, computes, releases: JavaData.h:65-111, IntelPairHmm.cc:150-186);
 //   * null holders / null byte[] fields / a too-short likelihood array raise
 //     IllegalArgumentException instead of crashing the JVM;
 //   * HIP failures raise java/lang/RuntimeException, allocation failures
@@ -18,11 +22,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gkl_hip_pairhmm.h"
@@ -76,16 +85,92 @@ struct PinnedBytes {
   }
 };
 
+// The five read arrays of one read range (the whole batch in a small call).
+struct ReadArena {
+  PinnedBytes read_bases, read_quals, ins, del, gcp;
+  std::vector<int64_t> read_off;
+  void clear() { for (PinnedBytes* a : {&read_bases, &read_quals, &ins, &del, &gcp}) a->clear(); }
+};
+
+// Pipelined big calls: a compute thread bound to one engine of the slot takes read ranges from `todo`, runs
+// gklhip_compute on them and reports on `done`.  The JNI side (marshalling, write-back, exceptions) stays on the
+// calling thread.
+struct RangeTask {
+  int k = 0;
+  gklhip_batch batch;
+  double* out = nullptr;
+  int status = GKLHIP_OK;
+  std::string error;
+};
+struct Pipeline {
+  std::mutex mu;
+  std::condition_variable has_todo, has_done;
+  std::deque<RangeTask*> todo, done;
+  bool quit = false;
+  std::vector<std::thread> threads;
+  void start(gklhip_ctx* ctx) {
+    threads.emplace_back([this, ctx] {
+      std::unique_lock<std::mutex> l(mu);
+      for (;;) {
+        has_todo.wait(l, [&] { return quit || !todo.empty(); });
+        if (todo.empty()) return;  // quit
+        RangeTask* t = todo.front();
+        todo.pop_front();
+        l.unlock();
+        t->status = gklhip_compute(ctx, &t->batch, t->out);
+        if (t->status != GKLHIP_OK) { const char* d = gklhip_last_error(); t->error = d ? d : ""; }  // (thread-local detail)
+        l.lock();
+        done.push_back(t);
+        has_done.notify_all();
+      }
+    });
+  }
+  void submit(RangeTask* t) {
+    { std::lock_guard<std::mutex> l(mu); todo.push_back(t); }
+    has_todo.notify_one();
+  }
+  RangeTask* take_done(bool wait) {
+    std::unique_lock<std::mutex> l(mu);
+    if (wait) has_done.wait(l, [&] { return !done.empty(); });
+    if (done.empty()) return nullptr;
+    RangeTask* t = done.front();
+    done.pop_front();
+    return t;
+  }
+  ~Pipeline() {
+    { std::lock_guard<std::mutex> l(mu); quit = true; }
+    has_todo.notify_all();
+    for (auto& th : threads) th.join();
+  }
+};
+
 // Everything one call needs; a slot serves one caller at a time.
 struct Slot {
   gklhip_ctx* ctx = nullptr;
-  PinnedBytes hap_bases, read_bases, read_quals, ins, del, gcp;
-  std::vector<int64_t> hap_off, read_off;
+  gklhip_ctx* ctx2 = nullptr;          // second engine of pipelined big calls (created by the first of them)
+  std::unique_ptr<Pipeline> pipe;      // declared after the contexts: its threads are joined before they go
+  PinnedBytes hap_bases;
+  std::vector<int64_t> hap_off;
+  ReadArena whole;                     // a small call's reads
+  std::vector<std::unique_ptr<ReadArena>> ranges;  // a pipelined call's read ranges
+  std::vector<RangeTask> tasks;
   std::vector<double> out;
   bool busy = false;
   int gen = 0;  // configuration generation (initNative with other arguments starts a new one)
-  ~Slot() { if (ctx) gklhip_done(ctx); }
+  ~Slot() {
+    pipe.reset();
+    if (ctx2) gklhip_done(ctx2);
+    if (ctx) gklhip_done(ctx);
+  }
 };
+
+// Where a call's time goes, summed over the calls of the process (nanoseconds; gkl_pairhmm_jni_timing reads them):
+// [0] marshalling on the calling thread, [1] waiting for compute that marshalling did not cover (a small call: the
+// whole gklhip_compute), [2] write-back into the Java array, [3] whole calls, [4] number of calls, [5] pipelined calls.
+std::atomic<int64_t> g_timing[6];
+int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // Process-wide state, like the reference's globals (IntelPairHmm.cc:41-48) and the
 // static field IDs of JavaData (JavaData.h:160-176).
@@ -283,12 +368,18 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
   SlotLease lease{acquire_slot(env)};
   Slot* sl = lease.s;
   if (!sl) return;
+  const int64_t t_call = now_ns();
   try {
     const jsize n_reads = gkljni::GetArrayLength(env, readDataArray);
     const jsize n_haps = gkljni::GetArrayLength(env, haplotypeDataArray);
-    for (PinnedBytes* a : {&sl->hap_bases, &sl->read_bases, &sl->read_quals, &sl->ins, &sl->del, &sl->gcp}) a->clear();
+    const int64_t n_pairs = (int64_t)n_reads * n_haps;
+    if (n_pairs > 0x7fffffffLL) { throw_java(env, kIAE, "more than 2^31 read x haplotype pairs"); return; }
+    if ((int64_t)gkljni::GetArrayLength(env, likelihoodArray) < n_pairs) {
+      throw_java(env, kIAE, "likelihood array shorter than reads x haplotypes");
+      return;
+    }
+    sl->hap_bases.clear();
     sl->hap_off.assign((size_t)n_haps + 1, 0);
-    sl->read_off.assign((size_t)n_reads + 1, 0);
     for (jsize h = 0; h < n_haps; h++) {
       jobject holder = holder_at(env, haplotypeDataArray, h);
       if (!holder) return;
@@ -297,37 +388,116 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
       if (len < 0) return;
       sl->hap_off[h + 1] = sl->hap_off[h] + len;
     }
-    for (jsize r = 0; r < n_reads; r++) {
-      jobject holder = holder_at(env, readDataArray, r);
-      if (!holder) return;
-      const long len = append_field(env, holder, g.readBases, sl->read_bases, -1);
-      const bool ok = len >= 0 && append_field(env, holder, g.insertionGOP, sl->ins, len) >= 0 &&
-                      append_field(env, holder, g.deletionGOP, sl->del, len) >= 0 &&
-                      append_field(env, holder, g.overallGCP, sl->gcp, len) >= 0 &&
-                      append_field(env, holder, g.readQuals, sl->read_quals, len) >= 0;
-      gkljni::DeleteLocalRef(env, holder);
-      if (!ok) return;
-      sl->read_off[r + 1] = sl->read_off[r] + len;
-    }
-    const int64_t n_pairs = (int64_t)n_reads * n_haps;
-    if (n_pairs > 0x7fffffffLL) { throw_java(env, kIAE, "more than 2^31 read x haplotype pairs"); return; }
-    if ((int64_t)gkljni::GetArrayLength(env, likelihoodArray) < n_pairs) {
-      throw_java(env, kIAE, "likelihood array shorter than reads x haplotypes");
+    // reads [r0, r1) into `a` (offsets rebased to 0); false after throwing
+    auto marshal_reads = [&](ReadArena& a, jsize r0, jsize r1) -> bool {
+      a.clear();
+      a.read_off.assign((size_t)(r1 - r0) + 1, 0);
+      for (jsize r = r0; r < r1; r++) {
+        jobject holder = holder_at(env, readDataArray, r);
+        if (!holder) return false;
+        const long len = append_field(env, holder, g.readBases, a.read_bases, -1);
+        const bool ok = len >= 0 && append_field(env, holder, g.insertionGOP, a.ins, len) >= 0 &&
+                        append_field(env, holder, g.deletionGOP, a.del, len) >= 0 &&
+                        append_field(env, holder, g.overallGCP, a.gcp, len) >= 0 &&
+                        append_field(env, holder, g.readQuals, a.read_quals, len) >= 0;
+        gkljni::DeleteLocalRef(env, holder);
+        if (!ok) return false;
+        a.read_off[(size_t)(r - r0) + 1] = a.read_off[(size_t)(r - r0)] + len;
+      }
+      return true;
+    };
+    auto batch_of = [&](const ReadArena& a, int32_t n) {
+      gklhip_batch b;
+      b.n_reads = n; b.n_haps = n_haps;
+      b.read_off = a.read_off.data(); b.hap_off = sl->hap_off.data();
+      b.read_bases = a.read_bases.p; b.read_quals = a.read_quals.p; b.ins_gop = a.ins.p;
+      b.del_gop = a.del.p; b.gcp = a.gcp.p; b.hap_bases = sl->hap_bases.p;
+      return b;
+    };
+    static const int64_t pipeline_from = [] { const char* v = getenv("GKL_HIP_JNI_PIPELINE_PAIRS"); return v && *v ? atoll(v) : 262144LL; }();
+    if (n_pairs < pipeline_from || n_reads < 64 || pipeline_from <= 0) {
+      // ---- one shot (a GATK active region): marshal, compute, write back ----
+      if (!marshal_reads(sl->whole, 0, n_reads)) return;
+      const int64_t t_m = now_ns();
+      if (n_pairs == 0) return;
+      const gklhip_batch b = batch_of(sl->whole, n_reads);
+      sl->out.resize((size_t)n_pairs);
+      const int st = gklhip_compute(sl->ctx, &b, sl->out.data());
+      const int64_t t_c = now_ns();
+      if (st != GKLHIP_OK) { throw_status(env, st); return; }
+      gkljni::SetDoubleArrayRegion(env, likelihoodArray, 0, (jsize)n_pairs, sl->out.data());
+      const int64_t t_w = now_ns();
+      g_timing[0] += t_m - t_call; g_timing[1] += t_c - t_m; g_timing[2] += t_w - t_c; g_timing[3] += t_w - t_call; g_timing[4]++;
       return;
     }
-    if (n_pairs == 0) return;
-    gklhip_batch b;
-    b.n_reads = n_reads; b.n_haps = n_haps;
-    b.read_off = sl->read_off.data(); b.hap_off = sl->hap_off.data();
-    b.read_bases = sl->read_bases.p; b.read_quals = sl->read_quals.p; b.ins_gop = sl->ins.p;
-    b.del_gop = sl->del.p; b.gcp = sl->gcp.p; b.hap_bases = sl->hap_bases.p;
+    // ---- pipelined: read ranges of ~150k pairs (100k..320k measure the same); range k+1 is marshalled while the ranges before it compute on the
+    // slot's two engines, finished ranges go back to the Java array in between ----
+    if (!sl->pipe) {
+      if (!sl->ctx2) {
+        gklhip_config cfg;
+        { std::lock_guard<std::mutex> lock(g.mu); cfg = g.cfg; }   // (a re-configuration meanwhile retires this slot when it comes back)
+        const int st = gklhip_init(&cfg, &sl->ctx2);
+        if (st != GKLHIP_OK) sl->ctx2 = nullptr;          // e.g. out of device memory: one engine
+      }
+      sl->pipe.reset(new Pipeline());
+      sl->pipe->start(sl->ctx);
+      if (sl->ctx2) sl->pipe->start(sl->ctx2);
+    }
+    static const int64_t range_pairs = [] { const char* v = getenv("GKL_HIP_JNI_RANGE_PAIRS"); return v && atoll(v) > 0 ? atoll(v) : 150000LL; }();
+    const int n_ranges = (int)std::max<int64_t>(2, std::min<int64_t>(32, (n_pairs + range_pairs - 1) / range_pairs));
+    while ((int)sl->ranges.size() < n_ranges) sl->ranges.emplace_back(new ReadArena());
+    sl->tasks.assign((size_t)n_ranges, RangeTask());
     sl->out.resize((size_t)n_pairs);
-    const int st = gklhip_compute(sl->ctx, &b, sl->out.data());
-    if (st != GKLHIP_OK) { throw_status(env, st); return; }
-    gkljni::SetDoubleArrayRegion(env, likelihoodArray, 0, (jsize)n_pairs, sl->out.data());
+    int64_t ns_marshal = now_ns() - t_call, ns_wait = 0, ns_write = 0;
+    int submitted = 0, finished = 0, failed_status = GKLHIP_OK;
+    std::string failed_detail;
+    bool java_exception = false;
+    auto retire = [&](RangeTask* t) {   // a finished range: write it back (calling thread), or remember its error
+      finished++;
+      if (t->status != GKLHIP_OK) { if (failed_status == GKLHIP_OK) { failed_status = t->status; failed_detail = t->error; } return; }
+      if (java_exception || failed_status != GKLHIP_OK) return;
+      const int64_t t0 = now_ns();
+      const int64_t at = t->out - sl->out.data();
+      gkljni::SetDoubleArrayRegion(env, likelihoodArray, (jsize)at, (jsize)((int64_t)t->batch.n_reads * n_haps), t->out);
+      if (gkljni::ExceptionCheck(env)) java_exception = true;
+      ns_write += now_ns() - t0;
+    };
+    for (int k = 0; k < n_ranges && !java_exception && failed_status == GKLHIP_OK; k++) {
+      const jsize r0 = (jsize)((int64_t)n_reads * k / n_ranges), r1 = (jsize)((int64_t)n_reads * (k + 1) / n_ranges);
+      const int64_t t0 = now_ns();
+      if (!marshal_reads(*sl->ranges[(size_t)k], r0, r1)) { java_exception = true; break; }
+      ns_marshal += now_ns() - t0;
+      RangeTask& t = sl->tasks[(size_t)k];
+      t.k = k;
+      t.batch = batch_of(*sl->ranges[(size_t)k], r1 - r0);
+      t.out = sl->out.data() + (int64_t)r0 * n_haps;
+      sl->pipe->submit(&t);
+      submitted++;
+      while (RangeTask* d = sl->pipe->take_done(false)) retire(d);
+    }
+    // whatever happened, the ranges in flight read this call's arenas: wait for all of them
+    while (finished < submitted) {
+      const int64_t t0 = now_ns();
+      RangeTask* d = sl->pipe->take_done(true);
+      ns_wait += now_ns() - t0;
+      retire(d);
+    }
+    if (java_exception) return;
+    if (failed_status != GKLHIP_OK) {
+      char msg[600];
+      snprintf(msg, sizeof msg, "GKL-HIP PairHMM: %s%s%s", gklhip_strerror(failed_status), failed_detail.empty() ? "" : ": ", failed_detail.c_str());
+      throw_java(env, failed_status == GKLHIP_ERR_INVALID_ARG ? kIAE : failed_status == GKLHIP_ERR_OOM ? kOOM : kRTE, msg);
+      return;
+    }
+    g_timing[0] += ns_marshal; g_timing[1] += ns_wait; g_timing[2] += ns_write; g_timing[3] += now_ns() - t_call; g_timing[4]++; g_timing[5]++;
   } catch (const std::bad_alloc&) {
     throw_java(env, kOOM, "Unable to allocate the PairHMM batch");
   }
+}
+
+// Diagnostics (not a JNI native): the call-time split summed since the last reset, nanoseconds -- see g_timing.
+__attribute__((visibility("default"))) void gkl_pairhmm_jni_timing(int64_t out[6], int reset) {
+  for (int i = 0; i < 6; i++) { out[i] = g_timing[i].load(); if (reset) g_timing[i].store(0); }
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv*, jobject) {

@@ -791,6 +791,16 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
   *out = nullptr;
   if (dev < 0 || dev >= ndev) return fail(GKLHIP_ERR_INVALID_ARG, "device %d of %d", dev, ndev);
   HIP_TRY(hipSetDevice(dev));
+  {
+    // GKL_HIP_SCHEDULE=spin|yield|blocking: how host threads wait for the device (hipSetDeviceFlags); default: HIP's own
+    static const char* sched = getenv("GKL_HIP_SCHEDULE");
+    if (sched && *sched) {
+      const unsigned f = strcmp(sched, "yield") == 0 ? hipDeviceScheduleYield : strcmp(sched, "blocking") == 0 ? hipDeviceScheduleBlockingSync
+                         : strcmp(sched, "spin") == 0 ? hipDeviceScheduleSpin : hipDeviceScheduleAuto;
+      (void)hipSetDeviceFlags(f);
+      (void)hipGetLastError();
+    }
+  }
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)

@@ -20,6 +20,7 @@
 #include "../gkl_amd/csrc/jni_min.h"
 #endif
 
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -36,7 +37,8 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
 /* native void computeLikelihoodsNative(Object[] readDataArray, Object[] haplotypeDataArray,
  *                                      double[] likelihoodArray)
  * Replaces IntelPairHmm.cc:125-181 + JavaData::getData (JavaData.h:65-111): copies the byte[]
- * fields into a flat batch, gklhip_compute(), writes likelihoodArray[r*numHaps + h]. */
+ * fields into a flat batch, gklhip_compute(), writes likelihoodArray[r*numHaps + h].  A big call is pipelined:
+ * read ranges are marshalled while the ranges before them compute on the slot's two engines. */
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative(
     JNIEnv* env, jobject obj, jobjectArray readDataArray, jobjectArray haplotypeDataArray,
     jdoubleArray likelihoodArray);
@@ -51,6 +53,13 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv
 struct JavaVM_;
 #endif
 JNIEXPORT jint JNICALL JNI_OnLoad(struct JavaVM_* vm, void* reserved);
+
+/* Diagnostics (not a JNI native, nothing in the reference): where the time of computeLikelihoodsNative goes, summed
+ * over the calls of the process since the last reset, in nanoseconds -- [0] marshalling the holders on the calling
+ * thread, [1] waiting for compute that marshalling did not cover (a small call: all of gklhip_compute), [2] writing the
+ * likelihoods back, [3] whole calls, [4] number of calls, [5] calls that were pipelined (read ranges marshalled while
+ * earlier ranges compute; GKL_HIP_JNI_PIPELINE_PAIRS, default 262144 pairs, sets the size from which that happens). */
+void gkl_pairhmm_jni_timing(int64_t out[6], int reset);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <chrono>
 #include <string>
@@ -303,6 +304,11 @@ int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_rea
 }
 
 
+int g_warm_iters = 0;             // mockjni_set_warm_iters: untimed calls per thread in front of mockjni_run_concurrent's timed part
+int64_t g_last_timing[6] = {0};   // the shim's call-time split over the timed part of the last mockjni_run_concurrent
+void mockjni_set_warm_iters(int n) { g_warm_iters = n < 0 ? 0 : n; }
+void mockjni_last_timing(int64_t* out) { for (int i = 0; i < 6; i++) out[i] = g_last_timing[i]; }
+
 // Concurrent callers (GATK Spark): one initNative, then `n_threads` threads, each with its own JNIEnv,
 // call computeLikelihoodsNative `iters` times on its own contiguous slice of the reads (all haplotypes),
 // then one doneNative.  out = the whole batch's likelihoods, read-major.  Returns 0, or 1/2 like
@@ -364,10 +370,27 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
     slices.push_back(arr);
     results.push_back(res);
   }
-  const auto t0 = std::chrono::steady_clock::now();
+  // g_warm_iters untimed calls per thread first (slots, engines and arenas exist afterwards), then all threads start
+  // the timed part together; the shim's call-time split (gkl_pairhmm_jni_timing) is reset at that point
+  typedef void (*timing_fn)(int64_t*, int);
+  timing_fn f_timing = (timing_fn)dlsym(h, "gkl_pairhmm_jni_timing");
+  std::atomic<int> warmed{0};
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  std::mutex t0_mu;
   std::vector<std::thread> pool;
   for (int t = 0; t < n_threads; t++)
     pool.emplace_back([&, t] {
+      for (int k = 0; k < g_warm_iters && !envs[t]->pending; k++)
+        f_compute(&envs[t]->env, nullptr, reinterpret_cast<jobjectArray>(slices[t]),
+                  reinterpret_cast<jobjectArray>(haps), reinterpret_cast<jdoubleArray>(results[t]));
+      if (warmed.fetch_add(1) + 1 == n_threads) {
+        std::lock_guard<std::mutex> l(t0_mu);
+        int64_t scratch[6];
+        if (f_timing) f_timing(scratch, 1);
+        t0 = std::chrono::steady_clock::now();
+        warmed.fetch_add(n_threads);  // release
+      }
+      while (warmed.load() < 2 * n_threads) std::this_thread::yield();
       for (int k = 0; k < iters && !envs[t]->pending; k++)
         f_compute(&envs[t]->env, nullptr, reinterpret_cast<jobjectArray>(slices[t]),
                   reinterpret_cast<jobjectArray>(haps), reinterpret_cast<jdoubleArray>(results[t]));
@@ -392,6 +415,7 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
   stop.store(true);
   if (churn.joinable()) churn.join();
   if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (f_timing) f_timing(g_last_timing, 0);
   if (churn_env.pending) { envs[0]->pending = true; envs[0]->exc_class = churn_env.exc_class; envs[0]->exc_msg = "churn thread: " + churn_env.exc_msg; }
   f_done(&m.env, nullptr);
   int rc_ = 0;
