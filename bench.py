@@ -356,6 +356,12 @@ def main():
             single_ms = _median_ms(one_call, 5, 1)
             pst = probe.stats()
             st["n_fallback"] = pst["n_fallback"]   # needs a synchronising call: outside the timed region
+            # the chip's issue ceiling for the recurrence's bare instruction mix (4 mul + 4 fma per cell, bank-clean
+            # operands, four wavefronts per SIMD) and the clock it sustains there: 50 ms, outside the timed region
+            try:
+                mix_cells_per_s, mix_clock_ghz = probe.issue_ceiling(use_double=a.double, ms_budget=50.0)
+            except Exception:
+                mix_cells_per_s, mix_clock_ghz = None, None
         k_ms = float(np.mean(ms_main))
         fb_ms = float(np.mean(ms_fb))
         dev_ms = float(np.mean(ms_dev))
@@ -403,11 +409,16 @@ def main():
                          "traffic": None, "traffic_from_profile": traffic_profile,
                          "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(k_ms, 3),
                          "kernel_gcups": round(batch.cells / k_ms / 1e6, 1),
+                         # what the chip issues when NOTHING but the recurrence's 4 mul + 4 fma per cell is in the way
+                         # (gklhip_measure_issue_ceiling, measured in this run): the ceiling of any kernel with this arithmetic
+                         "issue_ceiling_tflops": round(FLOP_PER_CELL * mix_cells_per_s / 1e12, 2) if mix_cells_per_s else None,
+                         "frac_of_issue_ceiling": round(achieved / (FLOP_PER_CELL * mix_cells_per_s / 1e12), 4) if mix_cells_per_s else None,
+                         "issue_ceiling_clock_ghz": round(mix_clock_ghz, 3) if mix_clock_ghz else None,
                          "note": "compute-bound recurrence priced at the dense fp32 (fp64 with --double) MFMA peak = the vector "
-                                 "peak; it has no contraction, so it runs on the vector ALUs and issues no MFMA; that peak is "
-                                 "reachable only by packed FMA-only code. The recurrence needs 4 mul + 4 fma per cell "
-                                 "(1.5 flop per instruction) and a SIMD retires one plain VALU op per ~2.7 cycles (measured), "
-                                 "so its issue-bound ceiling is ~7 TCUPS = 0.53 of peak (DESIGN.md section 3)"},
+                                 "peak (SIMD-32: one wave64 FMA per 2 cycles); it has no contraction, so it runs on the vector ALUs "
+                                 "and issues no MFMA. The recurrence needs 4 mul + 4 fma per cell (1.5 flop per instruction: 0.75 "
+                                 "of peak at best) and a SIMD issues one such op per ~2.3 cycles, not 2: issue_ceiling_tflops is "
+                                 "that bound, measured in this run (DESIGN.md section 3)"},
             "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(fb_ms, 3),
                            "device_total": round(dev_ms, 3), "from": kernel_times_from},
             # what a step costs beyond its two forward kernels (planning, policy, log10, launches, gaps); with

@@ -1598,6 +1598,46 @@ int64_t gklhip_get_table_f64(int which, double* dst, int64_t cap) {
   return (int64_t)v->size();
 }
 
+// Diagnostics: the VALU issue ceiling of the recurrence's instruction mix on this device (issue_mix_*_kernel: 4 multiplies
+// + 4 FMAs per "cell", four wavefronts per SIMD, every CU) over about `ms_budget` milliseconds.  cells_per_s x 12 FLOP is
+// what roofline.issue_ceiling_tflops reports; clock_ghz = shader cycles the kernel counted / its HIP-event time, i.e. the
+// clock the chip sustains under this load (it clocks to its power budget).
+int gklhip_measure_issue_ceiling(gklhip_ctx* ctx, int use_double, double ms_budget, double* cells_per_s, double* clock_ghz) {
+  if (!ctx || !cells_per_s) return fail(GKLHIP_ERR_INVALID_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DevCtx* c = ctx->dev[0];
+  HIP_TRY(hipSetDevice(c->device));
+  uint64_t* cyc = nullptr;
+  HIP_TRY(hipMalloc(&cyc, 8));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  const int blocks = c->n_cus * 4;  // 4 x 256 threads per CU = four wavefronts per SIMD
+  auto run = [&](int iters, float* ms) -> int {
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    if (use_double) hipLaunchKernelGGL(issue_mix_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, iters, cyc);
+    else            hipLaunchKernelGGL(issue_mix_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, iters, cyc);
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+    return GKLHIP_OK;
+  };
+  float ms = 0;
+  int rc = run(2000, &ms);   // warm-up + calibration (~1 ms)
+  int iters = (int)std::max(2000.0, std::min(4.0e6, 2000.0 * std::max(1.0, ms_budget) / std::max(ms, 0.05f)));
+  if (!rc) rc = run(iters, &ms);
+  uint64_t cycles = 0;
+  if (!rc && hipMemcpy(&cycles, cyc, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(GKLHIP_ERR_HIP, "hipMemcpy failed");
+  (void)hipFree(cyc);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  const double cells = (double)blocks * 4 /*wavefronts*/ * 64 /*lanes*/ * 8 /*cells per iteration*/ * (double)iters;
+  *cells_per_s = cells / (ms * 1e-3);
+  if (clock_ghz) *clock_ghz = (double)cycles / (ms * 1e-3) * 1e-9;
+  return GKLHIP_OK;
+}
+
 // Diagnostics: load RCCL and run one send/recv pair inside one group on a one-device communicator (what the
 // multi-device gather does per extra device).  0 = ok.
 int gklhip_rccl_selftest(int32_t device) {

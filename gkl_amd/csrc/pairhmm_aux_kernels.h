@@ -505,4 +505,176 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
   stamp(5);
 }
 
+// ---- diagnostics: the VALU issue ceiling of the forward recurrence's instruction mix ----------------------------
+// Eight "cells" of 4 multiplies + 4 fused multiply-adds per loop iteration, operands in registers chosen so that no
+// three-source op has all sources in one VGPR bank (even / odd), four wavefronts per SIMD on every CU: what the chip
+// issues when nothing but the recurrence's arithmetic is in the way.  gklhip_measure_issue_ceiling times it and
+// bench.py prices the forward kernel against it (roofline.issue_ceiling_tflops).  GENERATED text (same generator as
+// tools/gen_ubench_banks2.py's "cell mix").
+__global__ __launch_bounds__(256) void issue_mix_f32_kernel(int iters, uint64_t* cycles) {
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  asm volatile(
+      "v_mov_b32 v24, 1.0\n\tv_mov_b32 v25, 1.0\n\tv_mov_b32 v26, 1.0\n\tv_mov_b32 v27, 1.0\n\tv_mov_b32 v28, 1.0\n\tv_mov_b32 v29, 1.0\n\tv_mov_b32 v30, 1.0\n\tv_mov_b32 v31, 1.0\n\t"
+      "v_mov_b32 v32, 1.0\n\tv_mov_b32 v33, 1.0\n\tv_mov_b32 v34, 1.0\n\tv_mov_b32 v35, 1.0\n\tv_mov_b32 v36, 1.0\n\tv_mov_b32 v37, 1.0\n\tv_mov_b32 v38, 1.0\n\tv_mov_b32 v39, 1.0\n\t"
+      "v_mov_b32 v40, 1.0\n\tv_mov_b32 v41, 1.0\n\tv_mov_b32 v42, 1.0\n\tv_mov_b32 v43, 1.0\n\tv_mov_b32 v44, 1.0\n\tv_mov_b32 v45, 1.0\n\tv_mov_b32 v46, 1.0\n\tv_mov_b32 v47, 1.0\n\t"
+      "v_mov_b32 v48, 1.0\n\tv_mov_b32 v49, 1.0\n\tv_mov_b32 v50, 1.0\n\tv_mov_b32 v51, 1.0\n\tv_mov_b32 v52, 1.0\n\tv_mov_b32 v53, 1.0\n\tv_mov_b32 v54, 1.0\n\tv_mov_b32 v55, 1.0\n\t"
+      "s_mov_b32 s6, %0\n\t"
+      "1:\n\t"
+      "v_mul_f32 v27, v24, v25\n\t"
+      "v_fmac_f32 v27, v25, v26\n\t"
+      "v_fmac_f32 v27, v24, v26\n\t"
+      "v_mul_f32 v27, v27, v26\n\t"
+      "v_mul_f32 v24, v24, v25\n\t"
+      "v_fmac_f32 v24, v26, v25\n\t"
+      "v_mul_f32 v26, v26, v25\n\t"
+      "v_fmac_f32 v26, v27, v25\n\t"
+      "v_mul_f32 v31, v28, v29\n\t"
+      "v_fmac_f32 v31, v29, v30\n\t"
+      "v_fmac_f32 v31, v28, v30\n\t"
+      "v_mul_f32 v31, v31, v30\n\t"
+      "v_mul_f32 v28, v28, v29\n\t"
+      "v_fmac_f32 v28, v30, v29\n\t"
+      "v_mul_f32 v30, v30, v29\n\t"
+      "v_fmac_f32 v30, v31, v29\n\t"
+      "v_mul_f32 v35, v32, v33\n\t"
+      "v_fmac_f32 v35, v33, v34\n\t"
+      "v_fmac_f32 v35, v32, v34\n\t"
+      "v_mul_f32 v35, v35, v34\n\t"
+      "v_mul_f32 v32, v32, v33\n\t"
+      "v_fmac_f32 v32, v34, v33\n\t"
+      "v_mul_f32 v34, v34, v33\n\t"
+      "v_fmac_f32 v34, v35, v33\n\t"
+      "v_mul_f32 v39, v36, v37\n\t"
+      "v_fmac_f32 v39, v37, v38\n\t"
+      "v_fmac_f32 v39, v36, v38\n\t"
+      "v_mul_f32 v39, v39, v38\n\t"
+      "v_mul_f32 v36, v36, v37\n\t"
+      "v_fmac_f32 v36, v38, v37\n\t"
+      "v_mul_f32 v38, v38, v37\n\t"
+      "v_fmac_f32 v38, v39, v37\n\t"
+      "v_mul_f32 v43, v40, v41\n\t"
+      "v_fmac_f32 v43, v41, v42\n\t"
+      "v_fmac_f32 v43, v40, v42\n\t"
+      "v_mul_f32 v43, v43, v42\n\t"
+      "v_mul_f32 v40, v40, v41\n\t"
+      "v_fmac_f32 v40, v42, v41\n\t"
+      "v_mul_f32 v42, v42, v41\n\t"
+      "v_fmac_f32 v42, v43, v41\n\t"
+      "v_mul_f32 v47, v44, v45\n\t"
+      "v_fmac_f32 v47, v45, v46\n\t"
+      "v_fmac_f32 v47, v44, v46\n\t"
+      "v_mul_f32 v47, v47, v46\n\t"
+      "v_mul_f32 v44, v44, v45\n\t"
+      "v_fmac_f32 v44, v46, v45\n\t"
+      "v_mul_f32 v46, v46, v45\n\t"
+      "v_fmac_f32 v46, v47, v45\n\t"
+      "v_mul_f32 v51, v48, v49\n\t"
+      "v_fmac_f32 v51, v49, v50\n\t"
+      "v_fmac_f32 v51, v48, v50\n\t"
+      "v_mul_f32 v51, v51, v50\n\t"
+      "v_mul_f32 v48, v48, v49\n\t"
+      "v_fmac_f32 v48, v50, v49\n\t"
+      "v_mul_f32 v50, v50, v49\n\t"
+      "v_fmac_f32 v50, v51, v49\n\t"
+      "v_mul_f32 v55, v52, v53\n\t"
+      "v_fmac_f32 v55, v53, v54\n\t"
+      "v_fmac_f32 v55, v52, v54\n\t"
+      "v_mul_f32 v55, v55, v54\n\t"
+      "v_mul_f32 v52, v52, v53\n\t"
+      "v_fmac_f32 v52, v54, v53\n\t"
+      "v_mul_f32 v54, v54, v53\n\t"
+      "v_fmac_f32 v54, v55, v53\n\t"
+      "s_sub_u32 s6, s6, 1\n\t"
+      "s_cmp_lg_u32 s6, 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      :: "s"(iters) : "s6", "scc", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) cycles[0] = t1 - t0;
+}
+
+__global__ __launch_bounds__(256) void issue_mix_f64_kernel(int iters, uint64_t* cycles) {
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  asm volatile(
+      "v_mov_b32 v24, 0\n\tv_mov_b32 v25, 0x3ff00000\n\tv_mov_b32 v26, 0\n\tv_mov_b32 v27, 0x3ff00000\n\tv_mov_b32 v28, 0\n\tv_mov_b32 v29, 0x3ff00000\n\tv_mov_b32 v30, 0\n\tv_mov_b32 v31, 0x3ff00000\n\t"
+      "v_mov_b32 v32, 0\n\tv_mov_b32 v33, 0x3ff00000\n\tv_mov_b32 v34, 0\n\tv_mov_b32 v35, 0x3ff00000\n\tv_mov_b32 v36, 0\n\tv_mov_b32 v37, 0x3ff00000\n\tv_mov_b32 v38, 0\n\tv_mov_b32 v39, 0x3ff00000\n\t"
+      "v_mov_b32 v40, 0\n\tv_mov_b32 v41, 0x3ff00000\n\tv_mov_b32 v42, 0\n\tv_mov_b32 v43, 0x3ff00000\n\tv_mov_b32 v44, 0\n\tv_mov_b32 v45, 0x3ff00000\n\tv_mov_b32 v46, 0\n\tv_mov_b32 v47, 0x3ff00000\n\t"
+      "v_mov_b32 v48, 0\n\tv_mov_b32 v49, 0x3ff00000\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0x3ff00000\n\tv_mov_b32 v52, 0\n\tv_mov_b32 v53, 0x3ff00000\n\tv_mov_b32 v54, 0\n\tv_mov_b32 v55, 0x3ff00000\n\t"
+      "v_mov_b32 v56, 0\n\tv_mov_b32 v57, 0x3ff00000\n\tv_mov_b32 v58, 0\n\tv_mov_b32 v59, 0x3ff00000\n\tv_mov_b32 v60, 0\n\tv_mov_b32 v61, 0x3ff00000\n\tv_mov_b32 v62, 0\n\tv_mov_b32 v63, 0x3ff00000\n\t"
+      "v_mov_b32 v64, 0\n\tv_mov_b32 v65, 0x3ff00000\n\tv_mov_b32 v66, 0\n\tv_mov_b32 v67, 0x3ff00000\n\tv_mov_b32 v68, 0\n\tv_mov_b32 v69, 0x3ff00000\n\tv_mov_b32 v70, 0\n\tv_mov_b32 v71, 0x3ff00000\n\t"
+      "v_mov_b32 v72, 0\n\tv_mov_b32 v73, 0x3ff00000\n\tv_mov_b32 v74, 0\n\tv_mov_b32 v75, 0x3ff00000\n\tv_mov_b32 v76, 0\n\tv_mov_b32 v77, 0x3ff00000\n\tv_mov_b32 v78, 0\n\tv_mov_b32 v79, 0x3ff00000\n\t"
+      "v_mov_b32 v80, 0\n\tv_mov_b32 v81, 0x3ff00000\n\tv_mov_b32 v82, 0\n\tv_mov_b32 v83, 0x3ff00000\n\tv_mov_b32 v84, 0\n\tv_mov_b32 v85, 0x3ff00000\n\tv_mov_b32 v86, 0\n\tv_mov_b32 v87, 0x3ff00000\n\t"
+      "s_mov_b32 s6, %0\n\t"
+      "1:\n\t"
+      "v_mul_f64 v[30:31], v[24:25], v[26:27]\n\t"
+      "v_fma_f64 v[30:31], v[26:27], v[28:29], v[30:31]\n\t"
+      "v_fma_f64 v[30:31], v[24:25], v[28:29], v[30:31]\n\t"
+      "v_mul_f64 v[30:31], v[30:31], v[28:29]\n\t"
+      "v_mul_f64 v[24:25], v[24:25], v[26:27]\n\t"
+      "v_fma_f64 v[24:25], v[28:29], v[26:27], v[24:25]\n\t"
+      "v_mul_f64 v[28:29], v[28:29], v[26:27]\n\t"
+      "v_fma_f64 v[28:29], v[30:31], v[26:27], v[28:29]\n\t"
+      "v_mul_f64 v[38:39], v[32:33], v[34:35]\n\t"
+      "v_fma_f64 v[38:39], v[34:35], v[36:37], v[38:39]\n\t"
+      "v_fma_f64 v[38:39], v[32:33], v[36:37], v[38:39]\n\t"
+      "v_mul_f64 v[38:39], v[38:39], v[36:37]\n\t"
+      "v_mul_f64 v[32:33], v[32:33], v[34:35]\n\t"
+      "v_fma_f64 v[32:33], v[36:37], v[34:35], v[32:33]\n\t"
+      "v_mul_f64 v[36:37], v[36:37], v[34:35]\n\t"
+      "v_fma_f64 v[36:37], v[38:39], v[34:35], v[36:37]\n\t"
+      "v_mul_f64 v[46:47], v[40:41], v[42:43]\n\t"
+      "v_fma_f64 v[46:47], v[42:43], v[44:45], v[46:47]\n\t"
+      "v_fma_f64 v[46:47], v[40:41], v[44:45], v[46:47]\n\t"
+      "v_mul_f64 v[46:47], v[46:47], v[44:45]\n\t"
+      "v_mul_f64 v[40:41], v[40:41], v[42:43]\n\t"
+      "v_fma_f64 v[40:41], v[44:45], v[42:43], v[40:41]\n\t"
+      "v_mul_f64 v[44:45], v[44:45], v[42:43]\n\t"
+      "v_fma_f64 v[44:45], v[46:47], v[42:43], v[44:45]\n\t"
+      "v_mul_f64 v[54:55], v[48:49], v[50:51]\n\t"
+      "v_fma_f64 v[54:55], v[50:51], v[52:53], v[54:55]\n\t"
+      "v_fma_f64 v[54:55], v[48:49], v[52:53], v[54:55]\n\t"
+      "v_mul_f64 v[54:55], v[54:55], v[52:53]\n\t"
+      "v_mul_f64 v[48:49], v[48:49], v[50:51]\n\t"
+      "v_fma_f64 v[48:49], v[52:53], v[50:51], v[48:49]\n\t"
+      "v_mul_f64 v[52:53], v[52:53], v[50:51]\n\t"
+      "v_fma_f64 v[52:53], v[54:55], v[50:51], v[52:53]\n\t"
+      "v_mul_f64 v[62:63], v[56:57], v[58:59]\n\t"
+      "v_fma_f64 v[62:63], v[58:59], v[60:61], v[62:63]\n\t"
+      "v_fma_f64 v[62:63], v[56:57], v[60:61], v[62:63]\n\t"
+      "v_mul_f64 v[62:63], v[62:63], v[60:61]\n\t"
+      "v_mul_f64 v[56:57], v[56:57], v[58:59]\n\t"
+      "v_fma_f64 v[56:57], v[60:61], v[58:59], v[56:57]\n\t"
+      "v_mul_f64 v[60:61], v[60:61], v[58:59]\n\t"
+      "v_fma_f64 v[60:61], v[62:63], v[58:59], v[60:61]\n\t"
+      "v_mul_f64 v[70:71], v[64:65], v[66:67]\n\t"
+      "v_fma_f64 v[70:71], v[66:67], v[68:69], v[70:71]\n\t"
+      "v_fma_f64 v[70:71], v[64:65], v[68:69], v[70:71]\n\t"
+      "v_mul_f64 v[70:71], v[70:71], v[68:69]\n\t"
+      "v_mul_f64 v[64:65], v[64:65], v[66:67]\n\t"
+      "v_fma_f64 v[64:65], v[68:69], v[66:67], v[64:65]\n\t"
+      "v_mul_f64 v[68:69], v[68:69], v[66:67]\n\t"
+      "v_fma_f64 v[68:69], v[70:71], v[66:67], v[68:69]\n\t"
+      "v_mul_f64 v[78:79], v[72:73], v[74:75]\n\t"
+      "v_fma_f64 v[78:79], v[74:75], v[76:77], v[78:79]\n\t"
+      "v_fma_f64 v[78:79], v[72:73], v[76:77], v[78:79]\n\t"
+      "v_mul_f64 v[78:79], v[78:79], v[76:77]\n\t"
+      "v_mul_f64 v[72:73], v[72:73], v[74:75]\n\t"
+      "v_fma_f64 v[72:73], v[76:77], v[74:75], v[72:73]\n\t"
+      "v_mul_f64 v[76:77], v[76:77], v[74:75]\n\t"
+      "v_fma_f64 v[76:77], v[78:79], v[74:75], v[76:77]\n\t"
+      "v_mul_f64 v[86:87], v[80:81], v[82:83]\n\t"
+      "v_fma_f64 v[86:87], v[82:83], v[84:85], v[86:87]\n\t"
+      "v_fma_f64 v[86:87], v[80:81], v[84:85], v[86:87]\n\t"
+      "v_mul_f64 v[86:87], v[86:87], v[84:85]\n\t"
+      "v_mul_f64 v[80:81], v[80:81], v[82:83]\n\t"
+      "v_fma_f64 v[80:81], v[84:85], v[82:83], v[80:81]\n\t"
+      "v_mul_f64 v[84:85], v[84:85], v[82:83]\n\t"
+      "v_fma_f64 v[84:85], v[86:87], v[82:83], v[84:85]\n\t"
+      "s_sub_u32 s6, s6, 1\n\t"
+      "s_cmp_lg_u32 s6, 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      :: "s"(iters) : "s6", "scc", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) cycles[0] = t1 - t0;
+}
+
 }  // namespace gklhip

@@ -81,6 +81,8 @@ def load_library(path: Optional[str] = None):
     lib.gklhip_num_devices.restype = C.c_int
     lib.gklhip_gather_backend.argtypes = [C.c_void_p]
     lib.gklhip_gather_backend.restype = C.c_int
+    lib.gklhip_measure_issue_ceiling.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.gklhip_measure_issue_ceiling.restype = C.c_int
     lib.gklhip_gather_note.argtypes = [C.c_void_p]
     lib.gklhip_gather_note.restype = C.c_char_p
     lib.gklhip_partition_reads.argtypes = [C.c_int32, _i64p, C.c_int32, C.POINTER(C.c_int32)]
@@ -239,6 +241,14 @@ class PairHmmContext:
         """none | peer | rccl (lazily created: before the first device-resident call, what it will try) |
         peer-after-rccl-failure (gather_note says why)"""
         return ("none", "peer", "rccl", "peer-after-rccl-failure")[self.lib.gklhip_gather_backend(self.handle)]
+
+    def issue_ceiling(self, use_double: bool = False, ms_budget: float = 50.0):
+        """(cells per second of the recurrence's bare instruction mix, sustained clock in GHz) -- diagnostics."""
+        cells, clk = C.c_double(0.0), C.c_double(0.0)
+        st = self.lib.gklhip_measure_issue_ceiling(self.handle, 1 if use_double else 0, float(ms_budget), C.byref(cells), C.byref(clk))
+        if st != OK:
+            _raise(self.lib, st)
+        return cells.value, clk.value
 
     @property
     def gather_note(self) -> str:

@@ -186,6 +186,13 @@ int gklhip_plan_describe(int32_t n_reads, int32_t n_haps, const int64_t* read_of
                          int32_t rows_per_lane, int32_t* lanes_out, int64_t lanes_cap, int32_t* n_groups_out,
                          int32_t* n_long_out);
 
+/* Diagnostics: the VALU issue ceiling of the forward recurrence's instruction mix on the context's first device -- a
+ * kernel of nothing but 4 multiplies + 4 fused multiply-adds per cell (fp32, or fp64 with use_double), operands placed
+ * so that no op stalls on a register bank, four wavefronts per SIMD on every CU, run for about ms_budget milliseconds.
+ * cells_per_s: cells of that mix per second (x 12 FLOP = the ceiling bench.py prints next to the vector peak);
+ * clock_ghz (may be NULL): shader cycles counted by the kernel / its duration = the clock sustained under that load. */
+int gklhip_measure_issue_ceiling(gklhip_ctx* ctx, int use_double, double ms_budget, double* cells_per_s, double* clock_ghz);
+
 const char* gklhip_strerror(int status);
 /* Thread-local detail message of the last failing call on this thread. */
 const char* gklhip_last_error(void);

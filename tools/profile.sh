@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace.err
-CMDS="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+CMDS="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras"
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM"; do

@@ -72,6 +72,32 @@ if main:
         w = c["SQ_WAVE_CYCLES"]
         md += ["", f"wave-cycle split: issuing {c['SQ_ACTIVE_INST_ANY']/w:.1%}, issue-stalled {c['SQ_WAIT_INST_ANY']/w:.1%}, "
                    f"waiting (waitcnt) {c['SQ_WAIT_ANY']/w:.1%}"]
+# ---- per dispatch: duration and GRBM_GUI_ACTIVE of the main kernel (why dispatches of the same work differ) ----
+if main:
+    per = defaultdict(dict)
+    for path in find("pmc*/**/*counter_collection.csv"):
+        for r in csv.DictReader(open(path)):
+            if r["Kernel_Name"] != main or r["Counter_Name"] not in ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+                continue
+            key = (path, r["Dispatch_Id"])
+            per[key][r["Counter_Name"]] = float(r["Counter_Value"])
+            per[key]["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    rows_d = [v for v in per.values() if "GRBM_GUI_ACTIVE" in v]
+    if rows_d:
+        md += ["", "## per dispatch (the PMC pass that holds GRBM_GUI_ACTIVE; the counter sums the 8 XCDs)", "",
+               "| dispatch | ms | GRBM_GUI_ACTIVE | clock GHz = GUI_ACTIVE / 8 / time | SQ_WAVE_CYCLES |", "|---|---|---|---|---|"]
+        for i, v in enumerate(rows_d):
+            md.append(f"| {i} | {v['ms']:.3f} | {v['GRBM_GUI_ACTIVE']:.5g} | {v['GRBM_GUI_ACTIVE'] / 8 / (v['ms'] * 1e-3) * 1e-9:.3f} | {v.get('SQ_WAVE_CYCLES', 0):.5g} |")
+        ms = [v["ms"] for v in rows_d]
+        cyc = [v["GRBM_GUI_ACTIVE"] for v in rows_d]
+        out["dispatch_ms_min_max"] = [min(ms), max(ms)]
+        out["gui_active_min_max"] = [min(cyc), max(cyc)]
+        out["effective_clock_ghz"] = sum(cyc) / 8 / (sum(ms) * 1e-3) * 1e-9
+        md += ["", f"time spread {min(ms):.3f}..{max(ms):.3f} ms ({max(ms) / min(ms) - 1:.1%}), busy-cycle spread "
+                   f"{max(cyc) / min(cyc) - 1:.1%}: what is left of the time spread after the cycle spread is clock (power management), "
+                   "the cycle spread itself is dispatch order / tail."]
+if main and "SQ_INSTS_VALU" in c:
+    out["valu_per_cell_note"] = "SQ_INSTS_VALU x 64 / cells_per_gpu of the bench line"
 json.dump(out, open(os.path.join(dst, "latest_pmc.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(md) + "\n")
