@@ -374,10 +374,12 @@ def main():
         step_ms = elapsed / a.steps * 1e3
         achieved = FLOP_PER_CELL * batch.cells / (k_ms * 1e-3) / 1e12
         traffic_profile = None
+        clock_profile = None
         pmc = os.path.join(ROOT, "profiles", "latest_pmc.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
+                clock_profile = round(j["effective_clock_ghz"], 3) if j.get("effective_clock_ghz") else None
                 traffic_profile = {"hbm_bytes_per_launch": j.get("hbm_bytes_per_launch"), "profile": j.get("tag", "profiles/latest_pmc.json"),
                                    "note": "from the committed rocprofv3 --pmc passes of this command (profiles/), not measured in this run"}
             except Exception:
@@ -413,7 +415,12 @@ def main():
                          # (gklhip_measure_issue_ceiling, measured in this run): the ceiling of any kernel with this arithmetic
                          "issue_ceiling_tflops": round(FLOP_PER_CELL * mix_cells_per_s / 1e12, 2) if mix_cells_per_s else None,
                          "frac_of_issue_ceiling": round(achieved / (FLOP_PER_CELL * mix_cells_per_s / 1e12), 4) if mix_cells_per_s else None,
-                         "issue_ceiling_clock_ghz": round(mix_clock_ghz, 3) if mix_clock_ghz else None,
+                         # the same ceiling as cycles per wave64 VALU instruction per SIMD if the chip held its 2.4 GHz peak
+                         # clock (8 instructions per cell, 1024 SIMDs x 64 lanes); 2.0 would be the datasheet rate
+                         "issue_ceiling_cycles_per_instr_at_2p4ghz": round(1024 * 64 * 2.4e9 / (8 * mix_cells_per_s), 3) if mix_cells_per_s else None,
+                         # GRBM_GUI_ACTIVE / 8 / time of this kernel in the committed PMC pass (profiles/<tag>_summary.md
+                         # lists it per dispatch): the clock the chip sustains under THIS kernel -- it clocks to its power budget
+                         "effective_clock_ghz_from_profile": clock_profile,
                          "note": "compute-bound recurrence priced at the dense fp32 (fp64 with --double) MFMA peak = the vector "
                                  "peak (SIMD-32: one wave64 FMA per 2 cycles); it has no contraction, so it runs on the vector ALUs "
                                  "and issues no MFMA. The recurrence needs 4 mul + 4 fma per cell (1.5 flop per instruction: 0.75 "

@@ -30,7 +30,7 @@ JNIEXPORT jint JNICALL Java_com_intel_gkl_smithwaterman_IntelSmithWaterman_align
     JNIEnv* env, jclass cls, jbyteArray ref, jbyteArray alt, jbyteArray cigar, jint match, jint mismatch, jint open,
     jint extend, jbyte strategy);
 
-/* NOT in the reference: the batch entry point a caller has to adopt for the GPU to pay off (DESIGN.md section 9).
+/* NOT in the reference: the batch entry point a caller has to adopt for the GPU to pay off (DESIGN.md section 7).
  *   private native static int alignBatchNative(byte[] refs, long[] refOffsets, byte[] alts, long[] altOffsets,
  *                                              byte[] cigars, int cigarStride, int[] offsets,
  *                                              int match, int mismatch, int open, int extend, byte strategy)

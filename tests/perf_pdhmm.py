@@ -65,7 +65,7 @@ def main():
                             "frac": round(12 * cc / best_k / 1e9 / 78.6, 4), "traffic": None,
                             "note": "fp64 vector recurrence (no contraction for MFMA), priced at the dense fp64 MFMA peak = "
                                     "fp64 vector peak; 2 wavefronts per SIMD (240 VGPRs); a plain step is 34 fp64 operations in "
-                                    "about 90 instructions, 12 flop per cell caps the fraction at 0.75 (DESIGN.md section 8)"}}
+                                    "about 90 instructions, 12 flop per cell caps the fraction at 0.75 (DESIGN.md section 7)"}}
     for name, b in cases.items():
         ctx.compute(b)
         best_k, best_w = 1e9, 1e9
