@@ -210,6 +210,8 @@ def in_library_probe(n_dev, reads, haps, workload, steps, warmup):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         res["device_resident"] = {"ms_per_step": round(dt * 1e3, 3), "gcups": round(b.cells / dt / 1e9, 1)}
+        res["gather"] = c.gather_backend          # after the calls: what really gathered (RCCL is created by the first one)
+        res["gather_note"] = c.gather_note
         with native.PairHmmContext(device=0) as one:
             ref = one.compute_device(db)
             torch.cuda.synchronize()

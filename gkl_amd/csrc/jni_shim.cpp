@@ -272,7 +272,12 @@ Slot* acquire_slot(JNIEnv* env) {
         continue;
       }
       s->gen = gen;
-      if (gen != g.gen) continue;  // re-configured meanwhile: the new slot (old arguments) is dropped
+      if (gen != g.gen) {  // re-configured meanwhile: the new slot (old arguments) is dropped -- outside the lock
+        lock.unlock();
+        s.reset();
+        lock.lock();
+        continue;
+      }
       s->busy = true;
       g.slots.push_back(std::move(s));
       return g.slots.back().get();
@@ -296,15 +301,6 @@ struct SlotLease {
     g.slot_free.notify_all();  // waiters differ (a caller that wants a slot, any number of them): wake all
   }
 };
-
-// Frees the slots no call is using (their device memory, streams, pinned arenas).  Busy ones are left alone.
-void trim_idle_slots(bool only_old_generations) {
-  std::vector<std::unique_ptr<Slot>> dead;
-  for (auto it = g.slots.begin(); it != g.slots.end();) {
-    if (!(*it)->busy && (!only_old_generations || (*it)->gen != g.gen)) { dead.push_back(std::move(*it)); it = g.slots.erase(it); }
-    else ++it;
-  }
-}
 
 }  // namespace
 
@@ -344,16 +340,24 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
   bool have_slot = false;
   for (auto& sl : g.slots) have_slot |= sl->gen == g.gen;
   if (g.ready && memcmp(&cfg, &g.cfg, sizeof cfg) == 0 && have_slot) { g.max_slots = max_slots; return; }
-  // the first slot is created here so that "no GPU" surfaces from initNative, like a failed dlopen would
+  // The first slot is created here so that "no GPU" surfaces from initNative, like a failed dlopen would -- but NOT
+  // under the lock: device and stream creation take milliseconds, and concurrent computeLikelihoodsNative callers
+  // pass through g.mu when they take and return their slots.
+  lock.unlock();
   std::unique_ptr<Slot> first(new (std::nothrow) Slot());
   const int st = first ? gklhip_init(&cfg, &first->ctx) : GKLHIP_ERR_OOM;
-  if (st != GKLHIP_OK) { lock.unlock(); throw_status(env, st); return; }
+  if (st != GKLHIP_OK) { throw_status(env, st); return; }
+  std::vector<std::unique_ptr<Slot>> dead;   // retired slots are destroyed after the lock is released
+  lock.lock();
   g.cfg = cfg;
   g.max_slots = max_slots;
-  first->gen = ++g.gen;
+  first->gen = ++g.gen;   // (two racing initNative calls: the later one's generation wins, the other's slot retires like any old one)
   g.slots.push_back(std::move(first));
   g.ready = true;
-  trim_idle_slots(/*only_old_generations=*/true);
+  for (auto it = g.slots.begin(); it != g.slots.end();) {
+    if (!(*it)->busy && (*it)->gen != g.gen) { dead.push_back(std::move(*it)); it = g.slots.erase(it); }
+    else ++it;
+  }
   lock.unlock();
   g.slot_free.notify_all();
 }
@@ -504,8 +508,14 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv
   // The reference's doneNative is empty (IntelPairHmm.cc:189-192): other IntelPairHmm instances of the JVM keep
   // working after one of them closes.  Here it releases what no call is using (device memory, pinned arenas) and
   // keeps the configuration, so a later call simply gets a fresh slot.
-  std::lock_guard<std::mutex> lock(g.mu);
-  trim_idle_slots(/*only_old_generations=*/false);
+  std::vector<std::unique_ptr<Slot>> dead;   // destroyed (streams synchronised, buffers freed) after the lock is released
+  {
+    std::lock_guard<std::mutex> lock(g.mu);
+    for (auto it = g.slots.begin(); it != g.slots.end();) {
+      if (!(*it)->busy) { dead.push_back(std::move(*it)); it = g.slots.erase(it); }
+      else ++it;
+    }
+  }
 }
 
 }  // extern "C"

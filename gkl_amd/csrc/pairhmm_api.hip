@@ -840,15 +840,24 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
 }
 
 // Host threads of the reference-exact finalisation.  maxNumberOfThreads caps the OpenMP compute threads of the
-// reference (IntelPairHmm.cc:72-89); here the compute is on the device and the only host work is log10f/log10 over
-// the results, so the value 1 (GATK's and the non-OpenMP build's default) means "not set": min(cores, 8) threads,
-// overridable with GKL_HIP_FINALIZE_THREADS.  Values > 1 are honoured as given.
-int finalize_threads(const DevCtx* c) {
+// reference's OMP build and is ignored by its plain build (IntelPairHmm.cc:72-89, IntelPairHmm.java:114-118); here the
+// compute is on the device and the only host work is log10f/log10 over the results.  A value > 1 is honoured as given.
+// The value 1 (GATK's default) means "not set": the host-buffer calls in flight in this process SHARE a budget of
+// min(cores, 8) threads -- one call alone takes all of it, the two engines of a pipelined or twin-engine call half each,
+// eight concurrent JNI slots one each -- so the process never runs more than that many finaliser threads at a time,
+// however many slots and engines exist.  GKL_HIP_FINALIZE_THREADS overrides (per call).
+std::atomic<int> g_host_calls_in_flight{0};
+struct HostCallInFlight {
+  int share;
+  HostCallInFlight() : share(g_host_calls_in_flight.fetch_add(1) + 1) {}
+  ~HostCallInFlight() { g_host_calls_in_flight.fetch_sub(1); }
+};
+int finalize_threads(const DevCtx* c, int share) {
   static const int env = [] { const char* v = getenv("GKL_HIP_FINALIZE_THREADS"); return v ? atoi(v) : 0; }();
   if (env > 0) return env;
   const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
   int threads = c->cfg.max_threads;
-  if (threads <= 1) threads = std::min(hw, 8);
+  if (threads <= 1) threads = std::max(1, std::min(hw, 8) / std::max(1, share));
   return std::max(1, std::min(threads, 64));
 }
 
@@ -896,7 +905,8 @@ int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
   // as the policy has run, so in a big call the host finalises them WHILE the fp64 recomputation pass runs; only the
   // recomputed pairs are left for after the last kernel (their words are rewritten in place by finalize64_kernel;
   // the early pass skips every word that is not fp32-tagged, whatever it holds at that moment).
-  const int threads = finalize_threads(c);
+  const HostCallInFlight in_flight;
+  const int threads = finalize_threads(c, in_flight.share);
   HostFinalizer fin;
   if ((rc = run_device(c, &db, pin_out, kModePacked, s, inline_inputs))) return rc;  // records policy_done
   if (c->cfg.use_double || n_pairs <= kOnePassPairs) {

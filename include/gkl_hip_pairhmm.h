@@ -79,8 +79,8 @@ typedef struct {
   int32_t record_events;/* 1 = bracket kernels with HIP events and synchronise every call (gklhip_get_stats);
                            2 = record into a ring of 64 event sets WITHOUT synchronising: calls pipeline, the
                                times are read afterwards with gklhip_get_step_times */
-  int32_t rows_per_lane;/* fp32 main kernel: 0 = auto (8 rows per lane; 4 for small batches), 8 = 8-row kernel,
-                           4 = 4-row kernel */
+  int32_t rows_per_lane;/* fp32 main kernel: 0 = auto (8 rows per lane; 4 or 2 for small batches), 8 = 8-row kernel,
+                           4 (or -4) = 4-row kernel, 2 = 2-row kernel when every read has at most 127 bases, else 4 */
 } gklhip_config;
 
 /* Flat structure-of-arrays batch. Offsets always live on the host; the byte
