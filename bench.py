@@ -358,6 +358,14 @@ def main():
             single_ms = _median_ms(one_call, 5, 1)
             pst = probe.stats()
             st["n_fallback"] = pst["n_fallback"]   # needs a synchronising call: outside the timed region
+            # cells of the pairs the policy sent to the fp64 pass (flags of the probe call, read back outside the timed region)
+            try:
+                _, _, used = probe.raw(batch.n_pairs)
+                flagged = used.reshape(batch.n_reads, batch.n_haps).astype(np.int64)
+                cells_fp64 = int(batch.read_lens.astype(np.int64) @ flagged @ batch.hap_lens.astype(np.int64))
+                mix64_cells_per_s = None if a.double else probe.issue_ceiling(use_double=True, ms_budget=30.0)[0]
+            except Exception:
+                cells_fp64, mix64_cells_per_s = None, None
             # the chip's issue ceiling for the recurrence's bare instruction mix (4 mul + 4 fma per cell, bank-clean
             # operands, four wavefronts per SIMD) and the clock it sustains there: 50 ms, outside the timed region
             try:
@@ -428,6 +436,14 @@ def main():
                                  "and issues no MFMA. The recurrence needs 4 mul + 4 fma per cell (1.5 flop per instruction: 0.75 "
                                  "of peak at best) and a SIMD issues one such op per ~2.3 cycles, not 2: issue_ceiling_tflops is "
                                  "that bound, measured in this run (DESIGN.md section 3)"},
+            # the second kernel of a step, priced the same way: the packed fp64 recomputation of the flagged pairs
+            "fallback_pass": None if (a.double or not cells_fp64 or fb_ms <= 0) else {
+                "kernel": "pairhmm_fwd_jobs_kernel<double, 10>", "cells": cells_fp64, "kernel_ms": round(fb_ms, 3),
+                "kernel_gcups": round(cells_fp64 / fb_ms / 1e6, 1),
+                "achieved": round(FLOP_PER_CELL * cells_fp64 / (fb_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_VECTOR_TFLOPS / 2,
+                "unit": "TFLOP/s", "frac": round(FLOP_PER_CELL * cells_fp64 / (fb_ms * 1e-3) / 1e12 / (PEAK_FP32_VECTOR_TFLOPS / 2), 4),
+                "issue_ceiling_tflops": round(FLOP_PER_CELL * mix64_cells_per_s / 1e12, 2) if mix64_cells_per_s else None,
+                "frac_of_issue_ceiling": round(cells_fp64 / (fb_ms * 1e-3) / mix64_cells_per_s, 4) if mix64_cells_per_s else None},
             "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(fb_ms, 3),
                            "device_total": round(dev_ms, 3), "from": kernel_times_from},
             # what a step costs beyond its two forward kernels (planning, policy, log10, launches, gaps); with
@@ -478,6 +494,33 @@ def main():
                 res["small_batch"] = {"c1_100x10": host_call_record(native, c1, dev_index, calls=60, warm=30),
                                       f"eighth_{eighth.n_reads}x{eighth.n_haps}": host_call_record(native, eighth, dev_index, calls=20, warm=10),
                                       "note": "through gklhip_compute, back-to-back single calls, median"}
+                try:
+                    # the 8-GPU strong-scaling step on one GPU: an eighth of the batch, device-resident, pipelined -- on one
+                    # stream, and on two streams through ONE context (the library gives each stream an engine) and through two
+                    deighth = native.DeviceBatch.upload(eighth, dev)
+                    def shard_steps(ctxs_, streams_, n=200, warm=30):
+                        outs_ = [torch.empty(eighth.n_pairs, dtype=torch.float64, device=dev) for _ in streams_]
+                        def go(k):
+                            with torch.cuda.stream(streams_[k % len(streams_)]):
+                                ctxs_[k % len(ctxs_)].compute_device(deighth, outs_[k % len(outs_)], streams_[k % len(streams_)])
+                        for k in range(warm):
+                            go(k)
+                        torch.cuda.synchronize(dev)
+                        t1 = time.perf_counter()
+                        for k in range(n):
+                            go(k)
+                        torch.cuda.synchronize(dev)
+                        return round((time.perf_counter() - t1) / n * 1e3, 4)
+                    ss = [torch.cuda.Stream(dev) for _ in range(2)]
+                    with native.PairHmmContext(device=dev_index) as ca, native.PairHmmContext(device=dev_index) as cb:
+                        res["small_batch"]["eighth_device_resident"] = {
+                            "one_stream_ms_per_step": shard_steps([ca], ss[:1]),
+                            "two_streams_one_context_ms_per_step": shard_steps([ca], ss),
+                            "two_contexts_ms_per_step": shard_steps([ca, cb], ss),
+                            "note": "what one rank of an 8-GPU strong-scaling run does per step (before the gather); bench.py --gpus N "
+                                    "alternates two contexts per rank"}
+                except Exception as e:
+                    res["small_batch"]["eighth_device_resident"] = {"error": repr(e)}
                 try:
                     jrec, conc = jni_records(batch, c1, res["host_path"]["max_threads_1"]["ms_per_call"])
                     res["jni_path"] = jrec

@@ -1065,6 +1065,17 @@ struct gklhip_ctx {
   std::vector<ncclComm_t> comms;
   hipEvent_t inputs_ready = nullptr;                 // device 0: the caller's stream has reached this call
   std::vector<hipEvent_t> shard_done;                // [n_dev]: device d's results have landed on device 0
+  // Second engine per device for the device-resident entry point: a caller that issues consecutive calls on TWO streams
+  // (what bench.py does per rank for N > 1: the tail and the planning kernel of one step run under the next step's
+  // kernels, 1.91 -> 1.69 ms per eighth-shard step) gets an engine per stream, so the calls do not wait for each other's
+  // scratch.  Created by the first call that arrives on another stream than the previous one (GKL_HIP_DEVICE_ENGINES=1:
+  // never); a caller with one stream never pays for it.
+  std::vector<DevCtx*> dev_alt;
+  hipEvent_t inputs_ready_alt = nullptr;
+  std::vector<hipEvent_t> shard_done_alt;
+  hipStream_t stream_of[2] = {nullptr, nullptr};     // the caller stream each engine set served last
+  bool used_set[2] = {false, false};
+  int last_set = 0;
   gklhip_stats stats;
   int32_t last_reads = 0, last_haps = 0;
   ~gklhip_ctx() {
@@ -1073,7 +1084,11 @@ struct gklhip_ctx {
       if (comms[d]) { (void)hipSetDevice(dev[d]->device); (void)g_rccl.CommDestroy(comms[d]); }
     for (size_t d = 0; d < shard_done.size(); d++)
       if (shard_done[d]) { (void)hipSetDevice(dev[d]->device); (void)hipEventDestroy(shard_done[d]); }
+    for (size_t d = 0; d < shard_done_alt.size(); d++)
+      if (shard_done_alt[d]) { (void)hipSetDevice(dev[d]->device); (void)hipEventDestroy(shard_done_alt[d]); }
     if (inputs_ready) { (void)hipSetDevice(dev[0]->device); (void)hipEventDestroy(inputs_ready); }
+    if (inputs_ready_alt) { (void)hipSetDevice(dev[0]->device); (void)hipEventDestroy(inputs_ready_alt); }
+    for (DevCtx* d : dev_alt) dev_done(d);
     for (DevCtx* d : dev) dev_done(d);
     for (DevCtx* d : twins) dev_done(d);
   }
@@ -1204,19 +1219,24 @@ void rccl_lazy_init(gklhip_ctx* c) {
   c->use_rccl = true;
 }
 
-int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev, int mode, hipStream_t s) {
-  const int n = (int)c->dev.size();
+int multi_compute_device(gklhip_ctx* c, int set, const gklhip_batch* db, double* out_dev, int mode, hipStream_t s) {
+  const std::vector<DevCtx*>& devs = set ? c->dev_alt : c->dev;
+  const std::vector<hipEvent_t>& shard_done = set ? c->shard_done_alt : c->shard_done;
+  hipEvent_t inputs_ready = set ? c->inputs_ready_alt : c->inputs_ready;
+  const int n = (int)devs.size();
   rccl_lazy_init(c);
   const bool use_rccl = c->use_rccl;
   c->bounds.assign((size_t)n + 1, 0);
   partition_reads(db->n_reads, db->read_off, n, c->bounds.data());
-  DevCtx* root = c->dev[0];
+  DevCtx* root = devs[0];
   HIP_TRY(hipSetDevice(root->device));
-  HIP_TRY(hipEventRecord(c->inputs_ready, s));
+  HIP_TRY(hipEventRecord(inputs_ready, s));
   const int n_haps = db->n_haps;
   const size_t hl = (size_t)db->hap_off[n_haps];
+  const std::vector<DevCtx*>* dp = &devs;
+  const std::vector<hipEvent_t>* sdp = &shard_done;
   int rc = for_each_shard(c, n, [=](int d) -> int {
-    DevCtx* dc = c->dev[(size_t)d];
+    DevCtx* dc = (*dp)[(size_t)d];
     const gklhip_batch v = shard_view(c, db, d);
     if (d == 0) return run_device(dc, &v, out_dev, mode, s, false);
     HIP_TRY(hipSetDevice(dc->device));
@@ -1226,7 +1246,7 @@ int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev,
     if ((r = dc->batch_dev.reserve(5 * stride + align_up(hl)))) return r;
     if ((r = dc->out_dev.reserve((size_t)v.n_reads * n_haps * 8))) return r;
     unsigned char* dst = dc->batch_dev.as<unsigned char>();
-    HIP_TRY(hipStreamWaitEvent(sd, c->inputs_ready, 0));
+    HIP_TRY(hipStreamWaitEvent(sd, inputs_ready, 0));
     const uint8_t* srcs[5] = {v.read_bases, v.read_quals, v.ins_gop, v.del_gop, v.gcp};
     for (int i = 0; i < 5; i++)
       HIP_TRY(hipMemcpyPeerAsync(dst + i * stride, dc->device, srcs[i], root->device, rl, sd));
@@ -1238,7 +1258,7 @@ int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev,
     if (!use_rccl) {
       HIP_TRY(hipMemcpyPeerAsync(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, root->device, dc->out_dev.p, dc->device,
                                  (size_t)v.n_reads * n_haps * 8, sd));
-      HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], sd));
+      HIP_TRY(hipEventRecord((*sdp)[(size_t)d], sd));
     }
     return GKLHIP_OK;
   });
@@ -1259,7 +1279,7 @@ int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev,
           for (int d = 1; d < n && bad == ncclSuccess; d++) {
             const size_t cnt = (size_t)(c->bounds[(size_t)d + 1] - c->bounds[(size_t)d]) * n_haps;
             if (!cnt) continue;
-            r = g_rccl.Send(c->dev[(size_t)d]->out_dev.p, cnt, ncclDouble, 0, c->comms[(size_t)d], c->dev[(size_t)d]->stream);
+            r = g_rccl.Send(devs[(size_t)d]->out_dev.p, cnt, ncclDouble, 0, c->comms[(size_t)d], devs[(size_t)d]->stream);
             if (r != ncclSuccess) { bad = r; what = "ncclSend"; break; }
             r = g_rccl.Recv(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, cnt, ncclDouble, d, c->comms[0], s);
             if (r != ncclSuccess) { bad = r; what = "ncclRecv"; }
@@ -1273,26 +1293,26 @@ int multi_compute_device(gklhip_ctx* c, const gklhip_batch* db, double* out_dev,
     if (why.empty()) {
       for (int d = 1; d < n; d++)
         if (c->bounds[(size_t)d + 1] > c->bounds[(size_t)d]) {
-          HIP_TRY(hipSetDevice(c->dev[(size_t)d]->device));
-          HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], c->dev[(size_t)d]->stream));
+          HIP_TRY(hipSetDevice(devs[(size_t)d]->device));
+          HIP_TRY(hipEventRecord(shard_done[(size_t)d], devs[(size_t)d]->stream));
         }
     } else {
       rccl_give_up(c, why);
       for (int d = 1; d < n; d++) {
         const size_t cnt = (size_t)(c->bounds[(size_t)d + 1] - c->bounds[(size_t)d]) * n_haps;
         if (!cnt) continue;
-        DevCtx* dc = c->dev[(size_t)d];
+        DevCtx* dc = devs[(size_t)d];
         HIP_TRY(hipSetDevice(dc->device));
         HIP_TRY(hipMemcpyPeerAsync(out_dev + (int64_t)c->bounds[(size_t)d] * n_haps, root->device, dc->out_dev.p, dc->device, cnt * 8, dc->stream));
-        HIP_TRY(hipEventRecord(c->shard_done[(size_t)d], dc->stream));
+        HIP_TRY(hipEventRecord(shard_done[(size_t)d], dc->stream));
       }
     }
   }
   HIP_TRY(hipSetDevice(root->device));
   if (rc == GKLHIP_OK)
     for (int d = 1; d < n; d++)
-      if (c->bounds[(size_t)d + 1] > c->bounds[(size_t)d]) HIP_TRY(hipStreamWaitEvent(s, c->shard_done[(size_t)d], 0));
-  merge_stats(c, c->dev);
+      if (c->bounds[(size_t)d + 1] > c->bounds[(size_t)d]) HIP_TRY(hipStreamWaitEvent(s, shard_done[(size_t)d], 0));
+  merge_stats(c, devs);
   return rc;
 }
 
@@ -1465,15 +1485,45 @@ int gklhip_compute_device(gklhip_ctx* c, const gklhip_batch* dev_batch, double* 
   if (mode != GKLHIP_FINALIZE_DEVICE_F64 && mode != GKLHIP_FINALIZE_DEVICE_REF32) mode = GKLHIP_FINALIZE_DEVICE_F64;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);  // NULL = HIP's default stream
   c->last_reads = dev_batch->n_reads; c->last_haps = dev_batch->n_haps;
-  if (c->dev.size() == 1 || (int64_t)dev_batch->n_reads * dev_batch->n_haps == 0) {
-    c->bounds.assign(c->dev.size() + 1, dev_batch->n_reads);
+  // which engine set: the one that served this stream last; a call on a NEW stream while the other set is busy with
+  // another stream's work takes (first: creates) the second set
+  int set = 0;
+  static const bool one_engine = [] { const char* v = getenv("GKL_HIP_DEVICE_ENGINES"); return v && atoi(v) == 1; }();
+  if (!one_engine && c->used_set[0] && c->stream_of[0] != s && c->cfg.record_events == 0) {
+    if (c->used_set[1] && c->stream_of[1] != s) set = 1 - c->last_set;   // a third stream: the set used longest ago
+    else set = 1;
+    if (set == 1 && c->dev_alt.empty()) {
+      int ndev = 0;
+      HIP_TRY(hipGetDeviceCount(&ndev));
+      std::vector<DevCtx*> made;
+      for (DevCtx* d : c->dev) {
+        DevCtx* twin = nullptr;
+        if (dev_init(d->cfg, d->device, ndev, &twin) != GKLHIP_OK) break;   // e.g. out of memory: stay with one set
+        made.push_back(twin);
+      }
+      bool ok = made.size() == c->dev.size();
+      if (ok && c->dev.size() > 1) {
+        c->shard_done_alt.assign(c->dev.size(), nullptr);
+        ok = hipSetDevice(c->dev[0]->device) == hipSuccess && hipEventCreateWithFlags(&c->inputs_ready_alt, hipEventDisableTiming) == hipSuccess;
+        for (size_t d = 1; ok && d < c->dev.size(); d++)
+          ok = hipSetDevice(c->dev[d]->device) == hipSuccess && hipEventCreateWithFlags(&c->shard_done_alt[d], hipEventDisableTiming) == hipSuccess;
+        (void)hipSetDevice(c->dev[0]->device);
+      }
+      if (ok) c->dev_alt = made;
+      else { for (DevCtx* d : made) dev_done(d); (void)hipGetLastError(); set = 0; }
+    }
+  }
+  c->stream_of[set] = s; c->used_set[set] = true; c->last_set = set;
+  const std::vector<DevCtx*>& devs = set ? c->dev_alt : c->dev;
+  if (devs.size() == 1 || (int64_t)dev_batch->n_reads * dev_batch->n_haps == 0) {
+    c->bounds.assign(devs.size() + 1, dev_batch->n_reads);
     c->bounds[0] = 0;
-    rc = run_device(c->dev[0], dev_batch, out_dev, mode, s, false);
-    c->stats = c->dev[0]->stats;
-    c->last = &c->dev;
+    rc = run_device(devs[0], dev_batch, out_dev, mode, s, false);
+    c->stats = devs[0]->stats;
+    c->last = &devs;
     return rc;
   }
-  return multi_compute_device(c, dev_batch, out_dev, mode, s);
+  return multi_compute_device(c, set, dev_batch, out_dev, mode, s);
 }
 
 int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {

@@ -131,6 +131,36 @@ def test_config4_batch_through_eight_shards_bit_exact(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_one_context_serves_two_streams_with_an_engine_each(oracle, devices):
+    """Consecutive device-resident calls on two streams through ONE context run on two engine sets (the second is
+    created by the first call that arrives on another stream), so they overlap instead of waiting for each other's
+    scratch; results stay bit-identical, also when a third stream shows up and when the batch changes between calls."""
+    import torch
+    from gkl_amd import native
+    b1 = make_batch("hc", 500, 24, seed=41)
+    b2 = make_batch("hc", 300, 16, seed=42)
+    d1, d2 = native.DeviceBatch.upload(b1, "cuda:0"), native.DeviceBatch.upload(b2, "cuda:0")
+    kw = dict(devices=devices) if devices else dict(device=0)
+    with native.PairHmmContext(device=0) as one, native.PairHmmContext(**kw) as c:
+        r1, r2 = one.compute_device(d1).clone(), one.compute_device(d2).clone()
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream("cuda:0") for _ in range(3)]
+        outs = [(k, torch.full((b1.n_pairs if k % 2 == 0 else b2.n_pairs,), float("nan"), dtype=torch.float64, device="cuda:0"))
+                for k in range(9)]
+        torch.cuda.synchronize()
+        for k, out in outs:
+            st = streams[k % 2] if k < 6 else streams[k % 3]
+            with torch.cuda.stream(st):
+                c.compute_device(d1 if k % 2 == 0 else d2, out, st)
+        torch.cuda.synchronize()
+        for k, out in outs:
+            assert torch.equal(out, r1 if k % 2 == 0 else r2), k
+        # and the host path of the same context still answers like the oracle
+        assert np.array_equal(bits(c.compute(b2)), bits(oracle.batch(b2, n_threads=8)))
+
+
+@pytest.mark.gpu
 def test_jni_path_shards_over_the_device_list(oracle, monkeypatch):
     # computeLikelihoodsNative itself scales: GKL_HIP_DEVICES is read by initNative
     monkeypatch.setenv("GKL_HIP_DEVICES", "0,0")
