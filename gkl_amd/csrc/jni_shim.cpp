@@ -418,7 +418,8 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
       b.del_gop = a.del.p; b.gcp = a.gcp.p; b.hap_bases = sl->hap_bases.p;
       return b;
     };
-    static const int64_t pipeline_from = [] { const char* v = getenv("GKL_HIP_JNI_PIPELINE_PAIRS"); return v && *v ? atoll(v) : 262144LL; }();
+    const char* pv = getenv("GKL_HIP_JNI_PIPELINE_PAIRS");   // (read per call: tests switch it)
+    const int64_t pipeline_from = pv && *pv ? atoll(pv) : 262144LL;
     if (n_pairs < pipeline_from || n_reads < 64 || pipeline_from <= 0) {
       // ---- one shot (a GATK active region): marshal, compute, write back ----
       if (!marshal_reads(sl->whole, 0, n_reads)) return;
@@ -447,7 +448,8 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
       sl->pipe->start(sl->ctx);
       if (sl->ctx2) sl->pipe->start(sl->ctx2);
     }
-    static const int64_t range_pairs = [] { const char* v = getenv("GKL_HIP_JNI_RANGE_PAIRS"); return v && atoll(v) > 0 ? atoll(v) : 150000LL; }();
+    const char* rv = getenv("GKL_HIP_JNI_RANGE_PAIRS");
+    const int64_t range_pairs = rv && atoll(rv) > 0 ? atoll(rv) : 150000LL;
     const int n_ranges = (int)std::max<int64_t>(2, std::min<int64_t>(32, (n_pairs + range_pairs - 1) / range_pairs));
     while ((int)sl->ranges.size() < n_ranges) sl->ranges.emplace_back(new ReadArena());
     sl->tasks.assign((size_t)n_ranges, RangeTask());

@@ -205,3 +205,36 @@ def test_jni_onload_with_a_device(monkeypatch):
 def test_utils_library_with_a_device():
     # isAvxSupported / isAvx2Supported -> true on the GPU box (what IntelPairHmm.load() gates on)
     _check_utils_library(True)
+
+
+@pytest.mark.gpu
+def test_jni_pipelined_big_call_path_bit_exact_and_error_safe(oracle, monkeypatch):
+    """Big calls are pipelined: read ranges are marshalled on the calling thread while earlier ranges compute on the
+    slot's two engines (jni_shim.cpp).  Forced here on a small batch (GKL_HIP_JNI_PIPELINE_PAIRS / _RANGE_PAIRS): results
+    bit-identical to the oracle with 2..16 ranges, both precisions; a holder error in the first range and a too-short
+    likelihood array raise the same exceptions as the one-shot path, with ranges in flight or not, and leave the
+    library usable."""
+    b = make_batch("hc", 400, 24, seed=77)
+    exp = oracle.batch(b, n_threads=8)
+    expd = oracle.batch(b, use_double=True, n_threads=8)
+    monkeypatch.setenv("GKL_HIP_JNI_PIPELINE_PAIRS", "1")
+    for rp in ("600", "2400", "4800"):   # 16, 4 and 2 ranges
+        monkeypatch.setenv("GKL_HIP_JNI_RANGE_PAIRS", rp)
+        rc, out, cls, msg, refs = mockjni.run(b)
+        assert rc == 0, (cls, msg)
+        assert out.tobytes() == exp.tobytes(), rp
+        assert refs[2] == 0 and refs[3] <= 16, (msg, refs)     # -Xcheck:jni rules hold in the pipelined loop too
+    rc, out, cls, msg, _ = mockjni.run(b, use_double=True)
+    assert rc == 0 and out.tobytes() == expd.tobytes()
+    for flags in (mockjni.NULL_READQUALS, mockjni.SHORT_QUALS, mockjni.NULL_READ_ELEMENT):
+        rc, _, cls, msg, refs = mockjni.run(b, flags=flags)
+        assert rc == 2 and cls == "java/lang/IllegalArgumentException", (flags, cls, msg)
+        assert refs[2] == 0, msg
+    rc, _, cls, msg, _ = mockjni.run(b, out_len=b.n_pairs - 1)
+    assert rc == 2 and cls == "java/lang/IllegalArgumentException"
+    rc, out, cls, msg, _ = mockjni.run(b)
+    assert rc == 0 and out.tobytes() == exp.tobytes()
+    # several Java threads, every one pipelining through its own slot
+    rc, out, cls, msg, _ = mockjni.run_concurrent(b, 3, iters=3)
+    assert rc == 0, (cls, msg)
+    assert out.tobytes() == exp.tobytes()
