@@ -40,6 +40,20 @@ def test_bench_line_single_gpu():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert "error" not in d["two_callers"] and d["two_callers"]["ms_per_step"] > 0
     assert "extras_error" not in d
+    # the ceiling in numbers: issue rate of the recurrence's bare instruction mix, measured in the same run
+    assert r["issue_ceiling_tflops"] > r["achieved"] and abs(r["frac_of_issue_ceiling"] - r["achieved"] / r["issue_ceiling_tflops"]) < 2e-3
+    assert 1.9 < r["issue_ceiling_cycles_per_instr_at_2p4ghz"] < 4.0
+    fp = d["fallback_pass"]
+    assert fp and 0 < fp["frac"] < 1 and fp["cells"] > 0 and fp["issue_ceiling_tflops"] > fp["achieved"]
+    # computeLikelihoodsNative itself (mock JNIEnv): per-call time and its split; concurrent small callers
+    j = d["jni_path"]
+    assert "error" not in j, j
+    for k in ("c2", "c1"):
+        assert j[k]["ms_per_call"] > 0 and j[k]["marshal_ms"] >= 0 and j[k]["compute_wait_ms"] >= 0 and j[k]["writeback_ms"] >= 0
+    conc = d["small_batch"]["concurrent"]
+    assert all(conc[f"callers_{n}"]["aggregate_gcups"] > 0 for n in (1, 4, 16))
+    er = d["small_batch"]["eighth_device_resident"]
+    assert "error" not in er and er["two_streams_one_context_ms_per_step"] > 0
 
 
 @pytest.mark.gpu
