@@ -160,8 +160,28 @@ def set_b():
     variant("32 fma_f64 + 32 v_and_b32 alternating", sum([[f"v_fma_f64 {P(0,i%8)}, {P(0,i%8)}, v[2:3], v[6:7]", f"v_and_b32 v{acc(0,i%8,56)}, v{acc(0,i%8,56)}, v1"] for i in range(32)], []))
 
 
+
+def set_c():
+    """third round: compare + select costs (the PDHMM match predicate)"""
+    A = lambda i: acc(0, i % 8)
+    B = lambda i: acc(1, i % 8)
+    Cc = lambda i: acc(2, i % 8)
+    variant("cmp_e32 -> vcc ; 2 cndmask_e32 (vcc)", sum([[f"v_cmp_lt_u32 vcc, v1, v{A(i)}", f"v_cndmask_b32 v{B(i)}, v{B(i)}, v2, vcc", f"v_cndmask_b32 v{Cc(i)}, v{Cc(i)}, v3, vcc"] for i in range(21)], []))
+    variant("cmp_e64 -> s[8:9] ; 2 cndmask_e64", sum([[f"v_cmp_lt_u32_e64 s[8:9], v1, v{A(i)}", f"v_cndmask_b32_e64 v{B(i)}, v{B(i)}, v2, s[8:9]", f"v_cndmask_b32_e64 v{Cc(i)}, v{Cc(i)}, v3, s[8:9]"] for i in range(21)], []))
+    variant("cmp_e32 only", [f"v_cmp_lt_u32 vcc, v1, v{A(i)}" for i in range(64)])
+    variant("cmp_e64 only", [f"v_cmp_lt_u32_e64 s[8:9], v1, v{A(i)}" for i in range(64)])
+    variant("cndmask_e32 only (vcc set once before the loop)", [f"v_cndmask_b32 v{B(i)}, v{B(i)}, v2, vcc" for i in range(64)])
+    variant("and + cmp_e32 + 2 cndmask_e32 (the predicate, vcc)", sum([[f"v_and_b32 v{A(i)}, v1, v{Cc(i)}", f"v_cmp_lt_u32 vcc, v2, v{A(i)}", f"v_cndmask_b32 v{B(i)}, v{B(i)}, v2, vcc", f"v_cndmask_b32 v{B(i)+1}, v{B(i)+1}, v3, vcc"] for i in range(16)], []))
+    variant("and + cmp_e64 + 2 cndmask_e64 (the predicate, sgpr pair)", sum([[f"v_and_b32 v{A(i)}, v1, v{Cc(i)}", f"v_cmp_lt_u32_e64 s[8:9], v2, v{A(i)}", f"v_cndmask_b32_e64 v{B(i)}, v{B(i)}, v2, s[8:9]", f"v_cndmask_b32_e64 v{B(i)+1}, v{B(i)+1}, v3, s[8:9]"] for i in range(16)], []))
+    variant("bfe_i32 + 2 bfi (mask select)", sum([[f"v_bfe_i32 v{A(i)}, v1, v{Cc(i)}, 1", f"v_bfi_b32 v{B(i)}, v{A(i)}, v2, v{B(i)}", f"v_bfi_b32 v{B(i)+1}, v{A(i)}, v3, v{B(i)+1}"] for i in range(21)], []))
+    P = lambda b, i, base=24: f"v[{base+8*(i%8)+2*b}:{base+8*(i%8)+2*b+1}]"
+    variant("fma_f64 x3 + predicate(vcc) per 'row'", sum([[f"v_fma_f64 {P(0,i)}, {P(0,i)}, v[2:3], v[6:7]", f"v_and_b32 v{88+(i%8)}, v1, v{96+(i%8)}", f"v_fma_f64 {P(1,i)}, {P(1,i)}, v[2:3], v[6:7]", f"v_cmp_lt_u32 vcc, v2, v{88+(i%8)}", f"v_fma_f64 {P(2,i)}, {P(2,i)}, v[2:3], v[6:7]", f"v_cndmask_b32 v{104+(i%8)}, v{104+(i%8)}, v2, vcc", f"v_cndmask_b32 v{112+(i%4)}, v{112+(i%4)}, v3, vcc"] for i in range(9)], []))
+    variant("fma_f64 x3 + predicate(sgpr) per 'row'", sum([[f"v_fma_f64 {P(0,i)}, {P(0,i)}, v[2:3], v[6:7]", f"v_and_b32 v{88+(i%8)}, v1, v{96+(i%8)}", f"v_fma_f64 {P(1,i)}, {P(1,i)}, v[2:3], v[6:7]", f"v_cmp_lt_u32_e64 s[8:9], v2, v{88+(i%8)}", f"v_fma_f64 {P(2,i)}, {P(2,i)}, v[2:3], v[6:7]", f"v_cndmask_b32_e64 v{104+(i%8)}, v{104+(i%8)}, v2, s[8:9]", f"v_cndmask_b32_e64 v{112+(i%4)}, v{112+(i%4)}, v3, s[8:9]"] for i in range(9)], []))
+    variant("fma_f64 x3 only (27)", sum([[f"v_fma_f64 {P(0,i)}, {P(0,i)}, v[2:3], v[6:7]", f"v_fma_f64 {P(1,i)}, {P(1,i)}, v[2:3], v[6:7]", f"v_fma_f64 {P(2,i)}, {P(2,i)}, v[2:3], v[6:7]"] for i in range(9)], []))
+
+
 def main(path, which="b"):
-    (set_a if which == "a" else set_b)()
+    {"a": set_a, "b": set_b, "c": set_c}[which]()
     o = []
     o.append("// GENERATED by tools/gen_ubench_banks2.py -- dev tool (not product).  hipcc --offload-arch=gfx950 -O3 -o /tmp/ub tools/ubench_regbank.hip")
     o.append("#include <hip/hip_runtime.h>\n#include <cstdio>\n")
@@ -200,7 +220,7 @@ int main(int argc, char** argv) {
   float* d; CHECK(hipMalloc(&d, 4096));
   const int ITER = 4096;
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  for (int wps : {4}) {
+  for (int wps : {4, 2}) {
     const int blocks = p.multiProcessorCount * wps;
     for (auto& v : variants) {
       hipLaunchKernelGGL(v.k, dim3(blocks), dim3(256), 0, 0, d, 56);
