@@ -2,6 +2,7 @@
 // fp64 flush-to-zero flag of the PairHMM translation unit: the reference's PDHMM never touches
 // MXCSR (no _MM_SET_FLUSH_ZERO_MODE anywhere under src/main/native/pdhmm).
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 #include <sys/sysinfo.h>
 
 #include <algorithm>
@@ -216,6 +217,33 @@ int pd_validate(const PdProblem& q, const double* out_host) {
 
 int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host);
 
+// Does the haplotype hold a base outside ACGTN?  (Such columns need the byte-comparing step: the job goes to the full kernel.)
+bool has_odd_base_scalar(const int8_t* b, int64_t n) {
+  unsigned ok = 1;
+  for (int64_t j = 0; j < n; j++)
+    ok &= (unsigned)(b[j] == 'A') | (unsigned)(b[j] == 'C') | (unsigned)(b[j] == 'G') | (unsigned)(b[j] == 'T') | (unsigned)(b[j] == 'N');
+  return !ok;
+}
+__attribute__((target("avx2"))) bool has_odd_base_avx2(const int8_t* b, int64_t n) {
+  const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T'),
+                cN = _mm256_set1_epi8('N');
+  __m256i all = _mm256_set1_epi8((char)0xff);
+  int64_t j = 0;
+  for (; j + 32 <= n; j += 32) {
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b + j));
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, cA), _mm256_cmpeq_epi8(v, cC)),
+                                                       _mm256_or_si256(_mm256_cmpeq_epi8(v, cG), _mm256_cmpeq_epi8(v, cT))),
+                                       _mm256_cmpeq_epi8(v, cN));
+    all = _mm256_and_si256(all, ok);
+  }
+  if (_mm256_movemask_epi8(all) != -1) return true;
+  return has_odd_base_scalar(b + j, n - j);
+}
+bool has_odd_base(const int8_t* b, int64_t n) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  return avx2 ? has_odd_base_avx2(b, n) : has_odd_base_scalar(b, n);
+}
+
 // An error return must not leave asynchronous copies from this call's host vectors (or the caller's arrays) in
 // flight when those go out of scope: drain the stream first.
 int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
@@ -274,7 +302,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     shorts.reserve(nr);
     for (size_t r = 0; r < nr; r++) {
       if (blocks_for((int)q.read_lengths[r], kPdRpl) <= kLanes) { shorts.push_back((int32_t)r); continue; }
-      for (size_t h = 0; h < nh; h++) {  // a read over 255 bases: one striped job per haplotype
+      for (size_t h = 0; h < nh; h++) {  // a read that needs more than 64 lanes (320 bases or more): one striped job per haplotype
         job_pair.push_back((int32_t)(r * nh + h)); job_striped.push_back(1); job_steps.push_back(0);
       }
     }
@@ -369,10 +397,50 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
       job_pair.push_back(rep); job_striped.push_back(0); job_steps.push_back(steps);
     }
   }
+  // ---- routing: the hot launch (only the two in-place step loops, see pdhmm_fwd_kernel) takes every job without a
+  // striped read and without a haplotype that has a base outside ACGTN (such columns need the byte-comparing step);
+  // the rest -- rare -- go to a second launch of the full kernel.  Haplotypes / general jobs are reordered hot first.
+  std::vector<uint8_t> hap_odd(nh, 0);
+  for (size_t h = 0; h < nh; h++)   // (the paired layout holds a haplotype per PAIR: ~100 MB for 400k pairs, hence the SIMD scan)
+    hap_odd[h] = has_odd_base(q.hap_bases + h * (size_t)q.max_hap_len, q.hap_lengths[h]) ? 1 : 0;
+  size_t n_clean_haps = nh;
+  if (cross) {
+    std::stable_partition(hap_order.begin(), hap_order.end(), [&](int32_t h) { return hap_odd[(size_t)h] == 0; });
+    n_clean_haps = 0;
+    for (size_t h = 0; h < nh; h++) n_clean_haps += hap_odd[h] == 0;
+  }
+  size_t n_hot_general = 0;
+  {
+    const size_t ng = job_pair.size();
+    std::vector<uint8_t> full(ng, 0);
+    for (size_t j = 0; j < ng; j++) {
+      if (job_striped[j]) { full[j] = 1; continue; }
+      const PlanLane* row = lanes.data() + j * kLanes;
+      for (int l = 0; l < kLanes && !full[j]; l++)
+        if (row[l].read >= 0 && row[l].block == 0 && hap_odd[(size_t)(cross ? (size_t)row[l].read % (size_t)cross : (size_t)row[l].read)]) full[j] = 1;
+    }
+    std::vector<int32_t> order;
+    order.reserve(ng);
+    for (size_t j = 0; j < ng; j++) if (!full[j]) order.push_back((int32_t)j);
+    n_hot_general = order.size();
+    for (size_t j = 0; j < ng; j++) if (full[j]) order.push_back((int32_t)j);
+    if (n_hot_general != ng && n_hot_general != 0) {   // a mix: permute the four job arrays
+      std::vector<PlanLane> l2(lanes.size());
+      std::vector<int32_t> p2(ng), s2(ng);
+      std::vector<uint8_t> t2(ng);
+      for (size_t k = 0; k < ng; k++) {
+        const size_t j = (size_t)order[k];
+        std::copy(lanes.begin() + (ptrdiff_t)(j * kLanes), lanes.begin() + (ptrdiff_t)((j + 1) * kLanes), l2.begin() + (ptrdiff_t)(k * kLanes));
+        p2[k] = job_pair[j]; s2[k] = job_steps[j]; t2[k] = job_striped[j];
+      }
+      lanes.swap(l2); job_pair.swap(p2); job_steps.swap(s2); job_striped.swap(t2);
+    }
+  }
   const int n_chunks_cross = (int)chunk_steps.size();
   const int64_t n_cross_jobs64 = (int64_t)n_chunks_cross * (int64_t)(cross ? nh : 0);
   if (n_cross_jobs64 + (int64_t)job_pair.size() > 0x7fffffffLL) return pd_fail(GKLHIP_ERR_INVALID_ARG, "too many jobs");
   const int n_cross_jobs = (int)n_cross_jobs64;
+  const int n_cross_hot = cross ? (int)((int64_t)n_chunks_cross * (int64_t)n_clean_haps) : 0;
   const int n_general = (int)job_pair.size();
   const int n_jobs = n_cross_jobs + n_general;
   const int entry_stride = (q.max_hap_len + 2 * kLanes + 4 + 63) / 64 * 64;   // 64 idle, the columns, 63 skew + 4 look-ahead
@@ -442,9 +510,30 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
 
   hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)nh), dim3(kLanes), 0, s, a);   // one wavefront per haplotype item
   PD_HIP_TRY(hipEventRecord(c->ev0, s));
-  if (n_jobs > 0) {
-    if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(std::min(n_jobs, n_blocks)), dim3(64), 0, s, a, t.initial_condition);
-    else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(std::min(n_jobs, n_blocks)), dim3(64), 0, s, a, t.initial_condition);
+  {
+    // hot launch: cross jobs over the clean haplotypes + the first n_hot_general listed jobs
+    PdArgs ah = a;
+    ah.n_cross_jobs = n_cross_hot;
+    ah.n_jobs = n_cross_hot + (int)n_hot_general;
+    if (ah.n_jobs > 0) {
+      if (c->fma_mode) hipLaunchKernelGGL((pdhmm_fwd_kernel<true, false, true>), dim3(std::min(ah.n_jobs, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
+      else             hipLaunchKernelGGL((pdhmm_fwd_kernel<false, false, true>), dim3(std::min(ah.n_jobs, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
+    }
+    // full launch: cross jobs over the haplotypes with odd bases + the remaining listed jobs (striped reads, odd haplotypes)
+    PdArgs af = a;
+    const int n_full_general = n_general - (int)n_hot_general;
+    af.hap_order = a.hap_order + n_clean_haps;
+    af.n_cross_jobs = n_cross_jobs - n_cross_hot;
+    af.lanes = a.lanes + (int64_t)n_hot_general * kLanes;
+    af.job_pair = a.job_pair + n_hot_general;
+    af.job_steps = a.job_steps + n_hot_general;
+    af.job_striped = a.job_striped + n_hot_general;
+    af.n_jobs = af.n_cross_jobs + n_full_general;
+    af.next = c->misc.as<int32_t>() + 3;
+    if (af.n_jobs > 0) {
+      if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(std::min(af.n_jobs, n_blocks)), dim3(64), 0, s, af, t.initial_condition);
+      else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(std::min(af.n_jobs, n_blocks)), dim3(64), 0, s, af, t.initial_condition);
+    }
   }
   if (n_tail > 0) {
     PdArgs at = a;  // the tail pairs: jobs of their own, scalar-engine arithmetic (same stream: the carry rows are free again)

@@ -45,7 +45,16 @@ constexpr uint32_t kPdIdle = 1u << 30, kPdOdd = 1u << 31, kPdMatchBits = 0xfffff
 __device__ __forceinline__ uint32_t pd_onehot_acgt(uint32_t b) {
   return b == (uint32_t)'A' ? 1u : b == (uint32_t)'C' ? 2u : b == (uint32_t)'G' ? 4u : b == (uint32_t)'T' ? 8u : 0u;
 }
-constexpr int kPdRpl = 4;
+// Rows per lane.  A step's time is mostly fixed (the hand-off -> compute -> hand-off chain of a wavefront that shares its
+// SIMD with one other), so rows per lane is what amortises it: per-cell time on the x32 fixture 2 rows (three
+// wavefronts per SIMD) 11.2 ms, 3 rows 7.5, 4 rows 6.7, **5 rows 6.0** (256 VGPRs, 13 spilled outside the two
+// in-place step loops), 6 rows 6.5 (72-138 spilled), 8 rows 25 (523 spilled) with every step function in ONE kernel;
+// the kernel that carries only the two in-place loops (kHot, see pdhmm_fwd_kernel): 5 rows 6.0, **6 rows 5.5** (234
+// VGPRs, no spill), 7 rows 5.5 (5 spilled), 8 rows 5.5 (54 spilled).
+#ifndef GKL_PD_RPL
+#define GKL_PD_RPL 6
+#endif
+constexpr int kPdRpl = GKL_PD_RPL;
 
 struct PdArgs {
   const int8_t* hap_bases;     // [batch * max_hap]
@@ -179,12 +188,12 @@ __device__ __forceinline__ double pd_fma3(double a, double b, double c) {
   return r;
 }
 
-template <bool FMA, bool kSerial = false>
+template <bool FMA, bool kSerial = false, bool kHot = false>
 struct PdJob {
   static constexpr int RPL = kPdRpl;
   // six matrices, per row: match, insertion, deletion and their branch copies
   double mm[RPL], im[RPL], dm[RPL], bmm[RPL], bim[RPL], bdm[RPL];
-  double tmm[RPL], tim[RPL], tmi[RPL], tii[RPL], tmd[RPL], tdd[RPL];
+  double tmm[RPL], tim[RPL], tmi[RPL], tii[RPL], tmd[RPL];  // (tii is also the deletion-to-deletion probability: both are 10^(-gcp/10))
   double ptrue[RPL], pfalse[RPL];
   uint32_t xinfo[RPL];  // [7:0] read base, [14:8] its allele bit, bit 15: base is 'N'; [29:20] mirror of the entry's match bits:
                         // [23:20] one-hot of the raw base, [27:24] its allele bit, bit 28 = base is 'N', bit 29 = 1
@@ -212,7 +221,7 @@ struct PdJob {
     for (int s = 0; s < RPL; s++) {
       const int v = first + s;
       mm[s] = im[s] = dm[s] = bmm[s] = bim[s] = bdm[s] = 0.0;
-      tmm[s] = tim[s] = tmi[s] = tii[s] = tmd[s] = tdd[s] = 0.0;
+      tmm[s] = tim[s] = tmi[s] = tii[s] = tmd[s] = 0.0;
       ptrue[s] = pfalse[s] = 0.0;
       xinfo[s] = 0;
       if (active && v >= 0) {
@@ -226,7 +235,6 @@ struct PdJob {
         const double egc = a.q2err[ic > 254 ? 0 : ic];
         tim[s] = 1.0 - egc;
         tii[s] = egc;
-        tdd[s] = egc;
         const int qq = (int)a.read_qual[ro + v] & 0xff;
         const double eq = a.q2err[qq > 254 ? 0 : qq];
         ptrue[s] = 1.0 - eq;
@@ -238,7 +246,7 @@ struct PdJob {
         xinfo[s] = ((uint32_t)x & 0xffu) | (bit << 8) | (x == 'N' ? 0x8000u : 0u) | (pd_onehot_acgt((uint32_t)x & 0xffu) << 20) |
                    ((bit >> 3) << 24) | (x == 'N' ? 1u << 28 : 0u) | (1u << 29);
       } else if (active && v == -1) {
-        tdd[s] = 1.0;  // row 0: deletion matrix constant INITIAL_CONDITION / haplen, everything else 0
+        tii[s] = 1.0;  // row 0: deletion matrix constant INITIAL_CONDITION / haplen (the insertion matrix of a pad row only ever sees zeros, so the shared register is safe), everything else 0
         dm[s] = init;
       }
     }
@@ -308,15 +316,15 @@ struct PdJob {
       const double ib = del_end ? max_im_t : imT;
       if (kSerial) {
         nmm[s] = pr * ((mmD * tmm[s] + imD * tim[s]) + dmD * tim[s]);   // pdhmm-serial.cc:343-345
-        ndm[s] = mmL * tmd[s] + dmL * tdd[s];
+        ndm[s] = mmL * tmd[s] + dmL * tii[s];
         nim[s] = ia * tmi[s] + ib * tii[s];
       } else if (FMA) {
         nmm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
-        ndm[s] = __builtin_fma(dmL, tdd[s], mmL * tmd[s]);
+        ndm[s] = __builtin_fma(dmL, tii[s], mmL * tmd[s]);
         nim[s] = __builtin_fma(ib, tii[s], ia * tmi[s]);
       } else {
         nmm[s] = pr * (mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]));   // :427-429
-        ndm[s] = mmL * tmd[s] + dmL * tdd[s];                            // :431
+        ndm[s] = mmL * tmd[s] + dmL * tii[s];                            // :431
         nim[s] = ia * tmi[s] + ib * tii[s];
       }
     }
@@ -356,10 +364,10 @@ struct PdJob {
         const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
         const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
         if (FMA) {
-          dm[s] = pd_fma3(dm[s], tdd[s], mm[s] * tmd[s]);
+          dm[s] = pd_fma3(dm[s], tii[s], mm[s] * tmd[s]);
           mm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
         } else {
-          dm[s] = mm[s] * tmd[s] + dm[s] * tdd[s];                       // pdhmm.h:431
+          dm[s] = mm[s] * tmd[s] + dm[s] * tii[s];                       // pdhmm.h:431
           mm[s] = pr * (mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]));   // :427-429
         }
       }
@@ -412,10 +420,10 @@ struct PdJob {
         const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
         const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
         if (FMA) {
-          dm[s] = pd_fma3(dm[s], tdd[s], mm[s] * tmd[s]);
+          dm[s] = pd_fma3(dm[s], tii[s], mm[s] * tmd[s]);
           mm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
         } else {
-          dm[s] = mm[s] * tmd[s] + dm[s] * tdd[s];                       // pdhmm.h:431
+          dm[s] = mm[s] * tmd[s] + dm[s] * tii[s];                       // pdhmm.h:431
           mm[s] = pr * (mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]));   // :427-429
         }
       }
@@ -454,7 +462,7 @@ struct PdJob {
   // `bytewise`: some lane's haplotype has a base outside ACGTN (uniform over the wavefront): every step compares bytes.
   __device__ __forceinline__ void run_packed(const uint32_t* __restrict__ ep, int n_steps, bool bytewise) {
     fetch_above();
-    if (kSerial || bytewise) {
+    if (!kHot && (kSerial || bytewise)) {
       uint32_t cur = ep[0];
       for (int t = 0; t < n_steps; t++) {
         const uint32_t nxt = ep[t + 1];
@@ -521,7 +529,7 @@ struct PdJob {
           if (lane == 0) r[k] = v;
         }
       }
-      step<false>(cur);   // striped jobs (reads over 255 bases) keep the compute-and-select step
+      step<false>(cur);   // striped jobs (reads that need more than 64 lanes: 320 bases or more) keep the compute-and-select step
       cur = nxt;
       if (cout) {
         const int p = t - (kLanes - 1);
@@ -545,12 +553,17 @@ struct PdJob {
 };
 
 // Persistent wavefronts pull jobs (see PdArgs).
-template <bool FMA, bool kSerial = false>
-__global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_condition) {
+// kHot: the launch that does (nearly) all the work carries ONLY the two in-place step loops -- its job list holds no
+// striped job and no haplotype with a base outside ACGTN (the host routes those to a second launch of the full kernel).
+// Without the compute-and-select step the kernel needs 234 VGPRs at 6 rows per lane and spills nothing; with it 256 and
+// 72-138 spilled registers, which is why the full kernel alone ran best at 5 rows (x32 fixture: 6.0 ms full at 5 rows,
+// 5.5 ms hot at 6).  Both instantiations use the same rows per lane: they share the packing.
+template <bool FMA, bool kSerial = false, bool kHot = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pdhmm_fwd_kernel(PdArgs a, double init_condition) {
   const int lane = threadIdx.x;
   const int64_t cstride = 6 * (int64_t)a.carry_len + 64;
   double* my = a.carry + (int64_t)blockIdx.x * 2 * cstride;
-  using Job = PdJob<FMA, kSerial>;
+  using Job = PdJob<FMA, kSerial, kHot>;
   Job job;
   for (;;) {
     int j = 0;
@@ -574,7 +587,7 @@ __global__ __launch_bounds__(64) void pdhmm_fwd_kernel(PdArgs a, double init_con
     }
     j -= a.n_cross_jobs;
     const int rep = a.job_pair[j];
-    if (!a.job_striped[j]) {
+    if (kHot || !a.job_striped[j]) {
       const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
       const bool active = sl.read >= 0;
       const int p = active ? sl.read : rep;

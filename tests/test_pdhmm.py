@@ -217,7 +217,7 @@ def test_pdhmm_gpu_fixture_files_default_mode_is_gkl_at_every_position(pd_oracle
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(), dict(flag_rate=0.5), dict(read_len=(200, 520), hap_len=(100, 400)),
                                 dict(read_len=(1, 8), hap_len=(1, 6), flag_rate=0.6),
-                                dict(read_len=(255, 257), hap_len=(60, 70)),
+                                dict(read_len=(255, 257), hap_len=(60, 70)), dict(read_len=(317, 323), hap_len=(60, 70)),
                                 dict(odd_haps=0.3), dict(odd_haps=1.0, flag_rate=0.4, read_len=(20, 120), hap_len=(30, 160))])
 def test_pdhmm_gpu_random_batches_bit_exact(pd_ctx, pd_oracle, kw):
     rng = np.random.RandomState(77)
@@ -318,7 +318,7 @@ def cross_product(rng, n_reads, n_haps, read_len, hap_len):
 @pytest.mark.parametrize("shape", [(40, 6, (1, 60), (1, 90)), (90, 3, (100, 151), (150, 260)),
                                    (12, 4, (200, 600), (50, 300))])
 def test_pdhmm_gpu_cross_product_shares_haplotypes(pd_ctx, pd_oracle, shape):
-    # whole pairs (any haplotype) ride side by side in one wavefront; reads over 255 rows run striped
+    # whole pairs (any haplotype) ride side by side in one wavefront; reads of 320 rows or more run striped
     n_reads, n_haps, rl, hl = shape
     b = cross_product(np.random.RandomState(n_reads), n_reads, n_haps, rl, hl)
     got = pd_ctx.compute(b)
@@ -354,7 +354,7 @@ def test_pdhmm_gpu_cross_entry_point_equals_paired(pd_ctx, pd_oracle):
     # gklhip_pdhmm_compute_cross walks reads x haplotypes on the device; the paired entry point gets the same
     # cross product expanded on the host
     rng = np.random.RandomState(31)
-    reads = random_pd_batch(rng, 37, read_len=(1, 300), hap_len=(1, 2))       # includes reads over 255 bases (striped)
+    reads = random_pd_batch(rng, 37, read_len=(1, 400), hap_len=(1, 2))       # includes reads of 320 bases or more (striped)
     haps = random_pd_batch(rng, 11, read_len=(1, 2), hap_len=(1, 260), flag_rate=0.05)
     got = pd_ctx.compute_cross(reads, haps)
     pairs = []
