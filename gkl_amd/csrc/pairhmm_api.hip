@@ -598,6 +598,10 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     a.tab = c->dt32;
     a.y0 = reinterpret_cast<const float*>(dp + L.y0_32);
     a.raw = c->raw32.as<float>();
+    // (decided below as well: the small-call path applies the policy per pair and writes the words itself)
+    const bool per_pair_call = n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
+    const bool fold_packed = finalize_mode == kModePacked && !per_pair_call;
+    a.packed_out = fold_packed ? reinterpret_cast<uint64_t*>(out_dev) : nullptr;
     if (n_main_blocks > 0) {
       if (rpl_main == 2)      launch_stream<float, 2>(a, fma, n_main_blocks, s);
       else if (rpl_main == 4) launch_stream<float, 4>(a, fma, n_main_blocks, s);
@@ -622,11 +626,13 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     d.raw = c->raw64.as<double>();
     d.stream = stream_flat;
     d.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos_flat);
+    d.packed_out = fold_packed ? reinterpret_cast<uint64_t*>(out_dev) : nullptr;
+    d.packed_only_flagged = c->used64.as<uint8_t>();
     int32_t* cnts = c->counters.as<int32_t>();
     // Small calls (one GATK region): policy + fp64 recomputation + finalisation of one pair per wavefront in ONE launch
     // (pairhmm_pair_policy_kernel); rows per lane by the longest read.
     // (the one-pair-per-wavefront kernel holds at most 64 x kRplF64 - 1 rows)
-    const bool per_pair = n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
+    const bool per_pair = per_pair_call;
     if (per_pair) {
       PairPolicyArgs q;
       q.raw32 = c->raw32.as<float>(); q.out = out_dev; q.used64 = c->used64.as<uint8_t>(); q.count = cnts;
@@ -682,6 +688,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       // (a shard of the batch wants fewer, longer jobs: 4096 for an eighth, measured on the 1250 x 128 shard)
       pa.wanted_jobs = wanted_env > 0 ? wanted_env : (int)std::min<int64_t>(kFallbackWantedJobs, std::max<int64_t>(4096, n_pairs / 100));
       pa.min_job_cols = 256;
+      pa.packed_by_kernels = fold_packed ? 1 : 0;
       // every block must be resident at once (grid barriers): far fewer than one per CU
       static const int blocks_env = [] { const char* v = getenv("GKLHIP_PLAN_BLOCKS"); return v ? atoi(v) : 0; }();
       // (fewer blocks for smaller calls: the barriers get cheaper and the policy phase has less to share out -- an eighth of
@@ -721,7 +728,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       launch_long<double, kRplF64>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
-    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
+    // (host-buffer calls: the fp64 kernels stored the packed words of the recomputed pairs themselves)
+    if (!fold_packed) hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
     if (side_finalize) HIP_TRY(hipStreamWaitEvent(s, c->early_copy_done, 0));  // join the side stream
     }  // !per_pair
   }

@@ -176,6 +176,7 @@ struct PlanArgs {
   int32_t total_cols;    // columns + separators of all haplotypes
   int32_t wanted_jobs;   // the pass is cut into about this many jobs (when the runs allow it)
   int32_t min_job_cols;
+  int32_t packed_by_kernels;  // the forward kernels wrote the packed words themselves (FwdArgs::packed_out)
 };
 
 // All threads of all blocks call this the same number of times.  `target` counts arrivals expected so far.
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
         a.fa.used64[i] = fails ? 1 : 0;
         // "pending" (0) for the flagged pairs: finalize64_kernel fills them in; the device log10 of the kept pairs
         // is finalize32_kernel's job, which runs beside the fp64 pass
-        if (a.fa.mode == kModePacked)
+        if (a.fa.mode == kModePacked && !a.packed_by_kernels)
           reinterpret_cast<uint64_t*>(a.fa.out)[i] = fails ? 0ull : (kPackedF32Tag | (uint64_t)__float_as_uint(v));
       }
     }

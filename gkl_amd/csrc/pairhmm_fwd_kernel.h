@@ -100,6 +100,14 @@ struct FwdArgs {
   const LaneSlot* chunk_lanes;  // [n_chunks * 64]
   int32_t n_chunks;
   T* raw;  // [n_reads * n_haps], r-major, scaled likelihood sums
+  // Host-buffer calls (reference-exact log10 on the host): the packed result word of a pair (packed_word below; fp32
+  // pass: the tagged fp32 sum, or 0 = "pending" when the policy will send the pair to the fp64 pass) goes straight to
+  // pinned host memory from the lane that stores the sum -- the PCIe writes of a whole batch (10 MB) then trickle out
+  // under the forward kernels instead of taking 0.4 ms of the policy kernel behind them.  NULL: no such output.
+  uint64_t* packed_out;
+  // fp64 recomputation pass: the policy's flags.  Its jobs are (chunk, haplotype run) rectangles, so a few per cent of the
+  // pairs it computes were NOT flagged (they ride along): those keep their fp32 word.  NULL: every pair is wanted.
+  const uint8_t* packed_only_flagged;
   // job-list mode (packed fp64 fallback): jobs are (chunk, first hap, end hap) in stream order
   const FwdJob* jobs;
   const int32_t* job_count;
@@ -114,6 +122,21 @@ constexpr uint64_t kPackedF32Tag = 0xFFFFFFFF00000000ull;
 __device__ __forceinline__ uint64_t packed_word(double raw) {
   const uint64_t bits = (uint64_t)__double_as_longlong(raw);
   return (bits & kPackedF32Tag) == kPackedF32Tag ? 0x7FF8000000000000ull : bits;
+}
+
+// the store of a pair's result (all kernels): the raw sum, and the packed word when the call wants one
+template <typename T>
+__device__ __forceinline__ void emit_result(const FwdArgs<T>& a, int64_t idx, T v) {
+  a.raw[idx] = v;
+  if (a.packed_out) {
+    if (sizeof(T) == 4) {
+      const float f = (float)v;
+      // the policy's test (IntelPairHmm.cc:159; NaN compares false and stays fp32); policy_plan_kernel applies the same one
+      a.packed_out[idx] = f < 1e-28f ? 0ull : (kPackedF32Tag | (uint64_t)__float_as_uint(f));
+    } else if (!a.packed_only_flagged || a.packed_only_flagged[idx]) {
+      a.packed_out[idx] = packed_word((double)v);
+    }
+  }
 }
 
 // ---- cross-lane helpers -----------------------------------------------------
@@ -419,11 +442,11 @@ struct WaveJob {
     if (sep) {
       const int k = (int)(ent & 0x7fffffffu);
       if (k == k_cur) {  // k_cur is always inside [hap_begin, hap_end)
-        if (out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + orig_cur] = sM + sX;
+        if (out_read >= 0) emit_result(a, (int64_t)out_read * a.b.n_haps + orig_cur, sM + sX);
         y0n = y0_next;
       } else {
         const bool mine = (k >= hap_begin) && (k < hap_end);
-        if (mine && out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
+        if (mine && out_read >= 0) emit_result(a, (int64_t)out_read * a.b.n_haps + a.hap_orig[k], sM + sX);
         if (mine && k + 1 < hap_end) {
           y0n = a.y0[k + 1];
           // consume the load inside this (rare) branch: left pending, its s_waitcnt vmcnt(0) lands behind the join and
@@ -481,11 +504,11 @@ struct WaveJob {
       const int k = (int)(ent & 0x7fffffffu);
       T y0n = T(0);
       if (k == k_cur) {  // k_cur is always inside [hap_begin, hap_end)
-        if (out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + orig_cur] = sM + sX;
+        if (out_read >= 0) emit_result(a, (int64_t)out_read * a.b.n_haps + orig_cur, sM + sX);
         y0n = y0_next;
       } else {
         const bool mine = (k >= hap_begin) && (k < hap_end);
-        if (mine && out_read >= 0) a.raw[(int64_t)out_read * a.b.n_haps + a.hap_orig[k]] = sM + sX;
+        if (mine && out_read >= 0) emit_result(a, (int64_t)out_read * a.b.n_haps + a.hap_orig[k], sM + sX);
         if (mine && k + 1 < hap_end) {
           y0n = a.y0[k + 1];
           asm volatile("" :: "v"(y0n));  // consume the load inside this (rare) branch, see step_any
