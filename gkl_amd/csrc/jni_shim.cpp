@@ -450,7 +450,25 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     }
     const char* rv = getenv("GKL_HIP_JNI_RANGE_PAIRS");
     const int64_t range_pairs = rv && atoll(rv) > 0 ? atoll(rv) : 150000LL;
-    const int n_ranges = (int)std::max<int64_t>(2, std::min<int64_t>(32, (n_pairs + range_pairs - 1) / range_pairs));
+    // Range boundaries: the first range is small (its marshalling is the only part nothing overlaps with), the later ones
+    // grow geometrically (marshalling outruns compute, and bigger ranges use the chip better): sizes range_pairs * g^k.
+    const char* gv = getenv("GKL_HIP_JNI_RANGE_GROWTH");
+    const double growth = gv && atof(gv) >= 1.0 ? atof(gv) : 1.0;
+    std::vector<jsize> cut{0};
+    {
+      double want = (double)range_pairs / (double)n_haps;   // reads in the next range
+      double at = 0;
+      while ((jsize)at < n_reads && cut.size() < 33) {
+        at += std::max(1.0, want);
+        cut.push_back((jsize)std::min<double>(at, n_reads));
+        want *= growth;
+      }
+      cut.back() = n_reads;
+      if (cut.size() >= 3 && cut.back() - cut[cut.size() - 2] < (cut[cut.size() - 2] - cut[cut.size() - 3]) / 3) {  // no sliver at the end
+        cut.erase(cut.end() - 2);
+      }
+    }
+    const int n_ranges = (int)cut.size() - 1;
     while ((int)sl->ranges.size() < n_ranges) sl->ranges.emplace_back(new ReadArena());
     sl->tasks.assign((size_t)n_ranges, RangeTask());
     sl->out.resize((size_t)n_pairs);
@@ -469,7 +487,7 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
       ns_write += now_ns() - t0;
     };
     for (int k = 0; k < n_ranges && !java_exception && failed_status == GKLHIP_OK; k++) {
-      const jsize r0 = (jsize)((int64_t)n_reads * k / n_ranges), r1 = (jsize)((int64_t)n_reads * (k + 1) / n_ranges);
+      const jsize r0 = cut[(size_t)k], r1 = cut[(size_t)k + 1];
       const int64_t t0 = now_ns();
       if (!marshal_reads(*sl->ranges[(size_t)k], r0, r1)) { java_exception = true; break; }
       ns_marshal += now_ns() - t0;
