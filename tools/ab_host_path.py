@@ -10,7 +10,11 @@ from gkl_amd import native  # noqa: E402
 from gkl_amd.synth import make_batch  # noqa: E402
 
 whole = make_batch("hc")
-for name, b, calls in (("whole", whole, 12), ("eighth", whole.read_slice(0, whole.n_reads // 8), 40)):
+shapes = (("whole", whole, 12), ("eighth", whole.read_slice(0, whole.n_reads // 8), 40))
+if len(sys.argv) > 3 and sys.argv[3] == "small":
+    shapes = (("eighth", whole.read_slice(0, whole.n_reads // 8), 40), ("1000x32", make_batch("hc", 1000, 32), 60),
+              ("300x16", make_batch("region", 300, 16), 100), ("100x10", make_batch("hc", 100, 10), 200))
+for name, b, calls in shapes:
     out = np.empty(b.n_pairs)
     pin = native.PinnedBatch(b)
     for rnd in range(3):
