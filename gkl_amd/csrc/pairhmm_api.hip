@@ -23,6 +23,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <deque>
 #include <vector>
 
 #include "../../include/gkl_hip_pairhmm.h"
@@ -169,7 +170,7 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // and inputs travel in ONE copy.
 struct PlanLayout {
   size_t place_chunk, place_lane, chunk_used, groups, hap_len, hap_pos, hap_pos_flat, hap_orig, hap_sidx, hap_group, hap_src, y0_32, y0_64, read_off, long_lanes, long_jobs, long_count,
-      batch, batch_stride, stream, stream_flat, has_n, total;
+      batch, batch_stride, stream, stream_flat, has_n, desc, total;
 };
 PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lanes, size_t n_long_jobs, size_t inline_read_bytes,
                       size_t inline_hap_bytes) {
@@ -201,6 +202,8 @@ PlanLayout layout_for(const Plan& p, int n_reads, int n_haps, size_t n_long_lane
   l.stream = o; if (inline_read_bytes) o = align_up(o + (size_t)p.n_stream * 4);
   l.stream_flat = o; if (inline_read_bytes) o = align_up(o + (size_t)p.n_stream_flat * 4);
   l.has_n = o; if (inline_read_bytes) o = align_up(o + (size_t)n_haps);
+  // ... and the call's descriptor for the combined launches of several small calls (SmallCombiner)
+  l.desc = o; if (inline_read_bytes) o = align_up(o + sizeof(SmallCall));
   l.total = o;
   return l;
 }
@@ -268,6 +271,15 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
   else     hipLaunchKernelGGL((pairhmm_fwd_long_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a, carry, carry_len);
 }
 
+// A small host-buffer call, planned and staged but not launched: SmallCombiner decides how it reaches the device (on
+// its own, or in one set of launches with the calls of other threads).
+struct SmallLaunch {
+  bool filled = false;
+  SmallCall call;                          // the descriptor
+  const SmallCall* desc_pinned = nullptr;  // ... as the device sees it in the pinned staging block (the prep kernel reads this one)
+  const SmallCall* desc_dev = nullptr;     // ... in the device copy of the plan block (which the prep kernel pulls)
+};
+
 // Rows per lane.  fp32 main pass: 8 (4 or 2 for small batches).  fp64: 10 in the streaming and job-list kernels, 6 (kRplF64) in the
 // one-pair-per-wavefront and striped long-read kernels.  A read of length R needs R+1 rows; reads that exceed 64*RPL rows go to the
 // striped long-read kernel.
@@ -322,12 +334,33 @@ int pick_f32_rpl(int forced, int n_reads, int n_haps, const int64_t* read_off, c
   return 2;
 }
 
+void launch_main_f32(const FwdArgs<float>& a, int rpl_main, int fma, int n_blocks, hipStream_t s) {
+  if (rpl_main == 2)      launch_stream<float, 2>(a, fma, n_blocks, s);
+  else if (rpl_main == 4) launch_stream<float, 4>(a, fma, n_blocks, s);
+  else                    launch_stream<float, kRplF32>(a, fma, n_blocks, s);
+}
+void launch_pair_policy(const FwdArgs<double>& d, const PairPolicyArgs& q, int rows, int fma, int64_t n_pairs, hipStream_t s) {
+  const dim3 grid((unsigned)n_pairs), block(64);
+  if (fma) {
+    if (rows == 2)      hipLaunchKernelGGL((pairhmm_pair_policy_kernel<2, true>), grid, block, 0, s, d, q);
+    else if (rows == 4) hipLaunchKernelGGL((pairhmm_pair_policy_kernel<4, true>), grid, block, 0, s, d, q);
+    else                hipLaunchKernelGGL((pairhmm_pair_policy_kernel<kRplF64, true>), grid, block, 0, s, d, q);
+  } else {
+    if (rows == 2)      hipLaunchKernelGGL((pairhmm_pair_policy_kernel<2, false>), grid, block, 0, s, d, q);
+    else if (rows == 4) hipLaunchKernelGGL((pairhmm_pair_policy_kernel<4, false>), grid, block, 0, s, d, q);
+    else                hipLaunchKernelGGL((pairhmm_pair_policy_kernel<kRplF64, false>), grid, block, 0, s, d, q);
+  }
+}
+
 // The whole device-side pipeline on stream `s`: 5 launches in the policy mode (prep, fp32 forward, policy + planning
 // of the fp64 pass, fp64 forward over the job list, log10 of the recomputed pairs; + the log10 of the kept pairs on a
 // side stream in the device finalisation modes), no host synchronisation.  `db` holds host offsets and DEVICE byte
 // arrays -- or, with `inline_host`, HOST byte arrays that travel inside the plan block (small host-buffer calls: one
 // copy for plan and inputs).
-int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_mode, hipStream_t s, bool inline_host) {
+// `defer` (host-buffer calls on an idle context only): a call that takes the small-call path -- pulled plan block,
+// per-pair policy -- is planned and staged but NOT launched; its descriptor is returned in *defer (filled = true).
+int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_mode, hipStream_t s, bool inline_host,
+               SmallLaunch* defer = nullptr) {
   const int n_reads = db->n_reads, n_haps = db->n_haps;
   const int64_t n_pairs = (int64_t)n_reads * n_haps;
   gklhip_stats& st = c->stats;
@@ -449,12 +482,16 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   // Big plans ride the upload stream (the copy overlaps the previous call's kernels); a small plan (GATK-sized
   // call) is PULLED from the pinned staging block by the prep kernel itself: no copy-engine hop at all.
   const bool pull = L.total < (256u << 10);
+  // (the one-pair-per-wavefront policy kernel holds at most 64 x kRplF64 - 1 rows)
+  const bool per_pair_call = !use_double && n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
+  const bool deferred_launch = defer && pull && inline_host && c->cfg.record_events == 0 && per_pair_call && n_long_main == 0 &&
+                               finalize_mode == kModePacked && plan.n_chunks > 0;
   const unsigned char* hs_dev = nullptr;  // the staging block as the device sees it
   if (pull) {
     void* p = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&p, hs, 0));
     hs_dev = static_cast<const unsigned char*>(p);
-    HIP_TRY(hipStreamWaitEvent(s, c->plan_unused_slot[slot], 0));
+    if (!deferred_launch) HIP_TRY(hipStreamWaitEvent(s, c->plan_unused_slot[slot], 0));
   } else {
     HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->plan_unused_slot[slot], 0));  // readers of the old contents are done
     HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, c->upload_stream));
@@ -525,8 +562,13 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     pa.pull_dst = reinterpret_cast<uint4*>(dp);
     pa.pull_n16 = pull ? (int32_t)(L.total / 16) : 0;
     const int pull_blocks = pull ? (int)std::min<size_t>(64, (L.total / 16 + kPrepBlock * 4 - 1) / (kPrepBlock * 4)) : 0;
-    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)(pa.hap_blocks + pull_blocks)), dim3(kPrepBlock), 0, s, pa);
-    if (pull) HIP_TRY(hipEventRecord(c->stage_free_slot[slot], s));
+    if (deferred_launch) {
+      defer->call.prep = pa;
+      defer->call.prep_grid = pa.hap_blocks + pull_blocks;
+    } else {
+      hipLaunchKernelGGL(prep_kernel, dim3((unsigned)(pa.hap_blocks + pull_blocks)), dim3(kPrepBlock), 0, s, pa);
+      if (pull) HIP_TRY(hipEventRecord(c->stage_free_slot[slot], s));
+    }
   }
 
   DevBatch b;
@@ -598,14 +640,15 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     a.tab = c->dt32;
     a.y0 = reinterpret_cast<const float*>(dp + L.y0_32);
     a.raw = c->raw32.as<float>();
-    // (decided below as well: the small-call path applies the policy per pair and writes the words itself)
-    const bool per_pair_call = n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
+    // (the small-call path applies the policy per pair and writes the words itself)
     const bool fold_packed = finalize_mode == kModePacked && !per_pair_call;
     a.packed_out = fold_packed ? reinterpret_cast<uint64_t*>(out_dev) : nullptr;
-    if (n_main_blocks > 0) {
-      if (rpl_main == 2)      launch_stream<float, 2>(a, fma, n_main_blocks, s);
-      else if (rpl_main == 4) launch_stream<float, 4>(a, fma, n_main_blocks, s);
-      else                    launch_stream<float, kRplF32>(a, fma, n_main_blocks, s);
+    if (deferred_launch) {
+      defer->call.f = a;
+      defer->call.rpl_main = rpl_main;
+      defer->call.main_blocks = n_main_blocks;
+    } else if (n_main_blocks > 0) {
+      launch_main_f32(a, rpl_main, fma, n_main_blocks, s);
     }
     if (n_long_main > 0) {
       FwdArgs<float> la = a;
@@ -631,7 +674,6 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     int32_t* cnts = c->counters.as<int32_t>();
     // Small calls (one GATK region): policy + fp64 recomputation + finalisation of one pair per wavefront in ONE launch
     // (pairhmm_pair_policy_kernel); rows per lane by the longest read.
-    // (the one-pair-per-wavefront kernel holds at most 64 x kRplF64 - 1 rows)
     const bool per_pair = per_pair_call;
     if (per_pair) {
       PairPolicyArgs q;
@@ -639,18 +681,22 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       q.hap_sidx = reinterpret_cast<const int32_t*>(dp + L.hap_sidx);
       q.mode = finalize_mode;
       q.log10_init_f = fa.log10_init_f; q.log10_init32_as_f64 = fa.log10_init32_as_f64; q.log10_init_d = fa.log10_init_d;
-      if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
-      const dim3 grid((unsigned)n_pairs), block(64);
       const int rows = plan.max_read_len <= 2 * kLanes - 1 ? 2 : plan.max_read_len <= 4 * kLanes - 1 ? 4 : kRplF64;
-      if (fma) {
-        if (rows == 2)      hipLaunchKernelGGL((pairhmm_pair_policy_kernel<2, true>), grid, block, 0, s, d, q);
-        else if (rows == 4) hipLaunchKernelGGL((pairhmm_pair_policy_kernel<4, true>), grid, block, 0, s, d, q);
-        else                hipLaunchKernelGGL((pairhmm_pair_policy_kernel<kRplF64, true>), grid, block, 0, s, d, q);
-      } else {
-        if (rows == 2)      hipLaunchKernelGGL((pairhmm_pair_policy_kernel<2, false>), grid, block, 0, s, d, q);
-        else if (rows == 4) hipLaunchKernelGGL((pairhmm_pair_policy_kernel<4, false>), grid, block, 0, s, d, q);
-        else                hipLaunchKernelGGL((pairhmm_pair_policy_kernel<kRplF64, false>), grid, block, 0, s, d, q);
+      if (deferred_launch) {
+        SmallCall& k = defer->call;
+        k.d = d; k.q = q; k.rows = rows; k.n_pairs = (int32_t)n_pairs; k.fma = fma;
+        memcpy(hs + L.desc, &k, sizeof k);  // nothing has been launched yet: the block is still ours to write
+        defer->desc_pinned = reinterpret_cast<const SmallCall*>(hs_dev + L.desc);
+        defer->desc_dev = reinterpret_cast<const SmallCall*>(dp + L.desc);
+        defer->filled = true;
+        c->last_pairs = n_pairs;
+        c->last_stream = s;
+        c->have_last = true;
+        st.n_fallback = -1;
+        return GKLHIP_OK;
       }
+      if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
+      launch_pair_policy(d, q, rows, fma, n_pairs, s);
       if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
       HIP_TRY(hipEventRecord(c->policy_done, s));
     } else {
@@ -869,6 +915,165 @@ int finalize_threads(const DevCtx* c, int share) {
   return std::max(1, std::min(threads, 64));
 }
 
+// ---- small host-buffer calls of several threads: combined launches ----
+// The device executes the kernels of about four hardware queues at a time (tools/ubench_launch.hip: 16 threads with a
+// stream each get 4 x the kernel rate of one, not 16 x), so GATK-sized calls from many threads queue up behind each
+// other however many streams they use.  A call that arrives while others are in flight therefore waits for a flight
+// slot, and the thread that gets the slot launches ALL waiting calls in one set of three kernels (prep_multi_kernel,
+// fwd_stream_multi_kernel, pair_policy_multi_kernel: a block finds its call through block offsets in the kernel
+// arguments).  A call that finds a free slot and nobody waiting goes out on its own stream exactly as before.
+constexpr int kFlightSlots = 4;
+struct SmallCombiner {
+  struct Ticket {
+    const SmallLaunch* sl = nullptr;
+    int state = 0;  // 0 queued, 4 taken by a leader, 1 launched (wait for `ev`), 3 finished, 2 failed
+    hipEvent_t ev = nullptr;
+    int rc = GKLHIP_OK;
+    std::string err;
+    int64_t t_in = 0;
+  };
+  struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    bool busy = false;
+  };
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Ticket*> queue;
+  Slot slot[kFlightSlots];
+  int flights = 0;
+  int max_flights = 3;
+  bool followers_sleep = false;  // the calls a leader launched for others: true = they sleep until the leader has seen the end, false = they wait on its event themselves
+  int64_t n_calls = 0, n_combined = 0, n_launch_sets = 0;  // diagnostics (gklhip_small_call_counts)
+  int64_t ns_queued = 0, ns_launch = 0, ns_sync = 0, ns_total = 0;
+  static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+  int launch_single(const SmallCall& k, hipStream_t s) {
+    hipLaunchKernelGGL(prep_kernel, dim3((unsigned)k.prep_grid), dim3(kPrepBlock), 0, s, k.prep);
+    launch_main_f32(k.f, k.rpl_main, k.fma, k.main_blocks, s);
+    launch_pair_policy(k.d, k.q, k.rows, k.fma, k.n_pairs, s);
+    HIP_TRY(hipGetLastError());
+    return GKLHIP_OK;
+  }
+  int launch_multi(Ticket* const* batch, int n, int fma, Slot& sl) {
+    MultiArgs mp{}, mf{}, mq{};
+    mp.n = mf.n = mq.n = n;
+    for (int i = 0; i < n; i++) {
+      const SmallLaunch& L = *batch[i]->sl;
+      mp.call[i] = L.desc_pinned; mf.call[i] = L.desc_dev; mq.call[i] = L.desc_dev;
+      mp.begin[i + 1] = mp.begin[i] + L.call.prep_grid;
+      mf.begin[i + 1] = mf.begin[i] + L.call.main_blocks;
+      mq.begin[i + 1] = mq.begin[i] + L.call.n_pairs;
+    }
+    hipLaunchKernelGGL(prep_multi_kernel, dim3((unsigned)mp.begin[n]), dim3(kPrepBlock), 0, sl.stream, mp);
+    if (fma) {
+      hipLaunchKernelGGL((fwd_stream_multi_kernel<true, kRplF32>), dim3((unsigned)mf.begin[n]), dim3(64), 0, sl.stream, mf);
+      hipLaunchKernelGGL((pair_policy_multi_kernel<true, kRplF64>), dim3((unsigned)mq.begin[n]), dim3(64), 0, sl.stream, mq);
+    } else {
+      hipLaunchKernelGGL((fwd_stream_multi_kernel<false, kRplF32>), dim3((unsigned)mf.begin[n]), dim3(64), 0, sl.stream, mf);
+      hipLaunchKernelGGL((pair_policy_multi_kernel<false, kRplF64>), dim3((unsigned)mq.begin[n]), dim3(64), 0, sl.stream, mq);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sl.ev, sl.stream));
+    return GKLHIP_OK;
+  }
+
+  // Runs one staged call to completion (its packed words are in the caller's pinned result buffer on return).
+  int run(const SmallLaunch& mine, hipStream_t own_stream) {
+    Ticket t;
+    t.sl = &mine;
+    const int64_t t_in = t.t_in = now_ns();
+    std::unique_lock<std::mutex> l(mu);
+    n_calls++;
+    queue.push_back(&t);
+    while (t.state == 0 || t.state == 4) {
+      if (t.state == 4 || flights >= max_flights) { cv.wait(l); continue; }
+      // lead: this call first, then the waiting calls of the same arithmetic mode
+      const int64_t t_lead = now_ns();
+      ns_queued += t_lead - t_in;
+      Ticket* batch[kMultiMax];
+      int n = 0;
+      batch[n++] = &t;
+      for (auto it = queue.begin(); it != queue.end();) {
+        if (*it == &t) { it = queue.erase(it); continue; }
+        if (n < kMultiMax && (*it)->sl->call.fma == mine.call.fma) {
+          (*it)->state = 4;  // taken: its owner keeps sleeping until this thread reports the launch (or the end)
+          ns_queued += t_lead - (*it)->t_in;
+          batch[n++] = *it;
+          it = queue.erase(it);
+          continue;
+        }
+        ++it;
+      }
+      int si = 0;
+      while (slot[si].busy) si++;
+      Slot& sl = slot[si];
+      sl.busy = true;
+      flights++;
+      n_launch_sets++;
+      if (n > 1) n_combined += n;
+      int rc = GKLHIP_OK;
+      if (n > 1 && !sl.stream) {
+        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess)
+          rc = fail(GKLHIP_ERR_HIP, "stream for combined small calls");
+      }
+      l.unlock();
+      if (rc == GKLHIP_OK) rc = n == 1 ? launch_single(mine.call, own_stream) : launch_multi(batch, n, mine.call.fma, sl);
+      const std::string err = rc == GKLHIP_OK ? std::string() : g_err;
+      const int64_t t_launched = now_ns();
+      if (n > 1) {
+        l.lock();
+        if (!followers_sleep || rc != GKLHIP_OK) {
+          for (int i = 1; i < n; i++) {
+            batch[i]->rc = rc; batch[i]->err = err; batch[i]->ev = sl.ev;
+            batch[i]->state = rc == GKLHIP_OK ? 1 : 2;
+          }
+          cv.notify_all();
+        }
+        l.unlock();
+      }
+      hipError_t e = hipSuccess;
+      if (rc == GKLHIP_OK) e = n == 1 ? hipStreamSynchronize(own_stream) : hipEventSynchronize(sl.ev);
+      else (void)(n == 1 ? hipStreamSynchronize(own_stream) : hipStreamSynchronize(sl.stream));
+      l.lock();
+      {
+        const int64_t t_end = now_ns();
+        ns_launch += t_launched - t_lead; ns_sync += t_end - t_launched; ns_total += (t_end - t_in) + 0;
+      }
+      if (followers_sleep && rc == GKLHIP_OK)
+        for (int i = 1; i < n; i++) batch[i]->state = 3;
+      sl.busy = false;  // (the event is recorded again only from here on: a late waiter of this flight then waits a little longer)
+      flights--;
+      cv.notify_all();
+      l.unlock();
+      if (rc != GKLHIP_OK) { g_err = err; return rc; }
+      if (e != hipSuccess) return fail(GKLHIP_ERR_HIP, "%s (combined small calls)", hipGetErrorString(e));
+      return GKLHIP_OK;
+    }
+    l.unlock();
+    if (t.state == 2) { g_err = t.err; return t.rc; }
+    if (t.state == 1) HIP_TRY(hipEventSynchronize(t.ev));
+    return GKLHIP_OK;
+  }
+};
+SmallCombiner* small_combiner(int device) {
+  static std::mutex mu;
+  static std::vector<SmallCombiner*> all;
+  std::lock_guard<std::mutex> l(mu);
+  if ((int)all.size() <= device) all.resize((size_t)device + 1, nullptr);
+  if (!all[(size_t)device]) {
+    all[(size_t)device] = new SmallCombiner();  // lives as long as the process (a handful of streams and events)
+    if (const char* v = getenv("GKL_HIP_COMBINE_FLIGHTS")) all[(size_t)device]->max_flights = std::max(1, std::min(kFlightSlots, atoi(v)));
+    if (const char* v = getenv("GKL_HIP_COMBINE_WAIT")) all[(size_t)device]->followers_sleep = v[0] == 's';
+  }
+  return all[(size_t)device];
+}
+bool combine_enabled() {
+  static const bool on = [] { const char* v = getenv("GKL_HIP_COMBINE"); return !(v && v[0] == '0'); }();
+  return on;
+}
+
 int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
   const int64_t n_pairs = (int64_t)hb->n_reads * hb->n_haps;
   HIP_TRY(hipSetDevice(c->device));
@@ -916,7 +1121,16 @@ int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
   const HostCallInFlight in_flight;
   const int threads = finalize_threads(c, in_flight.share);
   HostFinalizer fin;
-  if ((rc = run_device(c, &db, pin_out, kModePacked, s, inline_inputs))) return rc;  // records policy_done
+  // (a context with an asynchronous device-resident call still in flight keeps the stream-ordered path)
+  SmallLaunch small;
+  const bool may_defer = inline_inputs && combine_enabled() && (!c->have_call_done || hipEventQuery(c->call_done) == hipSuccess);
+  (void)hipGetLastError();  // (hipErrorNotReady of the query)
+  if ((rc = run_device(c, &db, pin_out, kModePacked, s, inline_inputs, may_defer ? &small : nullptr))) return rc;  // records policy_done
+  if (small.filled) {
+    if ((rc = small_combiner(c->device)->run(small, s))) return rc;
+    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+    return GKLHIP_OK;
+  }
   if (c->cfg.use_double || n_pairs <= kOnePassPairs) {
     // all-fp64 mode, or a GATK-sized call (the fp64 stage of a region without underflowed pairs -- the usual case --
     // is two launches that find nothing to do): one pass over the words once the last kernel is done
@@ -1664,6 +1878,19 @@ int64_t gklhip_get_table_f64(int which, double* dst, int64_t cap) {
   if (!v) return -1;
   if (dst) memcpy(dst, v->data(), sizeof(double) * (size_t)std::min<int64_t>(cap, (int64_t)v->size()));
   return (int64_t)v->size();
+}
+
+int gklhip_small_call_counts(int device, int64_t out[3], int reset) {
+  if (!out || device < 0) return fail(GKLHIP_ERR_INVALID_ARG, "NULL argument or negative device");
+  SmallCombiner* k = small_combiner(device);
+  std::lock_guard<std::mutex> l(k->mu);
+  out[0] = k->n_calls; out[1] = k->n_combined; out[2] = k->n_launch_sets;
+  if (getenv("GKLHIP_TIMING"))
+    fprintf(stderr, "[gklhip] small calls: %lld calls, %lld combined, %lld launch sets; per set: queued %.1f us (sum over its calls), launch %.1f us, sync %.1f us\n",
+            (long long)k->n_calls, (long long)k->n_combined, (long long)k->n_launch_sets, k->ns_queued * 1e-3 / std::max<int64_t>(1, k->n_launch_sets),
+            k->ns_launch * 1e-3 / std::max<int64_t>(1, k->n_launch_sets), k->ns_sync * 1e-3 / std::max<int64_t>(1, k->n_launch_sets));
+  if (reset) k->n_calls = k->n_combined = k->n_launch_sets = k->ns_queued = k->ns_launch = k->ns_sync = k->ns_total = 0;
+  return GKLHIP_OK;
 }
 
 // Diagnostics: the VALU issue ceiling of the recurrence's instruction mix on this device (issue_mix_*_kernel: 4 multiplies

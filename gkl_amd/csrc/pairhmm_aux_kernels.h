@@ -44,13 +44,14 @@ struct PrepArgs {
   int32_t n_reads, n_chunks, rpl;
 };
 constexpr int kPrepBlock = 256;
-__global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
-  if ((int)blockIdx.x >= a.hap_blocks) {
-    const int stride = ((int)gridDim.x - a.hap_blocks) * kPrepBlock;
-    for (int w = ((int)blockIdx.x - a.hap_blocks) * kPrepBlock + (int)threadIdx.x; w < a.pull_n16; w += stride) a.pull_dst[w] = a.pull_src[w];
+// block `block` of `grid` blocks of one call's preparation
+__device__ __forceinline__ void prep_block(const PrepArgs& a, int block, int grid) {
+  if (block >= a.hap_blocks) {
+    const int stride = (grid - a.hap_blocks) * kPrepBlock;
+    for (int w = (block - a.hap_blocks) * kPrepBlock + (int)threadIdx.x; w < a.pull_n16; w += stride) a.pull_dst[w] = a.pull_src[w];
     return;
   }
-  const int i = blockIdx.x * kPrepBlock + threadIdx.x;
+  const int i = block * kPrepBlock + threadIdx.x;
   if (i < a.n_a) a.clear_a[i] = 0;
   if (i < a.n_b) a.clear_b[i] = 0;
   if (i < a.n_c) a.clear_c[i] = 0;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
     for (int l = a.chunk_used[i]; l < kLanes; l++) dst[l] = LaneSlot{-1, 0};
   }
   const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * (kPrepBlock / 64) + (threadIdx.x >> 6);
+  const int k = block * (kPrepBlock / 64) + (threadIdx.x >> 6);
   if (k >= a.n_haps) return;
   const int len = a.hap_len[k], pos = a.hap_pos[k];
   const int posf = a.hap_pos_flat ? a.hap_pos_flat[k] : 0;
@@ -89,6 +90,67 @@ __global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) {
   if (group_ends) a.stream[pos + len + 1 + lane] = kEntIdle;
   if (a.hap_pos_flat && k + 1 == a.n_haps) a.stream_flat[posf + len + 1 + lane] = kEntIdle;
   if (__ballot(has_n) != 0 && lane == 0) a.hap_has_n[k] = 1;
+}
+__global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) { prep_block(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// ---- several small host-buffer calls in ONE set of launches (pairhmm_api.hip: SmallCombiner) ----
+// The device executes the kernels of about four queues at a time (tools/ubench_launch.hip), so sixteen callers with a
+// GATK-sized region each get no more through than four.  When calls arrive while others are in flight, their three
+// launches (prep, fp32 forward, per-pair policy) are issued once for all of them: a block finds its call from the block
+// offsets in the kernel arguments and runs that call's part exactly as the single-call kernel would.  The per-call
+// arguments are the call's descriptor, which travels in its plan block.
+struct SmallCall {
+  PrepArgs prep;
+  FwdArgs<float> f;
+  FwdArgs<double> d;
+  PairPolicyArgs q;
+  int32_t prep_grid, rpl_main, main_blocks, rows, n_pairs, fma;
+};
+constexpr int kMultiMax = 16;
+struct MultiArgs {
+  const SmallCall* call[kMultiMax];  // prep: the descriptors in the pinned staging blocks; later kernels: the device copies
+  int32_t begin[kMultiMax + 1];      // first block of each call in this launch
+  int32_t n;
+};
+__device__ __forceinline__ int multi_find(const MultiArgs& m, int block) {
+  int r = 0;
+  for (int i = 1; i < m.n; i++) r += block >= m.begin[i] ? 1 : 0;
+  return __builtin_amdgcn_readfirstlane(r);
+}
+__global__ __launch_bounds__(kPrepBlock) void prep_multi_kernel(MultiArgs m) {
+  const int r = multi_find(m, (int)blockIdx.x);
+  const SmallCall* c = m.call[r];
+  const PrepArgs a = c->prep;
+  prep_block(a, (int)blockIdx.x - m.begin[r], c->prep_grid);
+}
+template <bool FMA, int kRplF32>  // kRplF32: the widest fp32 variant (2, 4 or this many rows per lane)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void fwd_stream_multi_kernel(MultiArgs m) {
+  constexpr int kLds2 = WaveJob<float, 2, FMA>::kLdsBytes, kLds4 = WaveJob<float, 4, FMA>::kLdsBytes, kLds8 = WaveJob<float, kRplF32, FMA>::kLdsBytes;
+  constexpr int kLds = kLds2 > kLds4 ? (kLds2 > kLds8 ? kLds2 : kLds8) : (kLds4 > kLds8 ? kLds4 : kLds8);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kLds];
+  const int r = multi_find(m, (int)blockIdx.x);
+  const SmallCall* c = m.call[r];
+  const int block = (int)blockIdx.x - m.begin[r];
+  const FwdArgs<float> a = c->f;
+  const int rpl = c->rpl_main;
+  if (rpl == 2)      fwd_stream_block<float, 2, FMA>(a, block, lds);
+  else if (rpl == 4) fwd_stream_block<float, 4, FMA>(a, block, lds);
+  else               fwd_stream_block<float, kRplF32, FMA>(a, block, lds);
+}
+template <bool FMA, int kRplF64>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pair_policy_multi_kernel(MultiArgs m) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WaveJob<double, kRplF64, FMA>::kLdsBytes];
+  static_assert(WaveJob<double, 2, FMA>::kLdsBytes <= WaveJob<double, kRplF64, FMA>::kLdsBytes &&
+                WaveJob<double, 4, FMA>::kLdsBytes <= WaveJob<double, kRplF64, FMA>::kLdsBytes, "LDS of the widest job");
+  const int r = multi_find(m, (int)blockIdx.x);
+  const SmallCall* c = m.call[r];
+  const int64_t p = (int)blockIdx.x - m.begin[r];
+  const FwdArgs<double> d = c->d;
+  const PairPolicyArgs q = c->q;
+  const int rows = c->rows;
+  if (rows == 2)      pair_policy_block<2, FMA>(d, q, p, lds);
+  else if (rows == 4) pair_policy_block<4, FMA>(d, q, p, lds);
+  else                pair_policy_block<kRplF64, FMA>(d, q, p, lds);
 }
 
 constexpr int kModePacked = kModePackedWords;  // FinalizeArgs::mode: `out` receives packed raw sums (kPackedF32Tag, pairhmm_fwd_kernel.h)

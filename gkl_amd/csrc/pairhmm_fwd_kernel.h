@@ -643,18 +643,22 @@ struct WaveJob {
 // ---- kernels -------------------------------------------------------------------
 // Main pass: block (one wavefront) = (chunk of packed reads) x (haplotype group).
 template <typename T, int RPL, bool FMA>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 2 : 4))) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
+__device__ __forceinline__ void fwd_stream_block(const FwdArgs<T>& a, int block, unsigned char* lds) {
   using Job = WaveJob<T, RPL, FMA>;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
-  const int g = blockIdx.x / a.n_chunks;  // group-major: the groups come in order of decreasing length
-  const int chunk = blockIdx.x - g * a.n_chunks;
+  const int g = block / a.n_chunks;  // group-major: the groups come in order of decreasing length
+  const int chunk = block - g * a.n_chunks;
   const HapGroup grp = a.groups[g];
   Job job;
   job.lds = lds;
   job.setup(a, lane, a.chunk_lanes[(int64_t)chunk * kLanes + lane]);
   __syncthreads();
   job.run(a, lane, grp.hap_begin, grp.hap_end);
+}
+template <typename T, int RPL, bool FMA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 2 : 4))) void pairhmm_fwd_stream_kernel(FwdArgs<T> a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WaveJob<T, RPL, FMA>::kLdsBytes];
+  fwd_stream_block<T, RPL, FMA>(a, (int)blockIdx.x, lds);
 }
 
 // Job-list pass (packed fp64 recomputation): persistent wavefronts pull (chunk, haplotype run)
@@ -706,11 +710,9 @@ struct PairPolicyArgs {
 constexpr int kModePackedWords = -2;
 
 template <int RPL, bool FMA>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pairhmm_pair_policy_kernel(FwdArgs<double> a, PairPolicyArgs q) {
+__device__ __forceinline__ void pair_policy_block(const FwdArgs<double>& a, const PairPolicyArgs& q, int64_t p, unsigned char* lds) {
   using Job = WaveJob<double, RPL, FMA>;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
-  const int64_t p = blockIdx.x;
   const float v = q.raw32[p];
   const bool fails = v < 1e-28f;  // NaN compares false and stays fp32, like the reference (IntelPairHmm.cc:159)
   if (lane == 0) q.used64[p] = fails ? 1 : 0;
@@ -738,6 +740,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
     if (q.mode == kModePackedWords) reinterpret_cast<uint64_t*>(q.out)[p] = packed_word(sum);
     else if (q.mode >= 0) q.out[p] = log10(sum) - q.log10_init_d;
   }
+}
+template <int RPL, bool FMA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pairhmm_pair_policy_kernel(FwdArgs<double> a, PairPolicyArgs q) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WaveJob<double, RPL, FMA>::kLdsBytes];
+  pair_policy_block<RPL, FMA>(a, q, (int64_t)blockIdx.x, lds);
 }
 
 // Long-read pass: a read with more rows than one chunk holds is processed stripe by stripe by

@@ -83,6 +83,8 @@ def load_library(path: Optional[str] = None):
     lib.gklhip_gather_backend.restype = C.c_int
     lib.gklhip_measure_issue_ceiling.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gklhip_measure_issue_ceiling.restype = C.c_int
+    lib.gklhip_small_call_counts.argtypes = [C.c_int, C.POINTER(C.c_int64), C.c_int]
+    lib.gklhip_small_call_counts.restype = C.c_int
     lib.gklhip_gather_note.argtypes = [C.c_void_p]
     lib.gklhip_gather_note.restype = C.c_char_p
     lib.gklhip_partition_reads.argtypes = [C.c_int32, _i64p, C.c_int32, C.POINTER(C.c_int32)]
@@ -202,6 +204,16 @@ def partition_reads(read_off, n_parts: int):
     if st != OK:
         _raise(lib, st)
     return list(bounds)
+
+
+def small_call_counts(device: int = 0, reset: bool = False):
+    """(small host-buffer calls, those launched together with other threads' calls, sets of launches) on `device`."""
+    lib = load_library()
+    out = (C.c_int64 * 3)()
+    st = lib.gklhip_small_call_counts(int(device), out, 1 if reset else 0)
+    if st != OK:
+        _raise(lib, st)
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def rccl_selftest(device: int = 0) -> None:

@@ -193,6 +193,12 @@ int gklhip_plan_describe(int32_t n_reads, int32_t n_haps, const int64_t* read_of
  * clock_ghz (may be NULL): shader cycles counted by the kernel / its duration = the clock sustained under that load. */
 int gklhip_measure_issue_ceiling(gklhip_ctx* ctx, int use_double, double ms_budget, double* cells_per_s, double* clock_ghz);
 
+/* Diagnostics: concurrent small host-buffer calls (a GATK region each, from several threads or JNI slots) are launched
+ * together when they meet on the device (GKL_HIP_COMBINE).  Process-wide counts for `device`:
+ * out[0] calls that took the small-call path, out[1] those of them launched together with other calls, out[2] sets of
+ * launches issued.  reset != 0 zeroes the counts after reading. */
+int gklhip_small_call_counts(int device, int64_t out[3], int reset);
+
 const char* gklhip_strerror(int status);
 /* Thread-local detail message of the last failing call on this thread. */
 const char* gklhip_last_error(void);
