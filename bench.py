@@ -176,10 +176,19 @@ def jni_records(batch, c1, host_ms):
             # every thread its own 100 reads (x 10 haplotypes): run_concurrent slices the reads by thread
             b = make_batch("hc", 100 * threads, 10, seed=DEFAULT_SEED)
             iters = 150
-            wall, t, calls = one(b, iters, 20, threads)
+            runs = sorted((one(b, iters, 20, threads) for _ in range(3)), key=lambda r: r[0])
+            wall, t, calls = runs[1]  # the median of three (the aggregate of many short calls moves +-10 % run to run)
             conc[f"callers_{threads}"] = {"aggregate_gcups": round(b.cells * iters / wall / 1e6, 1),
                                           "calls_per_s": round(threads * iters / wall * 1e3, 1),
-                                          "ms_per_call": round(t[3] / calls / 1e6, 4)}
+                                          "ms_per_call": round(t[3] / calls / 1e6, 4),
+                                          "best_of_3_gcups": round(b.cells * iters / runs[0][0] / 1e6, 1)}
+        try:
+            import ctypes as C
+            k = (C.c_int64 * 3)()
+            C.CDLL(mockjni.JNI_LIB).gklhip_small_call_counts(0, k, 0)
+            conc["launched_together"] = {"small_calls": int(k[0]), "combined": int(k[1]), "launch_sets": int(k[2])}
+        except (OSError, AttributeError):
+            pass
     finally:
         os.environ.pop("GKL_HIP_SLOTS", None)
     rec["note"] = ("through Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative with a mock JNIEnv; big calls are "

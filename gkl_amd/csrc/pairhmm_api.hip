@@ -307,11 +307,14 @@ constexpr int kTargetCols = 2048;  // columns of a full-size haplotype group (sw
 #define GKL_RPL_F32 8
 #endif
 constexpr int kRplF32 = GKL_RPL_F32;
+std::atomic<int> g_host_calls_in_flight{0};  // host-buffer calls inside the library right now, process-wide
 // fp32 main pass: which kernel.  rows_per_lane of the config: 0 = choose, 8 / 4 / 2 = that many rows per lane.
 // Choosing: a small batch (one GATK active region) gives the 8-row kernel fewer jobs than the chip has wavefront
 // slots worth filling (< 2 per SIMD), and a lone wavefront issues one instruction per ~6 cycles; fewer rows per
-// lane mean more chunks and a shorter step (2 rows: reads of up to 127 bases).
-int pick_f32_rpl(int forced, int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off) {
+// lane mean more chunks and a shorter step (2 rows: reads of up to 127 bases).  `load`: small host calls in flight in
+// this process -- they share the chip (and leave in combined launches, SmallCombiner), so their jobs count together
+// and the wider, cheaper-per-cell kernels pay from fewer jobs per call.
+int pick_f32_rpl(int forced, int n_reads, int n_haps, const int64_t* read_off, const int64_t* hap_off, int load = 1) {
   int max_len = 0;
   for (int r = 0; r < n_reads; r++) max_len = std::max(max_len, (int)(read_off[r + 1] - read_off[r]));
   if (forced == 2 && max_len <= 2 * kLanes - 1) return 2;
@@ -329,8 +332,8 @@ int pick_f32_rpl(int forced, int n_reads, int n_haps, const int64_t* read_off, c
                                                                         (4096 + chunks - 1) / chunks));
     return chunks * groups;
   };
-  if (jobs_at(kRplF32) >= 2048) return kRplF32;
-  if (jobs_at(4) >= 1024 || max_len > 2 * kLanes - 1) return 4;
+  if (jobs_at(kRplF32) * load >= 2048) return kRplF32;
+  if (jobs_at(4) * load >= 1024 || max_len > 2 * kLanes - 1) return 4;
   return 2;
 }
 
@@ -375,7 +378,12 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   const auto t_plan0 = std::chrono::steady_clock::now();
   Plan& plan = c->plan;
   const int rpl64 = kRplF64Jobs;
-  const int rpl_main = use_double ? rpl64 : pick_f32_rpl(c->cfg.rows_per_lane, n_reads, n_haps, db->read_off, db->hap_off);
+  static const int load_env = [] { const char* v = getenv("GKL_HIP_COMBINE_LOAD"); return v ? atoi(v) : 0; }();
+  // (about half of the calls inside the library are on the device at any moment, the others are being staged or
+  //  finalised: 16 callers of 100 x 10 regions keep the 4-row kernel -- the 8-row one needs three wavefronts per SIMD
+  //  to pay, tools/small_scaling.py -- and 32 callers get the 8-row one)
+  const int load = !defer ? 1 : load_env > 0 ? load_env : std::max(1, g_host_calls_in_flight.load(std::memory_order_relaxed) / 2);
+  const int rpl_main = use_double ? rpl64 : pick_f32_rpl(c->cfg.rows_per_lane, n_reads, n_haps, db->read_off, db->hap_off, load);
   static const int target_cols_env = [] { const char* v = getenv("GKLHIP_TARGET_COLS"); return v ? atoi(v) : 0; }();
   build_plan(n_reads, n_haps, db->read_off, db->hap_off, rpl_main, target_cols_env > 0 ? target_cols_env : kTargetCols, &plan);
   // Long reads: pseudo-chunks (lane 0 names the read) + one striped job per (read, stream group)
@@ -900,7 +908,6 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
 // min(cores, 8) threads -- one call alone takes all of it, the two engines of a pipelined or twin-engine call half each,
 // eight concurrent JNI slots one each -- so the process never runs more than that many finaliser threads at a time,
 // however many slots and engines exist.  GKL_HIP_FINALIZE_THREADS overrides (per call).
-std::atomic<int> g_host_calls_in_flight{0};
 struct HostCallInFlight {
   int share;
   HostCallInFlight() : share(g_host_calls_in_flight.fetch_add(1) + 1) {}
@@ -946,6 +953,7 @@ struct SmallCombiner {
   bool followers_sleep = false;  // the calls a leader launched for others: true = they sleep until the leader has seen the end, false = they wait on its event themselves
   int64_t n_calls = 0, n_combined = 0, n_launch_sets = 0;  // diagnostics (gklhip_small_call_counts)
   int64_t ns_queued = 0, ns_launch = 0, ns_sync = 0, ns_total = 0;
+  std::atomic<int64_t> ns_stage{0}, ns_run{0}, ns_finalize{0};  // per call, outside the lock
   static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
   int launch_single(const SmallCall& k, hipStream_t s) {
@@ -1125,10 +1133,17 @@ int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
   SmallLaunch small;
   const bool may_defer = inline_inputs && combine_enabled() && (!c->have_call_done || hipEventQuery(c->call_done) == hipSuccess);
   (void)hipGetLastError();  // (hipErrorNotReady of the query)
+  const int64_t t_call = SmallCombiner::now_ns();
   if ((rc = run_device(c, &db, pin_out, kModePacked, s, inline_inputs, may_defer ? &small : nullptr))) return rc;  // records policy_done
   if (small.filled) {
-    if ((rc = small_combiner(c->device)->run(small, s))) return rc;
+    SmallCombiner* k = small_combiner(c->device);
+    const int64_t t_staged = SmallCombiner::now_ns();
+    if ((rc = k->run(small, s))) return rc;
+    const int64_t t_done = SmallCombiner::now_ns();
     c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+    k->ns_stage.fetch_add(t_staged - t_call, std::memory_order_relaxed);
+    k->ns_run.fetch_add(t_done - t_staged, std::memory_order_relaxed);
+    k->ns_finalize.fetch_add(SmallCombiner::now_ns() - t_done, std::memory_order_relaxed);
     return GKLHIP_OK;
   }
   if (c->cfg.use_double || n_pairs <= kOnePassPairs) {
@@ -1889,7 +1904,14 @@ int gklhip_small_call_counts(int device, int64_t out[3], int reset) {
     fprintf(stderr, "[gklhip] small calls: %lld calls, %lld combined, %lld launch sets; per set: queued %.1f us (sum over its calls), launch %.1f us, sync %.1f us\n",
             (long long)k->n_calls, (long long)k->n_combined, (long long)k->n_launch_sets, k->ns_queued * 1e-3 / std::max<int64_t>(1, k->n_launch_sets),
             k->ns_launch * 1e-3 / std::max<int64_t>(1, k->n_launch_sets), k->ns_sync * 1e-3 / std::max<int64_t>(1, k->n_launch_sets));
-  if (reset) k->n_calls = k->n_combined = k->n_launch_sets = k->ns_queued = k->ns_launch = k->ns_sync = k->ns_total = 0;
+  if (getenv("GKLHIP_TIMING"))
+    fprintf(stderr, "[gklhip] small calls, per call: plan + staging %.1f us, queued + launches + wait %.1f us, host log10 %.1f us\n",
+            k->ns_stage.load() * 1e-3 / std::max<int64_t>(1, k->n_calls), k->ns_run.load() * 1e-3 / std::max<int64_t>(1, k->n_calls),
+            k->ns_finalize.load() * 1e-3 / std::max<int64_t>(1, k->n_calls));
+  if (reset) {
+    k->n_calls = k->n_combined = k->n_launch_sets = k->ns_queued = k->ns_launch = k->ns_sync = k->ns_total = 0;
+    k->ns_stage = 0; k->ns_run = 0; k->ns_finalize = 0;
+  }
   return GKLHIP_OK;
 }
 

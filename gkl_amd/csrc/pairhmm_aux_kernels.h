@@ -147,10 +147,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
   const int64_t p = (int)blockIdx.x - m.begin[r];
   const FwdArgs<double> d = c->d;
   const PairPolicyArgs q = c->q;
-  const int rows = c->rows;
-  if (rows == 2)      pair_policy_block<2, FMA>(d, q, p, lds);
-  else if (rows == 4) pair_policy_block<4, FMA>(d, q, p, lds);
-  else                pair_policy_block<kRplF64, FMA>(d, q, p, lds);
+  pair_policy_block<kRplF64, FMA>(d, q, p, lds);  // (rows per lane by the pair's own read)
 }
 
 constexpr int kModePacked = kModePackedWords;  // FinalizeArgs::mode: `out` receives packed raw sums (kPackedF32Tag, pairhmm_fwd_kernel.h)

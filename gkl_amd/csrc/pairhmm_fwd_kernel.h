@@ -709,10 +709,8 @@ struct PairPolicyArgs {
 };
 constexpr int kModePackedWords = -2;
 
-template <int RPL, bool FMA>
-__device__ __forceinline__ void pair_policy_block(const FwdArgs<double>& a, const PairPolicyArgs& q, int64_t p, unsigned char* lds) {
-  using Job = WaveJob<double, RPL, FMA>;
-  const int lane = threadIdx.x;
+// the policy's test on one pair; true: the pair must be recomputed in double precision
+__device__ __forceinline__ bool pair_policy_head(const PairPolicyArgs& q, int64_t p, int lane) {
   const float v = q.raw32[p];
   const bool fails = v < 1e-28f;  // NaN compares false and stays fp32, like the reference (IntelPairHmm.cc:159)
   if (lane == 0) q.used64[p] = fails ? 1 : 0;
@@ -722,11 +720,16 @@ __device__ __forceinline__ void pair_policy_block(const FwdArgs<double>& a, cons
       else if (q.mode == 1) q.out[p] = log10((double)v) - q.log10_init32_as_f64;                        // GKLHIP_FINALIZE_DEVICE_F64
       else if (q.mode == 2) q.out[p] = (double)((float)log10((double)v) - q.log10_init_f);             // GKLHIP_FINALIZE_DEVICE_REF32
     }
-    return;
+    return false;
   }
   if (lane == 0) atomicAdd(q.count, 1);
-  const int r = (int)(p / a.b.n_haps), k = q.hap_sidx[(int)(p - (int64_t)r * a.b.n_haps)];
-  const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+  return true;
+}
+template <int RPL, bool FMA>
+__device__ __forceinline__ void pair_policy_recompute(const FwdArgs<double>& a, const PairPolicyArgs& q, int64_t p, int r, int R, int k,
+                                                      unsigned char* lds) {
+  using Job = WaveJob<double, RPL, FMA>;
+  const int lane = threadIdx.x;
   LaneSlot slot;
   slot.read = lane < (R + RPL) / RPL ? r : -1;
   slot.block = lane;
@@ -741,9 +744,22 @@ __device__ __forceinline__ void pair_policy_block(const FwdArgs<double>& a, cons
     else if (q.mode >= 0) q.out[p] = log10(sum) - q.log10_init_d;
   }
 }
+// One pair per wavefront.  MAXR rows per lane hold the longest read of the call; a pair whose read fits fewer rows per
+// lane takes the narrower variant (same number of steps, half the instructions per step).
+template <int MAXR, bool FMA>
+__device__ __forceinline__ void pair_policy_block(const FwdArgs<double>& a, const PairPolicyArgs& q, int64_t p, unsigned char* lds) {
+  const int lane = threadIdx.x;
+  if (!pair_policy_head(q, p, lane)) return;
+  const int r = (int)(p / a.b.n_haps), k = q.hap_sidx[(int)(p - (int64_t)r * a.b.n_haps)];
+  const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+  if (MAXR > 2 && R <= 2 * kLanes - 1)      pair_policy_recompute<2, FMA>(a, q, p, r, R, k, lds);
+  else if (MAXR > 4 && R <= 4 * kLanes - 1) pair_policy_recompute<4, FMA>(a, q, p, r, R, k, lds);
+  else                                      pair_policy_recompute<MAXR, FMA>(a, q, p, r, R, k, lds);
+}
 template <int RPL, bool FMA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pairhmm_pair_policy_kernel(FwdArgs<double> a, PairPolicyArgs q) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[WaveJob<double, RPL, FMA>::kLdsBytes];
+  constexpr int kLds2 = WaveJob<double, 2, FMA>::kLdsBytes, kLds4 = WaveJob<double, 4, FMA>::kLdsBytes, kLdsR = WaveJob<double, RPL, FMA>::kLdsBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsR > kLds4 ? (kLdsR > kLds2 ? kLdsR : kLds2) : (kLds4 > kLds2 ? kLds4 : kLds2)];
   pair_policy_block<RPL, FMA>(a, q, (int64_t)blockIdx.x, lds);
 }
 
