@@ -103,8 +103,10 @@ struct gklhip_pdhmm_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
-  Buf tables, inputs, entries, sums, misc, carry, jobs;
+  Buf tables, inputs, entries, entries_tab, sums, misc, carry, jobs;
   float last_ms = 0.f;
+  int32_t last_routing[3] = {0, 0, 0};  // haplotype items of the last cross call: table kernel / predicate kernel / byte-comparing kernel
+  int use_table = 1;                    // GKL_HIP_PDHMM_TABLE=0: never route to the table kernel
   int fma_mode = 1;  // 1 = arithmetic of GKL's AVX-512 object (default), 0 = of its AVX2 object
   int tail_mode = 1; // 1 (default) = the last `batch mod SIMD width` pairs of every reference batch take the scalar engine's arithmetic, like GKL; 0 = vector arithmetic everywhere
 };
@@ -151,6 +153,8 @@ int gklhip_pdhmm_init(int device, gklhip_pdhmm_ctx** out_ctx) {
   {
     const char* tm = getenv("GKL_HIP_PDHMM_TAIL");
     c->tail_mode = (tm && (strcmp(tm, "vector") == 0 || strcmp(tm, "0") == 0)) ? 0 : 1;  // "reference" (default) | "vector"
+    const char* tb = getenv("GKL_HIP_PDHMM_TABLE");
+    c->use_table = (tb && tb[0] == '0') ? 0 : 1;
   }
   *out_ctx = c;
   return GKLHIP_OK;
@@ -168,7 +172,7 @@ int gklhip_pdhmm_done(gklhip_pdhmm_ctx* c) {
   if (!c) return GKLHIP_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->sums, &c->misc, &c->carry, &c->jobs}) b->release();
+  for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->entries_tab, &c->sums, &c->misc, &c->carry, &c->jobs}) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -185,6 +189,12 @@ int gklhip_pdhmm_set_fma_mode(gklhip_pdhmm_ctx* c, int fma_mode) {
 }
 
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* c) { return c ? c->last_ms : 0.f; }
+int gklhip_pdhmm_last_routing(gklhip_pdhmm_ctx* c, int32_t out[3]) {
+  if (!c || !out) return pd_fail(GKLHIP_ERR_INVALID_ARG, "NULL argument");
+  std::lock_guard<std::mutex> lock(c->mu);
+  for (int i = 0; i < 3; i++) out[i] = c->last_routing[i];
+  return GKLHIP_OK;
+}
 
 namespace {
 // Shared by the two entry points.  Paired layout: n_read_items == n_hap_items == n_pairs, cross_haps = 0.
@@ -403,11 +413,44 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   std::vector<uint8_t> hap_odd(nh, 0);
   for (size_t h = 0; h < nh; h++)   // (the paired layout holds a haplotype per PAIR: ~100 MB for 400k pairs, hence the SIMD scan)
     hap_odd[h] = has_odd_base(q.hap_bases + h * (size_t)q.max_hap_len, q.hap_lengths[h]) ? 1 : 0;
-  size_t n_clean_haps = nh;
+  size_t n_clean_haps = nh, n_tab_haps = 0;
+  // cross layout: a clean haplotype whose columns fall into at most kPdTabClasses classes of (base, SNP alleles, 'N')
+  // goes to the table kernel (pdhmm_fwd_tab_kernel); class c of haplotype h has the match bits class_codes[8 h + c]
+  std::vector<uint8_t> hap_ncls;
+  std::vector<uint32_t> class_codes;
   if (cross) {
+    hap_ncls.assign(nh, 0);
+    class_codes.assign(nh * 8, 0u);
+    for (size_t h = 0; h < nh && c->use_table; h++) {
+      if (hap_odd[h]) continue;
+      const int8_t* hb = q.hap_bases + h * (size_t)q.max_hap_len;
+      const int8_t* pd = q.hap_pdbases + h * (size_t)q.max_hap_len;
+      uint32_t* codes = class_codes.data() + h * 8;
+      int ncls = 0;
+      for (int64_t j = 0; j < q.hap_lengths[h] && ncls <= kPdTabClasses; j++) {
+        // (as pdhmm_entries_kernel builds the entry's match bits)
+        const uint32_t yb = (uint32_t)hb[j] & 0xffu, flags = (uint32_t)pd[j] & 0x7fu;
+        const uint32_t hot = yb == (uint32_t)'A' ? 1u : yb == (uint32_t)'C' ? 2u : yb == (uint32_t)'G' ? 4u : yb == (uint32_t)'T' ? 8u : 0u;
+        const uint32_t allele = (flags & kPdSnp) ? ((flags >> 3) & 0xfu) : 0u;
+        const uint32_t code = (hot << 20) | (allele << 24) | (1u << 28) | (yb == (uint32_t)'N' ? 1u << 29 : 0u);
+        int k = 0;
+        while (k < ncls && codes[k] != code) k++;
+        if (k == ncls) {
+          if (ncls < kPdTabClasses) codes[ncls] = code;
+          ncls++;
+        }
+      }
+      hap_ncls[h] = ncls <= kPdTabClasses ? (uint8_t)ncls : 0;
+    }
+    // order: table haplotypes, then the other clean ones, then those with odd bases (each group longest first)
     std::stable_partition(hap_order.begin(), hap_order.end(), [&](int32_t h) { return hap_odd[(size_t)h] == 0; });
     n_clean_haps = 0;
     for (size_t h = 0; h < nh; h++) n_clean_haps += hap_odd[h] == 0;
+    std::stable_partition(hap_order.begin(), hap_order.begin() + (ptrdiff_t)n_clean_haps, [&](int32_t h) { return hap_ncls[(size_t)h] != 0; });
+    for (size_t h = 0; h < nh; h++) n_tab_haps += hap_ncls[h] != 0;
+    c->last_routing[0] = (int32_t)n_tab_haps; c->last_routing[1] = (int32_t)(n_clean_haps - n_tab_haps); c->last_routing[2] = (int32_t)(nh - n_clean_haps);
+  } else {
+    c->last_routing[0] = c->last_routing[1] = c->last_routing[2] = 0;
   }
   size_t n_hot_general = 0;
   {
@@ -440,13 +483,15 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const int64_t n_cross_jobs64 = (int64_t)n_chunks_cross * (int64_t)(cross ? nh : 0);
   if (n_cross_jobs64 + (int64_t)job_pair.size() > 0x7fffffffLL) return pd_fail(GKLHIP_ERR_INVALID_ARG, "too many jobs");
   const int n_cross_jobs = (int)n_cross_jobs64;
-  const int n_cross_hot = cross ? (int)((int64_t)n_chunks_cross * (int64_t)n_clean_haps) : 0;
+  const int n_cross_tab = cross ? (int)((int64_t)n_chunks_cross * (int64_t)n_tab_haps) : 0;
+  const int n_cross_hot = cross ? (int)((int64_t)n_chunks_cross * (int64_t)(n_clean_haps - n_tab_haps)) : 0;
   const int n_general = (int)job_pair.size();
   const int n_jobs = n_cross_jobs + n_general;
   const int entry_stride = (q.max_hap_len + 2 * kLanes + 4 + 63) / 64 * 64;   // 64 idle, the columns, 63 skew + 4 look-ahead
   const int carry_len = entry_stride;
   const int n_blocks = std::max(1, std::min(std::max(n_jobs, (int)n_tail), 256 * 8));
   if ((rc = c->entries.reserve(nh * (size_t)entry_stride * 4))) return rc;
+  if (n_tab_haps && (rc = c->entries_tab.reserve(nh * (size_t)entry_stride * 4))) return rc;
   if ((rc = c->sums.reserve(n * 8))) return rc;
   if ((rc = c->misc.reserve(64))) return rc;
   if ((rc = c->carry.reserve((size_t)n_blocks * 2 * (6 * (size_t)carry_len + 64) * 8))) return rc;
@@ -455,7 +500,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
                o_ho = o_cl + up(cross_lanes.size() * sizeof(PlanLane)), o_cs = o_ho + up(hap_order.size() * 4),
                o_cr = o_cs + up(chunk_steps.size() * 4), o_tl = o_cr + up(chunk_rep.size() * 4),
                o_tp = o_tl + up(tail_lanes.size() * sizeof(PlanLane)), o_tn = o_tp + up(n_tail * 4), o_ts = o_tn + up(n_tail * 4),
-               jobs_total = o_ts + up(n_tail);
+               o_nc = o_ts + up(n_tail), o_cc = o_nc + up(hap_ncls.size()), jobs_total = o_cc + up(class_codes.size() * 4);
   if ((rc = c->jobs.reserve(jobs_total + 256))) return rc;
   unsigned char* dj = c->jobs.as<unsigned char>();
   auto put = [&](size_t off, const void* src, size_t bytes) {
@@ -473,6 +518,8 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   PD_HIP_TRY(put(o_tp, tail_pair.data(), n_tail * 4));
   PD_HIP_TRY(put(o_tn, tail_steps.data(), n_tail * 4));
   PD_HIP_TRY(put(o_ts, tail_striped.data(), n_tail));
+  PD_HIP_TRY(put(o_nc, hap_ncls.data(), hap_ncls.size()));
+  PD_HIP_TRY(put(o_cc, class_codes.data(), class_codes.size() * 4));
   PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
 
   const PdTables& t = pd_tables();
@@ -507,12 +554,24 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   a.hap_order = reinterpret_cast<const int32_t*>(dj + o_ho);
   a.chunk_steps = reinterpret_cast<const int32_t*>(dj + o_cs);
   a.chunk_rep = reinterpret_cast<const int32_t*>(dj + o_cr);
+  a.hap_ncls = n_tab_haps ? dj + o_nc : nullptr;
+  a.class_codes = reinterpret_cast<const uint32_t*>(dj + o_cc);
+  a.entries_tab = c->entries_tab.as<uint32_t>();
 
   hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)nh), dim3(kLanes), 0, s, a);   // one wavefront per haplotype item
   PD_HIP_TRY(hipEventRecord(c->ev0, s));
   {
-    // hot launch: cross jobs over the clean haplotypes + the first n_hot_general listed jobs
+    // table launch: cross jobs over the haplotypes with few column classes
+    if (n_cross_tab > 0) {
+      PdArgs at = a;
+      at.n_cross_jobs = at.n_jobs = n_cross_tab;
+      at.next = c->misc.as<int32_t>() + 4;
+      if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_tab_kernel<true>, dim3(std::min(n_cross_tab, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
+      else             hipLaunchKernelGGL(pdhmm_fwd_tab_kernel<false>, dim3(std::min(n_cross_tab, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
+    }
+    // hot launch: cross jobs over the other clean haplotypes + the first n_hot_general listed jobs
     PdArgs ah = a;
+    ah.hap_order = a.hap_order + n_tab_haps;
     ah.n_cross_jobs = n_cross_hot;
     ah.n_jobs = n_cross_hot + (int)n_hot_general;
     if (ah.n_jobs > 0) {
@@ -523,7 +582,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     PdArgs af = a;
     const int n_full_general = n_general - (int)n_hot_general;
     af.hap_order = a.hap_order + n_clean_haps;
-    af.n_cross_jobs = n_cross_jobs - n_cross_hot;
+    af.n_cross_jobs = n_cross_jobs - n_cross_hot - n_cross_tab;
     af.lanes = a.lanes + (int64_t)n_hot_general * kLanes;
     af.job_pair = a.job_pair + n_hot_general;
     af.job_steps = a.job_steps + n_hot_general;

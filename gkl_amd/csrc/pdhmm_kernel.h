@@ -42,6 +42,15 @@ constexpr int kPdSnp = 1, kPdDelStart = 2, kPdDelEnd = 4, kPdA = 8, kPdC = 16, k
 // Bit 15 ("special"): the column is entered inside or right after a deletion or carries DEL_END -- the one bit the
 // step loop ballots on.
 constexpr uint32_t kPdIdle = 1u << 30, kPdOdd = 1u << 31, kPdMatchBits = 0xfffffu, kPdSpecial = 1u << 15;
+// Table entries (a second stream, written for haplotypes whose columns fall into at most kPdTabClasses classes of
+// (base, SNP alleles, 'N') -- real PD haplotypes: the four bases and a few SNP columns): the match prior of a column
+// depends on its class and the read row only, so the job builds [class][row] priors per lane in LDS once and a step
+// FETCHES its six priors (three ds_read_b128) instead of evaluating the predicate per cell (and + compare + two selects
+// per row, a third of a plain step's issue time -- the PairHMM kernel's LDS prior planes).  Format: [14:0] the class's
+// byte offset in the lane-interleaved table (class * kPdTabClassBytes), bit 15 special, [17:16] state on entry,
+// bit 18 DEL_END, bit 30 idle.
+constexpr int kPdTabClasses = 6;
+constexpr uint32_t kPdTabDelEnd = 1u << 18, kPdTabOffsetMask = 0x7fffu;
 __device__ __forceinline__ uint32_t pd_onehot_acgt(uint32_t b) {
   return b == (uint32_t)'A' ? 1u : b == (uint32_t)'C' ? 2u : b == (uint32_t)'G' ? 4u : b == (uint32_t)'T' ? 8u : 0u;
 }
@@ -55,6 +64,12 @@ __device__ __forceinline__ uint32_t pd_onehot_acgt(uint32_t b) {
 #define GKL_PD_RPL 6
 #endif
 constexpr int kPdRpl = GKL_PD_RPL;
+#ifndef GKL_PD_TAB_UNROLL
+#define GKL_PD_TAB_UNROLL 1
+#endif
+constexpr int kPdTabPlanes = (kPdRpl + 1) / 2;              // 16-byte planes of one class: two rows' priors each
+constexpr int kPdTabClassBytes = kPdTabPlanes * kLanes * 16;  // [plane][lane][2 doubles]
+static_assert(kPdTabClasses * kPdTabClassBytes <= (int)kPdTabOffsetMask + 1, "class offsets fit the entry");
 
 struct PdArgs {
   const int8_t* hap_bases;     // [batch * max_hap]
@@ -95,6 +110,11 @@ struct PdArgs {
   const int32_t* hap_order;    // haplotype items, longest first
   const int32_t* chunk_steps;  // per chunk: highest row block in it (steps = hap_len + that)
   const int32_t* chunk_rep;    // per chunk: a read item of it (for idle lanes)
+  // table kernel (cross layout): per haplotype item the number of column classes (0: not eligible) and their match bits
+  // (entry bits [29:20]); entries_tab: the table-format stream of the eligible haplotypes (same stride as entries)
+  const uint8_t* hap_ncls;
+  const uint32_t* class_codes;  // [n_hap_items * 8]
+  uint32_t* entries_tab;
 };
 
 __device__ __forceinline__ int pd_read_of(const PdArgs& a, int p) { return a.cross_haps ? p / a.cross_haps : p; }
@@ -117,6 +137,12 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
   uint32_t* e = a.entries + (int64_t)p * a.entry_stride;
   e[lane] = kPdIdle;
   e += kLanes;
+  const int ncls = a.hap_ncls ? (int)a.hap_ncls[p] : 0;
+  uint32_t* et = ncls ? a.entries_tab + (int64_t)p * a.entry_stride : nullptr;
+  uint32_t codes[kPdTabClasses];
+#pragma unroll
+  for (int c = 0; c < kPdTabClasses; c++) codes[c] = ncls ? a.class_codes[(int64_t)p * 8 + c] : 0u;
+  if (et) { et[lane] = kPdIdle; et += kLanes; }
   int carry = -1;  // key of the last flagged column of the tiles before this one
   int first_flagged = H;  // first column with DEL_START / DEL_END (H: none)
   bool has_odd = false;
@@ -140,9 +166,15 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
       has_odd |= hot == 0u && yb != (uint32_t)'N';
       const uint32_t allele = (flags & kPdSnp) ? ((flags >> 3) & 0xfu) : 0u;
       const bool is_n = yb == (uint32_t)'N';
-      e[j] = yb | (flags << 8) | (state << 16) | (state << 18) | (hot << 20) | (allele << 24) | (1u << 28) |
-             (is_n ? 1u << 29 : 0u) | ((hot == 0u && !is_n) ? kPdOdd : 0u) |
-             ((state != 0u || (flags & kPdDelEnd) != 0u) ? kPdSpecial : 0u);
+      const uint32_t code = (hot << 20) | (allele << 24) | (1u << 28) | (is_n ? 1u << 29 : 0u);
+      const uint32_t special = (state != 0u || (flags & kPdDelEnd) != 0u) ? kPdSpecial : 0u;
+      e[j] = yb | (flags << 8) | (state << 16) | (state << 18) | code | ((hot == 0u && !is_n) ? kPdOdd : 0u) | special;
+      if (et) {
+        uint32_t cls = 0;
+#pragma unroll
+        for (int c = 1; c < kPdTabClasses; c++) cls = codes[c] == code ? (uint32_t)c : cls;  // (the host listed every code of the haplotype)
+        et[j] = cls * (uint32_t)kPdTabClassBytes | special | (state << 16) | ((flags & kPdDelEnd) ? kPdTabDelEnd : 0u);
+      }
     }
     const uint64_t fl = __ballot(flagged);
     if (fl && first_flagged == H) first_flagged = base + __builtin_ctzll(fl);
@@ -160,7 +192,10 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
       e[j] = (e[j] & ~(3u << 18)) | (st << 18);
     }
   }
-  for (int j = H + lane; j < a.entry_stride - kLanes; j += kLanes) e[j] = kPdIdle;
+  for (int j = H + lane; j < a.entry_stride - kLanes; j += kLanes) {
+    e[j] = kPdIdle;
+    if (et) et[j] = kPdIdle;
+  }
   // a haplotype with an odd column says so in its first (idle) word: its jobs run the byte-comparing steps throughout
   if (__ballot(has_odd) != 0 && lane == 0) e[-kLanes] = kPdIdle | kPdOdd;
 }
@@ -188,9 +223,12 @@ __device__ __forceinline__ double pd_fma3(double a, double b, double c) {
   return r;
 }
 
-template <bool FMA, bool kSerial = false, bool kHot = false>
+// kTab: the match priors come from the job's LDS table (table-format entries, see kPdTabClasses); only the two in-place
+// step loops, like kHot.
+template <bool FMA, bool kSerial = false, bool kHot = false, bool kTab = false>
 struct PdJob {
   static constexpr int RPL = kPdRpl;
+  static_assert(!kTab || (kHot && !kSerial), "the table kernel carries the in-place steps only");
   // six matrices, per row: match, insertion, deletion and their branch copies
   double mm[RPL], im[RPL], dm[RPL], bmm[RPL], bim[RPL], bdm[RPL];
   double tmm[RPL], tim[RPL], tmi[RPL], tii[RPL], tmd[RPL];  // (tii is also the deletion-to-deletion probability: both are 10^(-gcp/10))
@@ -204,6 +242,37 @@ struct PdJob {
   int32_t* status_flag;
   int row1_slot;      // kSerial: the slot holding the read's FIRST row (the only row that starts in NORMAL), else -1
   bool has_non_acgt;  // kSerial: some real row's base is not A/C/G/T (any case)
+  uint32_t tab_lane;  // kTab: LDS byte address of this lane's slot in class 0, plane 0
+
+  // kTab: the lane's [class][row] priors into LDS (after setup(); `codes`: the haplotype's class match bits).
+  // `lds_base`: the LDS byte address of the job's table.
+  typedef double PdVec2 __attribute__((ext_vector_type(2)));
+  typedef PdVec2 __attribute__((address_space(3))) PdLdsVec2;
+  __device__ __forceinline__ void build_table(uint32_t lds_base, int lane, const uint32_t* __restrict__ codes, int ncls) {
+    tab_lane = lds_base + (uint32_t)lane * 16u;
+    for (int c = 0; c < ncls; c++) {
+      const uint32_t code = codes[c];
+#pragma unroll
+      for (int pl = 0; pl < kPdTabPlanes; pl++) {
+        constexpr int kLast = RPL - 1;
+        const int s0 = 2 * pl, s1 = 2 * pl + 1 < RPL ? 2 * pl + 1 : kLast;
+        PdVec2 v;
+        v.x = (code & xinfo[s0]) > kPdMatchBits ? ptrue[s0] : pfalse[s0];
+        v.y = (code & xinfo[s1]) > kPdMatchBits ? ptrue[s1] : pfalse[s1];
+        *reinterpret_cast<PdLdsVec2*>((uintptr_t)(tab_lane + (uint32_t)(c * kPdTabClassBytes + pl * (kLanes * 16)))) = v;
+      }
+    }
+  }
+  // kTab: the priors of the entry's class (class offsets and the lane's slot are disjoint multiples: one add)
+  __device__ __forceinline__ void fetch_priors(uint32_t entry, double (&pr)[RPL]) const {
+    const uint32_t addr = (entry & kPdTabOffsetMask) + tab_lane;
+#pragma unroll
+    for (int pl = 0; pl < kPdTabPlanes; pl++) {
+      const PdVec2 v = *reinterpret_cast<const PdLdsVec2*>((uintptr_t)(addr + (uint32_t)(pl * (kLanes * 16))));
+      pr[2 * pl] = v.x;
+      if (2 * pl + 1 < RPL) pr[2 * pl + 1] = v.y;
+    }
+  }
 
   __device__ __forceinline__ void setup(const PdArgs& a, int p, int block, int n_blocks, bool active, double init) {
     const int ri = pd_read_of(a, p);
@@ -356,36 +425,75 @@ struct PdJob {
   // (own or the row above's) during a run of plain steps and the two general steps that follow every run rebuild them
   // (step_general: a branch copy after a step without events is the live value from before it), so a plain step touches
   // neither the copies nor d[3..5] / r[3..5].
+  // kFlip: the roles of d[0..2] (row above at the previous column) and r[0..2] (... at this column) are exchanged --
+  // the table kernel's plain loop is unrolled by two and alternates the roles instead of copying r to d every step
+  // (three 64-bit moves, as expensive as three fp64 operations); the hand-off then lands in the set that held the
+  // diagonal values, which are dead by then.
+  template <bool kFlip = false, bool kNoCopy = false>
   __device__ __forceinline__ void step_plain(uint32_t entry) {
     ent = entry;
+    if (kNoCopy) __builtin_amdgcn_sched_barrier(0);  // keep the two unrolled steps apart (interleaved they need 260+ registers)
+    double (&dg)[6] = kFlip ? r : d;   // diagonal inputs
+    double (&tp)[6] = kFlip ? d : r;   // inputs from the row above at this column
+    double pr[RPL];
+    if (kTab) fetch_priors(ent, pr);  // (idle entries read class 0: harmless)
     if ((ent & kPdIdle) == 0u) {
 #pragma unroll
       for (int s = RPL - 1; s >= 0; s--) {
-        const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
-        const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
+        const double mmD = s ? mm[s - 1] : dg[0], imD = s ? im[s - 1] : dg[1], dmD = s ? dm[s - 1] : dg[2];
+        if (!kTab) pr[s] = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
+        // kTab: the prior is multiplied in below, when the LDS reads have landed (same operations, same order per value)
         if (FMA) {
           dm[s] = pd_fma3(dm[s], tii[s], mm[s] * tmd[s]);
-          mm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
+          const double inner = __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
+          mm[s] = kTab ? inner : pr[s] * inner;
         } else {
           dm[s] = mm[s] * tmd[s] + dm[s] * tii[s];                       // pdhmm.h:431
-          mm[s] = pr * (mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]));   // :427-429
+          const double inner = mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]);
+          mm[s] = kTab ? inner : pr[s] * inner;                          // :427-429
         }
+      }
+      if (kTab) {
+#pragma unroll
+        for (int s = 0; s < RPL; s++) mm[s] = pr[s] * mm[s];
       }
 #pragma unroll
       for (int s = 0; s < RPL; s++) {
-        const double ia = s ? mm[s - 1] : r[0], ib = s ? im[s - 1] : r[1];
+        const double ia = s ? mm[s - 1] : tp[0], ib = s ? im[s - 1] : tp[1];
         if (FMA) im[s] = __builtin_fma(ib, tii[s], ia * tmi[s]);
         else im[s] = ia * tmi[s] + ib * tii[s];
       }
       sum = sum + (mm[RPL - 1] + im[RPL - 1]);  // finalSum += M + I, ascending columns (:839-846)
     }
-    d[0] = r[0]; d[1] = r[1]; d[2] = r[2];
-    asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));  // the copies first: the hand-off can then land in r's registers
-    r[0] = recv_above(mm[RPL - 1], lmask);
-    r[1] = recv_above(im[RPL - 1], lmask);
-    r[2] = recv_above(dm[RPL - 1], lmask);
+    if (kNoCopy) {
+      // the next step runs with the roles exchanged: this column's row-above values become its diagonal inputs where
+      // they are, the new hand-off replaces this step's diagonal inputs.  One group of six v_and_b32_dpp behind one
+      // s_nop (a DPP op straight behind another VALU op stalls the SIMD, tools/ubench_dpp.hip; and in the second step
+      // of a pair the compiler would split each into v_mov_b32_dpp + v_and_b32).
+      const uint64_t um = (uint64_t)__double_as_longlong(mm[RPL - 1]), ui = (uint64_t)__double_as_longlong(im[RPL - 1]),
+                     ud = (uint64_t)__double_as_longlong(dm[RPL - 1]);
+      uint32_t o0, o1, o2, o3, o4, o5;
+      asm("s_nop 1\n\t"
+          "v_and_b32_dpp %0, %6, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_and_b32_dpp %1, %7, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_and_b32_dpp %2, %8, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_and_b32_dpp %3, %9, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_and_b32_dpp %4, %10, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_and_b32_dpp %5, %11, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+          : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4), "=&v"(o5)
+          : "v"((uint32_t)um), "v"((uint32_t)(um >> 32)), "v"((uint32_t)ui), "v"((uint32_t)(ui >> 32)), "v"((uint32_t)ud),
+            "v"((uint32_t)(ud >> 32)), "v"(lmask));
+      dg[0] = __longlong_as_double((long long)(((uint64_t)o1 << 32) | o0));
+      dg[1] = __longlong_as_double((long long)(((uint64_t)o3 << 32) | o2));
+      dg[2] = __longlong_as_double((long long)(((uint64_t)o5 << 32) | o4));
+    } else {
+      d[0] = r[0]; d[1] = r[1]; d[2] = r[2];
+      asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));  // the copies first: the hand-off can then land in r's registers
+      r[0] = recv_above(mm[RPL - 1], lmask);
+      r[1] = recv_above(im[RPL - 1], lmask);
+      r[2] = recv_above(dm[RPL - 1], lmask);
+    }
   }
-
   // The general step of the vector arithmetic (not kSerial: a lane's rows share the column's state).  The three kinds
   // of special lane differ from a plain lane only in how INPUTS are merged, so each kind does its extra work under its
   // own EXEC mask and everything is updated in place, like step_plain (it also serves the two steps before a special
@@ -400,7 +508,9 @@ struct PdJob {
     ent = entry;
     const bool off = (ent & kPdIdle) != 0;
     const uint32_t state = (ent >> 16) & 3u;
-    const bool del_end = (ent & ((uint32_t)kPdDelEnd << 8)) != 0;
+    const bool del_end = (ent & (kTab ? kPdTabDelEnd : (uint32_t)kPdDelEnd << 8)) != 0;
+    double pr[RPL];
+    if (kTab) fetch_priors(ent, pr);
     if (!off) {
       if (state == 2u) {
         asm volatile("" ::: "memory");
@@ -418,14 +528,20 @@ struct PdJob {
 #pragma unroll
       for (int s = RPL - 1; s >= 0; s--) {
         const double mmD = s ? mm[s - 1] : d[0], imD = s ? im[s - 1] : d[1], dmD = s ? dm[s - 1] : d[2];
-        const double pr = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
+        if (!kTab) pr[s] = (ent & xinfo[s]) > kPdMatchBits ? ptrue[s] : pfalse[s];
         if (FMA) {
           dm[s] = pd_fma3(dm[s], tii[s], mm[s] * tmd[s]);
-          mm[s] = pr * __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
+          const double inner = __builtin_fma(mmD, tmm[s], __builtin_fma(dmD, tim[s], imD * tim[s]));
+          mm[s] = kTab ? inner : pr[s] * inner;
         } else {
           dm[s] = mm[s] * tmd[s] + dm[s] * tii[s];                       // pdhmm.h:431
-          mm[s] = pr * (mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]));   // :427-429
+          const double inner = mmD * tmm[s] + (imD * tim[s] + dmD * tim[s]);
+          mm[s] = kTab ? inner : pr[s] * inner;                          // :427-429
         }
+      }
+      if (kTab) {
+#pragma unroll
+        for (int s = 0; s < RPL; s++) mm[s] = pr[s] * mm[s];
       }
       if (del_end) {
         asm volatile("" ::: "memory");
@@ -479,6 +595,19 @@ struct PdJob {
     bool s0 = any_special(cur), s1 = any_special(n1), s2 = any_special(n2);
     int t = 0;
     while (t < n_steps) {
+      if (kTab && GKL_PD_TAB_UNROLL) {
+        // plain steps two at a time, the d / r roles alternating (see step_plain); no way out between the two, or the
+        // compiler restores the roles with copies on the main path
+        bool s3 = any_special(n3);
+        while (t + 2 <= n_steps && !(s0 || s1 || s2 || s3)) {
+          const uint32_t n4 = ep[t + 4], n5 = ep[t + 5];
+          step_plain<false, true>(cur);
+          step_plain<true, true>(n1);
+          t += 2;
+          cur = n2; n1 = n3; n2 = n4; n3 = n5;
+          s0 = s2; s1 = s3; s2 = any_special(n2); s3 = any_special(n3);
+        }
+      }
       while (t < n_steps && !(s0 || s1 || s2)) {
         const uint32_t n4 = ep[t + 4];
         const bool s3 = any_special(n3);
@@ -623,6 +752,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
       __threadfence_block();
     }
     if (job.holds_last) a.sums[rep] = job.sum;
+  }
+}
+
+// The table launch: cross jobs over the haplotypes whose columns fall into at most kPdTabClasses classes (see the
+// table entry format).  18 KB of LDS per wavefront: eight wavefronts per CU, the two per SIMD the register budget allows.
+template <bool FMA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pdhmm_fwd_tab_kernel(PdArgs a, double init_condition) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kPdTabClasses * kPdTabClassBytes];
+  const int lane = threadIdx.x;
+  using Job = PdJob<FMA, false, true, true>;
+  Job job;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+  for (;;) {
+    int j = 0;
+    if (lane == 0) j = atomicAdd(a.next, 1);
+    j = __builtin_amdgcn_readfirstlane(j);
+    if (j >= a.n_cross_jobs) break;
+    const int k = j / a.n_chunks_cross, chunk = j - k * a.n_chunks_cross;
+    const int hi = a.hap_order[k];
+    const LaneSlot sl = a.cross_lanes[(int64_t)chunk * kLanes + lane];
+    const bool active = sl.read >= 0;
+    const int ri = active ? sl.read : a.chunk_rep[chunk];
+    const int p = ri * a.cross_haps + hi;
+    const int H = (int)a.hap_len[hi];
+    const int n_blocks = ((int)a.read_len[ri] + Job::RPL) / Job::RPL;
+    job.setup(a, p, sl.block, n_blocks, active, init_condition / (double)H);
+    job.build_table(lds_base, lane, a.class_codes + (int64_t)hi * 8, (int)a.hap_ncls[hi]);
+    const uint32_t* e0 = a.entries_tab + (int64_t)hi * a.entry_stride;
+    job.run_packed(e0 + kLanes - sl.block, H + a.chunk_steps[chunk], false);
+    if (job.holds_last) a.sums[p] = job.sum;
   }
 }
 

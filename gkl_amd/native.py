@@ -393,6 +393,8 @@ def load_pdhmm_library(path: Optional[str] = None):
     lib.gklhip_pdhmm_done.restype = C.c_int
     lib.gklhip_pdhmm_last_kernel_ms.argtypes = [C.c_void_p]
     lib.gklhip_pdhmm_last_kernel_ms.restype = C.c_float
+    lib.gklhip_pdhmm_last_routing.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.gklhip_pdhmm_last_routing.restype = C.c_int
     lib.gklhip_pdhmm_get_table.argtypes = [C.c_int, C.c_void_p, C.c_int64]
     lib.gklhip_pdhmm_get_table.restype = C.c_int64
     lib.gklhip_pdhmm_last_error.restype = C.c_char_p
@@ -477,6 +479,14 @@ class PdhmmContext:
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.gklhip_pdhmm_last_kernel_ms(self.handle))
+
+    def last_routing(self):
+        """Haplotypes of the last cross call by kernel: (LDS prior table, predicate, byte-comparing)."""
+        out = (C.c_int32 * 3)()
+        st = self.lib.gklhip_pdhmm_last_routing(self.handle, out)
+        if st != OK:
+            self._raise(st)
+        return int(out[0]), int(out[1]), int(out[2])
 
     def close(self):
         if getattr(self, "handle", None):

@@ -87,6 +87,11 @@ int gklhip_pdhmm_compute_cross_batched(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm
 int64_t gklhip_pdhmm_reference_batch_pairs(int32_t max_memory_mb, int32_t max_read_len, int32_t max_hap_len, int64_t total_pairs);
 /* HIP-event time of the forward kernel of the last call, milliseconds. */
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* ctx);
+/* Diagnostics: how the last cross call's haplotypes were routed: out[0] to the table kernel (at most six classes of
+ * (base, SNP alleles, 'N') columns: the match priors come from an LDS table), out[1] to the predicate kernel, out[2] to
+ * the byte-comparing kernel (a base outside ACGTN).  All zero after a paired call.  GKL_HIP_PDHMM_TABLE=0 disables the
+ * table kernel.  Results are identical whichever kernel computes a pair. */
+int gklhip_pdhmm_last_routing(gklhip_pdhmm_ctx* ctx, int32_t out[3]);
 int gklhip_pdhmm_done(gklhip_pdhmm_ctx* ctx);
 /* host-built tables as uploaded: 0 qualToErrorProb[255], 1 matchToMatchProb[32640] */
 int64_t gklhip_pdhmm_get_table(int which, double* dst, int64_t cap);

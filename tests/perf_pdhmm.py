@@ -53,19 +53,22 @@ def main():
     print(f"fixture pdhmm_new, cross entry point ({cross_reads.batch} reads x {cross_haps.batch} haplotypes): {cc:.3e} cells  "
           f"kernel {best_k:.3f} ms = {cc / best_k / 1e6:.1f} GCUPS   host-to-host {best_w * 1e3:.2f} ms = "
           f"{cc / best_w / 1e9:.1f} GCUPS", flush=True)
+    routing = ctx0.last_routing()
     ctx0.close()
     summary = {"metric": "pdhmm_gcups", "unit": "GCUPS", "dtype": "f64", "data": "the reference's own fixture pdhmm_new.txt",
                "config": {"workload": f"IntelPDHMM.computeLikelihoods: {cross_reads.batch} reads x {cross_haps.batch} PD haplotypes "
                                       f"(the fixture's 276 reads x{a.fixture_x}), cross entry point", "cells": cc},
+               "haplotypes_by_kernel": {"lds_prior_table": routing[0], "predicate": routing[1], "byte_comparing": routing[2]},
                "kernel_ms": round(best_k, 4), "kernel_gcups": round(cc / best_k / 1e6, 1),
                "host_to_host_ms": round(best_w * 1e3, 3), "value": round(cc / best_w / 1e9, 1),
                # 12 flop per cell: M = prior * fma(.., fma(.., mul)) = 6, D = fma + mul = 3, I = fma + mul = 3 (pdhmm.h:427-443)
-               "roofline": {"bound": "mfma", "limiter": "valu-fp64 issue", "kernel": "pdhmm_fwd_kernel", "flop_per_cell": 12,
+               "roofline": {"bound": "mfma", "limiter": "valu-fp64 issue", "kernel": "pdhmm_fwd_tab_kernel", "flop_per_cell": 12,
                             "achieved": round(12 * cc / best_k / 1e9, 2), "peak": 78.6, "unit": "TFLOP/s",
                             "frac": round(12 * cc / best_k / 1e9 / 78.6, 4), "traffic": None,
                             "note": "fp64 vector recurrence (no contraction for MFMA), priced at the dense fp64 MFMA peak = "
-                                    "fp64 vector peak; 2 wavefronts per SIMD (240 VGPRs); a plain step is 34 fp64 operations in "
-                                    "about 90 instructions, 12 flop per cell caps the fraction at 0.75 (DESIGN.md section 7)"}}
+                                    "fp64 vector peak; 2 wavefronts per SIMD; table kernel (match priors from an LDS class table): a plain "
+                                    "step of 6 rows is 50 fp64 operations in 70 vector instructions; 12 flop per cell caps the "
+                                    "fraction at 0.75 (DESIGN.md section 7)"}}
     for name, b in cases.items():
         ctx.compute(b)
         best_k, best_w = 1e9, 1e9

@@ -372,6 +372,67 @@ def test_pdhmm_gpu_cross_entry_point_equals_paired(pd_ctx, pd_oracle):
     assert pd_ctx.compute(b).tobytes() == vec.tobytes()
 
 
+def expand_cross(reads, haps):
+    pairs = []
+    for r in range(reads.batch):
+        R = int(reads.read_lengths[r])
+        rr = lambda a: a.reshape(reads.batch, reads.max_read_len)[r, :R]  # noqa: E731
+        for h in range(haps.batch):
+            H = int(haps.hap_lengths[h])
+            hh = lambda a: a.reshape(haps.batch, haps.max_hap_len)[h, :H]  # noqa: E731
+            pairs.append((hh(haps.hap_bases), hh(haps.hap_pdbases), rr(reads.read_bases), rr(reads.read_qual),
+                          rr(reads.read_ins_qual), rr(reads.read_del_qual), rr(reads.gcp)))
+    return PdhmmBatch.from_pairs(pairs)
+
+
+@pytest.mark.gpu
+def test_pdhmm_gpu_table_kernel_routing_and_parity(pd_ctx, pd_oracle):
+    # A haplotype whose columns fall into at most six classes of (base, SNP alleles, 'N') takes the kernel that
+    # fetches its match priors from an LDS table; more classes -> the predicate kernel; a base outside ACGTN -> the
+    # byte-comparing one.  Same bits whichever kernel computes a pair.
+    rng = np.random.RandomState(77)
+    one = np.zeros(1, np.int8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.int8)
+
+    def hap(n_snp_kinds, with_n=False, odd=False, deletion=True):
+        H = int(rng.randint(120, 300))
+        b = acgt[rng.randint(0, 4, H)].copy()
+        pd = np.zeros(H, np.int8)
+        kinds = [(int(rng.randint(0, 4)), int(rng.randint(1, 16))) for _ in range(n_snp_kinds)]
+        for k, (base, alleles) in enumerate(kinds):           # every kind at least once, some twice
+            for j in rng.choice(np.arange(5, H - 5), 2, replace=False):
+                b[j] = acgt[base]
+                pd[j] = 1 | alleles << 3
+        if with_n:
+            b[int(rng.randint(0, H))] = ord("N")
+        if odd:
+            b[int(rng.randint(0, H))] = ord("a")
+        if deletion:
+            j = int(rng.randint(10, H - 20))
+            pd[j] |= 2
+            pd[j + int(rng.randint(1, 6))] |= 4
+        return b, pd
+
+    haps_l = [hap(0), hap(1), hap(2), hap(1, with_n=True),            # 4, 5, 6, 6 classes: table
+              hap(0, deletion=False), hap(2, deletion=False),
+              hap(3), hap(6), hap(2, with_n=True),                      # 7+ classes (all four bases occur in 120+ random columns): predicate
+              hap(1, odd=True), hap(0, odd=True)]                       # byte-comparing
+    haps = PdhmmBatch.from_pairs([(b, pd, one, one, one, one, one) for b, pd in haps_l])
+    reads = random_pd_batch(rng, 150, read_len=(1, 200), hap_len=(1, 2))   # lower-case and 'N' read bases included
+    got = pd_ctx.compute_cross(reads, haps)
+    tab, pred, odd = pd_ctx.last_routing()
+    assert odd == 2 and tab >= 6 and tab + pred + odd == len(haps_l), (tab, pred, odd)
+    _, vec = pd_oracle.compute(expand_cross(reads, haps), semantics=pd_ctx.sem)
+    assert got.tobytes() == vec.tobytes()
+    # the reference's own reads x haplotypes fixture: every haplotype has five or six classes
+    r2, h2, b2, _ = holders_fixture_batch()
+    src = PdhmmBatch.from_pairs([(one, one, *r) for r in r2])
+    hp = PdhmmBatch.from_pairs([(x[0], x[1], one, one, one, one, one) for x in h2])
+    got = pd_ctx.compute_cross(src, hp)
+    assert pd_ctx.last_routing() == (len(h2), 0, 0)
+    assert got.tobytes() == pd_oracle.compute(b2, semantics=pd_ctx.sem)[1].tobytes()
+
+
 @pytest.mark.gpu
 def test_pdhmm_gpu_argument_errors(pd_ctx):
     from gkl_amd import native
