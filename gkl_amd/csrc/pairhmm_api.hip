@@ -933,7 +933,7 @@ constexpr int kFlightSlots = 4;
 struct SmallCombiner {
   struct Ticket {
     const SmallLaunch* sl = nullptr;
-    int state = 0;  // 0 queued, 4 taken by a leader, 1 launched (wait for `ev`), 3 finished, 2 failed
+    int state = 0;  // 0 queued, 4 taken by a leader, 1 launched (wait for `ev`), 2 failed
     hipEvent_t ev = nullptr;
     int rc = GKLHIP_OK;
     std::string err;
@@ -950,9 +950,8 @@ struct SmallCombiner {
   Slot slot[kFlightSlots];
   int flights = 0;
   int max_flights = 3;
-  bool followers_sleep = false;  // the calls a leader launched for others: true = they sleep until the leader has seen the end, false = they wait on its event themselves
   int64_t n_calls = 0, n_combined = 0, n_launch_sets = 0;  // diagnostics (gklhip_small_call_counts)
-  int64_t ns_queued = 0, ns_launch = 0, ns_sync = 0, ns_total = 0;
+  int64_t ns_queued = 0, ns_launch = 0, ns_sync = 0;
   std::atomic<int64_t> ns_stage{0}, ns_run{0}, ns_finalize{0};  // per call, outside the lock
   static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -1032,13 +1031,13 @@ struct SmallCombiner {
       const int64_t t_launched = now_ns();
       if (n > 1) {
         l.lock();
-        if (!followers_sleep || rc != GKLHIP_OK) {
-          for (int i = 1; i < n; i++) {
-            batch[i]->rc = rc; batch[i]->err = err; batch[i]->ev = sl.ev;
-            batch[i]->state = rc == GKLHIP_OK ? 1 : 2;
-          }
-          cv.notify_all();
+        // (the others wait on the set's event themselves; letting them sleep until this thread has seen the end
+        //  measured the same)
+        for (int i = 1; i < n; i++) {
+          batch[i]->rc = rc; batch[i]->err = err; batch[i]->ev = sl.ev;
+          batch[i]->state = rc == GKLHIP_OK ? 1 : 2;
         }
+        cv.notify_all();
         l.unlock();
       }
       hipError_t e = hipSuccess;
@@ -1047,10 +1046,8 @@ struct SmallCombiner {
       l.lock();
       {
         const int64_t t_end = now_ns();
-        ns_launch += t_launched - t_lead; ns_sync += t_end - t_launched; ns_total += (t_end - t_in) + 0;
+        ns_launch += t_launched - t_lead; ns_sync += t_end - t_launched;
       }
-      if (followers_sleep && rc == GKLHIP_OK)
-        for (int i = 1; i < n; i++) batch[i]->state = 3;
       sl.busy = false;  // (the event is recorded again only from here on: a late waiter of this flight then waits a little longer)
       flights--;
       cv.notify_all();
@@ -1073,7 +1070,6 @@ SmallCombiner* small_combiner(int device) {
   if (!all[(size_t)device]) {
     all[(size_t)device] = new SmallCombiner();  // lives as long as the process (a handful of streams and events)
     if (const char* v = getenv("GKL_HIP_COMBINE_FLIGHTS")) all[(size_t)device]->max_flights = std::max(1, std::min(kFlightSlots, atoi(v)));
-    if (const char* v = getenv("GKL_HIP_COMBINE_WAIT")) all[(size_t)device]->followers_sleep = v[0] == 's';
   }
   return all[(size_t)device];
 }
@@ -1909,7 +1905,7 @@ int gklhip_small_call_counts(int device, int64_t out[3], int reset) {
             k->ns_stage.load() * 1e-3 / std::max<int64_t>(1, k->n_calls), k->ns_run.load() * 1e-3 / std::max<int64_t>(1, k->n_calls),
             k->ns_finalize.load() * 1e-3 / std::max<int64_t>(1, k->n_calls));
   if (reset) {
-    k->n_calls = k->n_combined = k->n_launch_sets = k->ns_queued = k->ns_launch = k->ns_sync = k->ns_total = 0;
+    k->n_calls = k->n_combined = k->n_launch_sets = k->ns_queued = k->ns_launch = k->ns_sync = 0;
     k->ns_stage = 0; k->ns_run = 0; k->ns_finalize = 0;
   }
   return GKLHIP_OK;
