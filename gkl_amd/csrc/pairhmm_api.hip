@@ -1020,11 +1020,7 @@ struct SmallCombiner {
       n_launch_sets++;
       if (n > 1) n_combined += n;
       int rc = GKLHIP_OK;
-      if (n > 1 && !sl.stream) {
-        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess)
-          rc = fail(GKLHIP_ERR_HIP, "stream for combined small calls");
-      }
+      if (n > 1 && !sl.stream) rc = fail(GKLHIP_ERR_HIP, "no stream for combined small calls");
       l.unlock();
       if (rc == GKLHIP_OK) rc = n == 1 ? launch_single(mine.call, own_stream) : launch_multi(batch, n, mine.call.fma, sl);
       const std::string err = rc == GKLHIP_OK ? std::string() : g_err;
@@ -1068,7 +1064,20 @@ SmallCombiner* small_combiner(int device) {
   std::lock_guard<std::mutex> l(mu);
   if ((int)all.size() <= device) all.resize((size_t)device + 1, nullptr);
   if (!all[(size_t)device]) {
-    all[(size_t)device] = new SmallCombiner();  // lives as long as the process (a handful of streams and events)
+    SmallCombiner* k = all[(size_t)device] = new SmallCombiner();  // lives as long as the process (a handful of streams and events)
+    // The flight streams are created together: the runtime deals streams round-robin onto the device's (four) hardware
+    // queues, so consecutive ones land on different queues and the sets in flight really run side by side.
+    int prev = 0;
+    const bool have_dev = hipGetDevice(&prev) == hipSuccess;
+    if (hipSetDevice(device) == hipSuccess) {
+      for (auto& sl : k->slot)
+        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) {
+          sl.stream = nullptr;  // (a set that gets this slot reports the failure)
+          (void)hipGetLastError();
+        }
+    }
+    if (have_dev) (void)hipSetDevice(prev);
     if (const char* v = getenv("GKL_HIP_COMBINE_FLIGHTS")) all[(size_t)device]->max_flights = std::max(1, std::min(kFlightSlots, atoi(v)));
   }
   return all[(size_t)device];
