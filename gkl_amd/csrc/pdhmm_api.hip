@@ -13,6 +13,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 #include "../../include/gkl_hip_pairhmm.h"  // status codes
@@ -104,6 +106,7 @@ struct gklhip_pdhmm_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
   Buf tables, inputs, entries, entries_tab, sums, misc, carry, jobs;
+  PackScratch pack_scratch;
   float last_ms = 0.f;
   int32_t last_routing[3] = {0, 0, 0};  // haplotype items of the last cross call: table kernel / predicate kernel / byte-comparing kernel
   int use_table = 1;                    // GKL_HIP_PDHMM_TABLE=0: never route to the table kernel
@@ -269,6 +272,9 @@ int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
 }
 
 int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
+  static const bool timing = getenv("GKLHIP_TIMING") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   PD_HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   const size_t n = (size_t)q.n_pairs;
@@ -281,21 +287,36 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   int rc;
   if ((rc = c->inputs.reserve(total))) return rc;
   unsigned char* d = c->inputs.as<unsigned char>();
-  PD_HIP_TRY(hipMemcpyAsync(d + o_hb, q.hap_bases, hap_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_hp, q.hap_pdbases, hap_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_rb, q.read_bases, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_rq, q.read_qual, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_ri, q.read_ins_qual, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_rd, q.read_del_qual, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_gc, q.gcp, read_bytes, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_hl, q.hap_lengths, nh * 8, hipMemcpyHostToDevice, s));
-  PD_HIP_TRY(hipMemcpyAsync(d + o_rl, q.read_lengths, nr * 8, hipMemcpyHostToDevice, s));
+  // The nine input copies (the paired layout of a big batch is hundreds of MB of padded [pair][maxLen] arrays: the
+  // calls alone -- pinning the caller's pages -- take milliseconds): a helper thread issues them while this one builds
+  // the jobs; both meet before anything else goes onto the stream.
+  struct Uploads {
+    hipError_t err = hipSuccess;
+    std::thread th;
+    ~Uploads() { if (th.joinable()) th.join(); }
+  } up_th;
+  auto do_uploads = [&, d]() {
+    auto cp = [&](size_t off, const void* src, size_t bytes) {
+      if (up_th.err != hipSuccess || bytes == 0) return;
+      up_th.err = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
+    };
+    (void)hipSetDevice(c->device);
+    cp(o_hb, q.hap_bases, hap_bytes); cp(o_hp, q.hap_pdbases, hap_bytes);
+    cp(o_rb, q.read_bases, read_bytes); cp(o_rq, q.read_qual, read_bytes); cp(o_ri, q.read_ins_qual, read_bytes);
+    cp(o_rd, q.read_del_qual, read_bytes); cp(o_gc, q.gcp, read_bytes);
+    cp(o_hl, q.hap_lengths, nh * 8); cp(o_rl, q.read_lengths, nr * 8);
+  };
+  if (hap_bytes + 5 * read_bytes >= ((size_t)8 << 20)) up_th.th = std::thread(do_uploads);
+  else do_uploads();
+  const double ms_uploads = ms_since(t_begin);
   const int cross = q.cross_haps;
   auto read_len_of = [&](size_t p) { return (int)q.read_lengths[cross ? p / (size_t)cross : p]; };
   auto hap_len_of = [&](size_t p) { return (int)q.hap_lengths[cross ? p % (size_t)cross : p]; };
 
   // ---- jobs ----
-  std::vector<PlanLane> lanes;                 // general packed jobs: [job][64] = {pair, block}
+  std::vector<int32_t> place_chunk;            // paired layout: compact packing of the pairs (pack_reads_place)
+  std::vector<uint8_t> place_lane, chunk_used;
+  size_t n_striped = 0;
   std::vector<int32_t> job_pair, job_steps;
   std::vector<uint8_t> job_striped;
   std::vector<PlanLane> cross_lanes;           // cross layout: [chunk][64] = {read item, block}
@@ -334,7 +355,6 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     for (size_t h = 0; h < nh; h++) hap_order[h] = (int32_t)h;
     std::stable_sort(hap_order.begin(), hap_order.end(),
                      [&](int32_t x, int32_t y) { return q.hap_lengths[x] > q.hap_lengths[y]; });
-    lanes.resize(job_pair.size() * kLanes, PlanLane{-1, 0});  // striped jobs do not use their lane rows
     // "Reference tail" of the cross product: computeLikelihoods expands it into read-major pairs, batch by batch
     // (JavaData.h:177-242), and computePDHMM finishes the last `batch mod SIMD width` pairs of EVERY batch with the
     // scalar engine (pdhmm.h:1264-1268).  The main launch computes all pairs with the vector arithmetic; the pairs at
@@ -391,28 +411,34 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     }
     for (size_t i = 0; i < n_vec; i++) {
       if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) continue;
-      job_pair.push_back((int32_t)i); job_striped.push_back(1); job_steps.push_back(0);
-      lanes.resize(lanes.size() + kLanes, PlanLane{-1, 0});  // striped job: its lane row stays unused
+      job_pair.push_back((int32_t)i); job_striped.push_back(1); job_steps.push_back(0);  // (a striped job's lane row stays unused)
     }
-    const int before = (int)(lanes.size() / kLanes);
-    const int made = pack_reads_windowed(shorts.data(), (int)shorts.size(), pair_off.data(), kPdRpl, 192, &lanes, nullptr);
-    for (int k = 0; k < made; k++) {
-      int32_t rep = -1, steps = 0;
-      const PlanLane* row = lanes.data() + (size_t)(before + k) * kLanes;
-      for (int l = 0; l < kLanes; l++) {
-        if (row[l].read < 0) continue;
-        if (rep < 0) rep = row[l].read;
-        steps = std::max(steps, (int32_t)hap_len_of((size_t)row[l].read) + row[l].block);
-      }
-      job_pair.push_back(rep); job_striped.push_back(0); job_steps.push_back(steps);
+    // compact packing (5 bytes per pair); pdhmm_expand_kernel turns it into the lane rows on the device
+    n_striped = job_pair.size();
+    place_chunk.assign(n, -1);
+    place_lane.assign(n, 0);
+    const int made = pack_reads_place(shorts.data(), (int)shorts.size(), pair_off.data(), kPdRpl, 192, place_chunk.data(),
+                                      place_lane.data(), &chunk_used, nullptr, &c->pack_scratch);
+    job_pair.resize(n_striped + (size_t)made, -1);
+    job_steps.resize(n_striped + (size_t)made, 0);
+    job_striped.resize(n_striped + (size_t)made, 0);
+    for (const int32_t i : shorts) {
+      const size_t j = n_striped + (size_t)place_chunk[(size_t)i];
+      if (job_pair[j] < 0) job_pair[j] = i;
+      job_steps[j] = std::max(job_steps[j], (int32_t)(hap_len_of((size_t)i) + blocks_for(read_len_of((size_t)i), kPdRpl) - 1));
     }
   }
+  const double ms_jobs = ms_since(t_begin);
   // ---- routing: the hot launch (only the two in-place step loops, see pdhmm_fwd_kernel) takes every job without a
   // striped read and without a haplotype that has a base outside ACGTN (such columns need the byte-comparing step);
-  // the rest -- rare -- go to a second launch of the full kernel.  Haplotypes / general jobs are reordered hot first.
-  std::vector<uint8_t> hap_odd(nh, 0);
-  for (size_t h = 0; h < nh; h++)   // (the paired layout holds a haplotype per PAIR: ~100 MB for 400k pairs, hence the SIMD scan)
-    hap_odd[h] = has_odd_base(q.hap_bases + h * (size_t)q.max_hap_len, q.hap_lengths[h]) ? 1 : 0;
+  // the rest -- rare -- go to a second launch of the full kernel.  Cross layout: the host looks at the (few)
+  // haplotypes and orders them by kernel.  Listed jobs (paired layout: every job): routed on the device
+  // (PdArgs::job_flags) -- a host scan of a haplotype per PAIR is ~100 MB for 400k pairs.
+  std::vector<uint8_t> hap_odd;
+  if (cross) {
+    hap_odd.assign(nh, 0);
+    for (size_t h = 0; h < nh; h++) hap_odd[h] = has_odd_base(q.hap_bases + h * (size_t)q.max_hap_len, q.hap_lengths[h]) ? 1 : 0;
+  }
   size_t n_clean_haps = nh, n_tab_haps = 0;
   // cross layout: a clean haplotype whose columns fall into at most kPdTabClasses classes of (base, SNP alleles, 'N')
   // goes to the table kernel (pdhmm_fwd_tab_kernel); class c of haplotype h has the match bits class_codes[8 h + c]
@@ -452,33 +478,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   } else {
     c->last_routing[0] = c->last_routing[1] = c->last_routing[2] = 0;
   }
-  size_t n_hot_general = 0;
-  {
-    const size_t ng = job_pair.size();
-    std::vector<uint8_t> full(ng, 0);
-    for (size_t j = 0; j < ng; j++) {
-      if (job_striped[j]) { full[j] = 1; continue; }
-      const PlanLane* row = lanes.data() + j * kLanes;
-      for (int l = 0; l < kLanes && !full[j]; l++)
-        if (row[l].read >= 0 && row[l].block == 0 && hap_odd[(size_t)(cross ? (size_t)row[l].read % (size_t)cross : (size_t)row[l].read)]) full[j] = 1;
-    }
-    std::vector<int32_t> order;
-    order.reserve(ng);
-    for (size_t j = 0; j < ng; j++) if (!full[j]) order.push_back((int32_t)j);
-    n_hot_general = order.size();
-    for (size_t j = 0; j < ng; j++) if (full[j]) order.push_back((int32_t)j);
-    if (n_hot_general != ng && n_hot_general != 0) {   // a mix: permute the four job arrays
-      std::vector<PlanLane> l2(lanes.size());
-      std::vector<int32_t> p2(ng), s2(ng);
-      std::vector<uint8_t> t2(ng);
-      for (size_t k = 0; k < ng; k++) {
-        const size_t j = (size_t)order[k];
-        std::copy(lanes.begin() + (ptrdiff_t)(j * kLanes), lanes.begin() + (ptrdiff_t)((j + 1) * kLanes), l2.begin() + (ptrdiff_t)(k * kLanes));
-        p2[k] = job_pair[j]; s2[k] = job_steps[j]; t2[k] = job_striped[j];
-      }
-      lanes.swap(l2); job_pair.swap(p2); job_steps.swap(s2); job_striped.swap(t2);
-    }
-  }
+  const double ms_routing = ms_since(t_begin);
   const int n_chunks_cross = (int)chunk_steps.size();
   const int64_t n_cross_jobs64 = (int64_t)n_chunks_cross * (int64_t)(cross ? nh : 0);
   if (n_cross_jobs64 + (int64_t)job_pair.size() > 0x7fffffffLL) return pd_fail(GKLHIP_ERR_INVALID_ARG, "too many jobs");
@@ -495,18 +495,21 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   if ((rc = c->sums.reserve(n * 8))) return rc;
   if ((rc = c->misc.reserve(64))) return rc;
   if ((rc = c->carry.reserve((size_t)n_blocks * 2 * (6 * (size_t)carry_len + 64) * 8))) return rc;
-  const size_t o_jl = 0, o_jp = up(lanes.size() * sizeof(PlanLane)), o_jn = o_jp + up((size_t)n_general * 4),
+  const size_t o_jl = 0, o_jp = up((size_t)n_general * kLanes * sizeof(PlanLane)), o_jn = o_jp + up((size_t)n_general * 4),
                o_js = o_jn + up((size_t)n_general * 4), o_cl = o_js + up((size_t)n_general),
                o_ho = o_cl + up(cross_lanes.size() * sizeof(PlanLane)), o_cs = o_ho + up(hap_order.size() * 4),
                o_cr = o_cs + up(chunk_steps.size() * 4), o_tl = o_cr + up(chunk_rep.size() * 4),
                o_tp = o_tl + up(tail_lanes.size() * sizeof(PlanLane)), o_tn = o_tp + up(n_tail * 4), o_ts = o_tn + up(n_tail * 4),
-               o_nc = o_ts + up(n_tail), o_cc = o_nc + up(hap_ncls.size()), jobs_total = o_cc + up(class_codes.size() * 4);
+               o_nc = o_ts + up(n_tail), o_cc = o_nc + up(hap_ncls.size()), o_jf = o_cc + up(class_codes.size() * 4),
+               o_pc = o_jf + up((size_t)n_general), o_pl = o_pc + up(place_chunk.size() * 4), o_cu = o_pl + up(place_lane.size()),
+               o_fj = o_cu + up(chunk_used.size()), jobs_total = o_fj + up((size_t)n_general * 4);
+  if (up_th.th.joinable()) up_th.th.join();
+  PD_HIP_TRY(up_th.err);
   if ((rc = c->jobs.reserve(jobs_total + 256))) return rc;
   unsigned char* dj = c->jobs.as<unsigned char>();
   auto put = [&](size_t off, const void* src, size_t bytes) {
     return bytes ? hipMemcpyAsync(dj + off, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
   };
-  PD_HIP_TRY(put(o_jl, lanes.data(), lanes.size() * sizeof(PlanLane)));
   PD_HIP_TRY(put(o_jp, job_pair.data(), (size_t)n_general * 4));
   PD_HIP_TRY(put(o_jn, job_steps.data(), (size_t)n_general * 4));
   PD_HIP_TRY(put(o_js, job_striped.data(), (size_t)n_general));
@@ -520,7 +523,18 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   PD_HIP_TRY(put(o_ts, tail_striped.data(), n_tail));
   PD_HIP_TRY(put(o_nc, hap_ncls.data(), hap_ncls.size()));
   PD_HIP_TRY(put(o_cc, class_codes.data(), class_codes.size() * 4));
+  PD_HIP_TRY(put(o_pc, place_chunk.data(), place_chunk.size() * 4));
+  PD_HIP_TRY(put(o_pl, place_lane.data(), place_lane.size()));
+  PD_HIP_TRY(put(o_cu, chunk_used.data(), chunk_used.size()));
+  if (n_general > 0) PD_HIP_TRY(hipMemsetAsync(dj + o_jf, 0, (size_t)n_general, s));
+  // the full launch's list of listed jobs: the striped ones (the first n_striped in the paired layout, all of them in
+  // the cross layout) from here, flagged packed jobs appended by pdhmm_collect_kernel; its length lives in misc[5]
+  const int32_t n_striped_listed = cross ? n_general : (int32_t)n_striped;   // (lives, like the vectors, until the stream is drained below)
+  std::vector<int32_t> full_first((size_t)n_striped_listed);
+  for (int32_t k = 0; k < n_striped_listed; k++) full_first[(size_t)k] = k;
   PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
+  PD_HIP_TRY(put(o_fj, full_first.data(), full_first.size() * 4));
+  PD_HIP_TRY(hipMemcpyAsync(c->misc.as<int32_t>() + 5, &n_striped_listed, 4, hipMemcpyHostToDevice, s));
 
   const PdTables& t = pd_tables();
   PdArgs a;
@@ -557,8 +571,25 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   a.hap_ncls = n_tab_haps ? dj + o_nc : nullptr;
   a.class_codes = reinterpret_cast<const uint32_t*>(dj + o_cc);
   a.entries_tab = c->entries_tab.as<uint32_t>();
+  a.job_flags = dj + o_jf;
+  a.full_jobs = reinterpret_cast<const int32_t*>(dj + o_fj);
+  a.full_count = c->misc.as<int32_t>() + 5;
 
   hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)nh), dim3(kLanes), 0, s, a);   // one wavefront per haplotype item
+  if (!cross && !chunk_used.empty()) {
+    PdExpandArgs x;
+    x.place_chunk = reinterpret_cast<const int32_t*>(dj + o_pc);
+    x.place_lane = dj + o_pl;
+    x.chunk_used = dj + o_cu;
+    x.read_len = a.read_len;
+    x.entries = a.entries; x.entry_stride = entry_stride;
+    x.lanes = reinterpret_cast<LaneSlot*>(dj + o_jl);
+    x.job_flags = dj + o_jf;
+    x.n_pairs = (int32_t)n; x.n_chunks = (int32_t)chunk_used.size(); x.n_striped = (int32_t)n_striped; x.rpl = kPdRpl;
+    hipLaunchKernelGGL(pdhmm_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x);
+    hipLaunchKernelGGL(pdhmm_collect_kernel, dim3((unsigned)((n_general + 255) / 256)), dim3(256), 0, s, dj + o_jf, dj + o_js, n_general,
+                       reinterpret_cast<int32_t*>(dj + o_fj), c->misc.as<int32_t>() + 5);
+  }
   PD_HIP_TRY(hipEventRecord(c->ev0, s));
   {
     // table launch: cross jobs over the haplotypes with few column classes
@@ -569,25 +600,20 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
       if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_tab_kernel<true>, dim3(std::min(n_cross_tab, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
       else             hipLaunchKernelGGL(pdhmm_fwd_tab_kernel<false>, dim3(std::min(n_cross_tab, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
     }
-    // hot launch: cross jobs over the other clean haplotypes + the first n_hot_general listed jobs
+    // hot launch: cross jobs over the other clean haplotypes + the listed jobs the device routes to it
     PdArgs ah = a;
     ah.hap_order = a.hap_order + n_tab_haps;
     ah.n_cross_jobs = n_cross_hot;
-    ah.n_jobs = n_cross_hot + (int)n_hot_general;
+    ah.n_jobs = n_cross_hot + (cross ? 0 : n_general);   // (cross layout: the listed jobs are striped reads, all the full kernel's)
     if (ah.n_jobs > 0) {
       if (c->fma_mode) hipLaunchKernelGGL((pdhmm_fwd_kernel<true, false, true>), dim3(std::min(ah.n_jobs, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
       else             hipLaunchKernelGGL((pdhmm_fwd_kernel<false, false, true>), dim3(std::min(ah.n_jobs, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
     }
-    // full launch: cross jobs over the haplotypes with odd bases + the remaining listed jobs (striped reads, odd haplotypes)
+    // full launch: cross jobs over the haplotypes with odd bases + the listed jobs with a striped read or an odd haplotype
     PdArgs af = a;
-    const int n_full_general = n_general - (int)n_hot_general;
     af.hap_order = a.hap_order + n_clean_haps;
     af.n_cross_jobs = n_cross_jobs - n_cross_hot - n_cross_tab;
-    af.lanes = a.lanes + (int64_t)n_hot_general * kLanes;
-    af.job_pair = a.job_pair + n_hot_general;
-    af.job_steps = a.job_steps + n_hot_general;
-    af.job_striped = a.job_striped + n_hot_general;
-    af.n_jobs = af.n_cross_jobs + n_full_general;
+    af.n_jobs = af.n_cross_jobs + n_general;
     af.next = c->misc.as<int32_t>() + 3;
     if (af.n_jobs > 0) {
       if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(std::min(af.n_jobs, n_blocks)), dim3(64), 0, s, af, t.initial_condition);
@@ -602,6 +628,8 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     at.job_striped = dj + o_ts;
     at.n_jobs = (int32_t)n_tail;
     at.n_cross_jobs = 0;
+    at.job_flags = nullptr;   // every tail job is this launch's
+    at.full_jobs = nullptr;
     at.next = c->misc.as<int32_t>() + 2;
     hipLaunchKernelGGL((pdhmm_fwd_kernel<false, true>), dim3((unsigned)std::min<size_t>(n_tail, (size_t)n_blocks)), dim3(64), 0, s, at, t.initial_condition);  // persistent: one carry slab per block
   }
@@ -611,11 +639,26 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   int32_t status[2] = {0, 0};
   PD_HIP_TRY(hipMemcpyAsync(sums.data(), c->sums.p, n * 8, hipMemcpyDeviceToHost, s));
   PD_HIP_TRY(hipMemcpyAsync(status, c->misc.p, 8, hipMemcpyDeviceToHost, s));
+  const double ms_launched = ms_since(t_begin);
   PD_HIP_TRY(hipStreamSynchronize(s));
   PD_HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  if (timing)
+    fprintf(stderr, "[gklhip] pdhmm call: uploads enqueued %.2f ms, jobs built %.2f, routed %.2f, launched %.2f, synchronised %.2f (kernels %.2f ms), %zu pairs\n",
+            ms_uploads, ms_jobs, ms_routing, ms_launched, ms_since(t_begin), (double)c->last_ms, n);
   if (status[0] != 0)  // PDHMM_INPUT_DATA_ERROR (pdhmm-serial.cc:183-199): negative ins / del / gcp quality
     return pd_fail(GKLHIP_ERR_INVALID_ARG, "Error while calculating pdhmm. Input arrays aren't valid.");
-  for (size_t i = 0; i < n; i++) out_host[i] = std::log10(sums[i]) - t.initial_condition_log10;  // pdhmm.h:846
+  auto finalise = [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) out_host[i] = std::log10(sums[i]) - t.initial_condition_log10;  // pdhmm.h:846
+  };
+  if (n >= 100000) {
+    const size_t parts = 4, per = (n + parts - 1) / parts;
+    std::thread th[parts - 1];
+    for (size_t k = 1; k < parts; k++) th[k - 1] = std::thread(finalise, std::min(n, k * per), std::min(n, (k + 1) * per));
+    finalise(0, std::min(n, per));
+    for (auto& x : th) x.join();
+  } else {
+    finalise(0, n);
+  }
   return GKLHIP_OK;
 }
 }  // namespace

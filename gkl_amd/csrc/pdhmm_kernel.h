@@ -115,6 +115,15 @@ struct PdArgs {
   const uint8_t* hap_ncls;
   const uint32_t* class_codes;  // [n_hap_items * 8]
   uint32_t* entries_tab;
+  // listed jobs routed on the device: job_flags[j] != 0 (set by pdhmm_expand_kernel: some haplotype of the job has a base
+  // outside ACGTN) or a striped job -> the full kernel's, everything else the hot kernel's; both launches walk the whole
+  // list.  NULL: the launch takes every listed job (the tail launch).
+  const uint8_t* job_flags;
+  // ... and the full launch walks this list instead (listed-job indices: the striped jobs from the host, then what
+  // pdhmm_collect_kernel appends), full_count[0] entries -- walking all listed jobs of a big paired batch just to skip
+  // them costs a millisecond of contended atomics
+  const int32_t* full_jobs;
+  const int32_t* full_count;
 };
 
 __device__ __forceinline__ int pd_read_of(const PdArgs& a, int p) { return a.cross_haps ? p / a.cross_haps : p; }
@@ -198,6 +207,45 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
   }
   // a haplotype with an odd column says so in its first (idle) word: its jobs run the byte-comparing steps throughout
   if (__ballot(has_odd) != 0 && lane == 0) e[-kLanes] = kPdIdle | kPdOdd;
+}
+
+// Paired layout: the host packs the pairs into chunks in compact form (pairhmm_plan.h pack_reads_place: chunk and
+// first lane per pair, lanes taken per chunk -- 5 bytes per pair instead of 512 bytes per chunk row); this kernel
+// expands it into the lane rows of the listed jobs and flags the jobs that need the byte-comparing steps (a haplotype
+// with a base outside ACGTN: its first stream word says so, written by pdhmm_entries_kernel earlier on the stream).
+struct PdExpandArgs {
+  const int32_t* place_chunk;   // [n_pairs], -1: not packed (striped read, tail pair)
+  const uint8_t* place_lane;
+  const uint8_t* chunk_used;    // [n_chunks]
+  const int64_t* read_len;      // per pair
+  const uint32_t* entries;
+  int32_t entry_stride;
+  LaneSlot* lanes;              // listed jobs' lane rows; chunk c is job n_striped + c
+  uint8_t* job_flags;
+  int32_t n_pairs, n_chunks, n_striped, rpl;
+};
+__global__ __launch_bounds__(256) void pdhmm_expand_kernel(PdExpandArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.n_pairs) {
+    const int ch = a.place_chunk[i];
+    if (ch >= 0) {
+      const int nb = ((int)a.read_len[i] + a.rpl) / a.rpl;
+      LaneSlot* dst = a.lanes + (int64_t)(a.n_striped + ch) * kLanes + a.place_lane[i];
+      for (int b = 0; b < nb; b++) dst[b] = LaneSlot{i, b};
+      if (a.entries[(int64_t)i * a.entry_stride] & kPdOdd) a.job_flags[a.n_striped + ch] = 1;
+    }
+  }
+  if (i < a.n_chunks) {
+    LaneSlot* dst = a.lanes + (int64_t)(a.n_striped + i) * kLanes;
+    for (int l = a.chunk_used[i]; l < kLanes; l++) dst[l] = LaneSlot{-1, 0};
+  }
+}
+
+// the flagged packed jobs, appended to the full launch's list (one thread per listed job)
+__global__ __launch_bounds__(256) void pdhmm_collect_kernel(const uint8_t* job_flags, const uint8_t* job_striped, int n_general,
+                                                           int32_t* full_jobs, int32_t* full_count) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n_general && job_flags[j] && !job_striped[j]) full_jobs[atomicAdd(full_count, 1)] = j;
 }
 
 // _mm256_max_pd / std::max on the values this recurrence produces (finite, non-negative, no -0): one v_max_f64.  Written
@@ -698,7 +746,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
     int j = 0;
     if (lane == 0) j = atomicAdd(a.next, 1);
     j = __builtin_amdgcn_readfirstlane(j);
-    if (j >= a.n_jobs) break;
+    const bool listed_by_index = !kHot && a.full_jobs != nullptr;  // the full launch: its listed jobs come from full_jobs
+    if (j >= (listed_by_index ? a.n_cross_jobs + a.full_count[0] : a.n_jobs)) break;
     if (j < a.n_cross_jobs) {
       const int k = j / a.n_chunks_cross, chunk = j - k * a.n_chunks_cross;
       const int hi = a.hap_order[k];
@@ -715,6 +764,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
       continue;
     }
     j -= a.n_cross_jobs;
+    if (listed_by_index) j = a.full_jobs[j];
+    else if (kHot && a.job_flags && (a.job_striped[j] != 0 || a.job_flags[j] != 0)) continue;  // the full launch's
     const int rep = a.job_pair[j];
     if (kHot || !a.job_striped[j]) {
       const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
