@@ -37,7 +37,7 @@ def main():
     from oracle.oracle import Oracle
     from oracle.pdhmm import PdhmmOracle
     from oracle.sw import SwOracle
-    from tests.test_pdhmm import cross_product, random_pd_batch
+    from tests.test_pdhmm import cross_product, expand_cross, random_pd_batch
 
     oracle, pdo, swo = Oracle(), PdhmmOracle(), SwOracle()
     ctxs = {}
@@ -102,6 +102,18 @@ def main():
             if st != 0 or got.tobytes() != vec.tobytes():
                 n_bad += 1
                 print(f"PDHMM MISMATCH seed={seed} fma={m} batch={pb.batch}", flush=True)
+            if rnd % 3 == 0:
+                # the cross entry point (what computeLikelihoodsNative calls): few flags -> the LDS-table kernel, many
+                # or odd bases -> the predicate / byte-comparing kernels, reads of 320+ bases -> striped jobs
+                fr = float(rng.choice([0.0, 0.005, 0.02, 0.15]))
+                prd = random_pd_batch(rng, int(rng.randint(1, 90)), read_len=(1, int(rng.randint(2, 400))), hap_len=(1, 2))
+                phd = random_pd_batch(rng, int(rng.randint(1, 10)), read_len=(1, 2), hap_len=(1, int(rng.randint(2, 400))), flag_rate=fr,
+                                      with_n=bool(rng.randint(0, 2)), odd_haps=float(rng.choice([0.0, 0.0, 0.3])))
+                got = pd_ctx[m].compute_cross(prd, phd)
+                st, vec = pdo.compute(expand_cross(prd, phd), semantics=2 if m == 1 else 0)
+                if st != 0 or got.tobytes() != vec.tobytes():
+                    n_bad += 1
+                    print(f"PDHMM CROSS MISMATCH seed={seed} fma={m} reads={prd.batch} haps={phd.batch} routing={pd_ctx[m].last_routing()}", flush=True)
             # ---------------- Smith-Waterman
             n_ref, n_alt = int(rng.randint(1, 700)), int(rng.randint(1, 700))
             ref = bytes(np.frombuffer(b"ACGT", np.uint8)[rng.randint(0, 4, n_ref)])
