@@ -47,10 +47,11 @@ constexpr uint32_t kPdIdle = 1u << 30, kPdOdd = 1u << 31, kPdMatchBits = 0xfffff
 // depends on its class and the read row only, so the job builds [class][row] priors per lane in LDS once and a step
 // FETCHES its six priors (three ds_read_b128) instead of evaluating the predicate per cell (and + compare + two selects
 // per row, a third of a plain step's issue time -- the PairHMM kernel's LDS prior planes).  Format: [14:0] the class's
-// byte offset in the lane-interleaved table (class * kPdTabClassBytes), bit 15 special, [17:16] state on entry,
-// bit 18 DEL_END, bit 30 idle.
+// byte offset in the lane-interleaved table (class * kPdTabClassBytes), [17:16] state on entry, bit 18 DEL_END,
+// bit 31 special (the sign: one signed compare in front of the ballot), an idle entry is exactly kPdIdle (one compare
+// against an inline constant instead of and + compare).
 constexpr int kPdTabClasses = 6;
-constexpr uint32_t kPdTabDelEnd = 1u << 18, kPdTabOffsetMask = 0x7fffu;
+constexpr uint32_t kPdTabDelEnd = 1u << 18, kPdTabOffsetMask = 0x7fffu, kPdTabSpecial = 1u << 31;
 __device__ __forceinline__ uint32_t pd_onehot_acgt(uint32_t b) {
   return b == (uint32_t)'A' ? 1u : b == (uint32_t)'C' ? 2u : b == (uint32_t)'G' ? 4u : b == (uint32_t)'T' ? 8u : 0u;
 }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
         uint32_t cls = 0;
 #pragma unroll
         for (int c = 1; c < kPdTabClasses; c++) cls = codes[c] == code ? (uint32_t)c : cls;  // (the host listed every code of the haplotype)
-        et[j] = cls * (uint32_t)kPdTabClassBytes | special | (state << 16) | ((flags & kPdDelEnd) ? kPdTabDelEnd : 0u);
+        et[j] = cls * (uint32_t)kPdTabClassBytes | (special ? kPdTabSpecial : 0u) | (state << 16) | ((flags & kPdDelEnd) ? kPdTabDelEnd : 0u);
       }
     }
     const uint64_t fl = __ballot(flagged);
@@ -485,7 +486,7 @@ struct PdJob {
     double (&tp)[6] = kFlip ? d : r;   // inputs from the row above at this column
     double pr[RPL];
     if (kTab) fetch_priors(ent, pr);  // (idle entries read class 0: harmless)
-    if ((ent & kPdIdle) == 0u) {
+    if (kTab ? ent != kPdIdle : (ent & kPdIdle) == 0u) {
 #pragma unroll
       for (int s = RPL - 1; s >= 0; s--) {
         const double mmD = s ? mm[s - 1] : dg[0], imD = s ? im[s - 1] : dg[1], dmD = s ? dm[s - 1] : dg[2];
@@ -554,7 +555,7 @@ struct PdJob {
   // (that form: 32 v_max_f64 + 64 v_cndmask + 44 v_mov per step).
   __device__ __forceinline__ void step_general(uint32_t entry) {
     ent = entry;
-    const bool off = (ent & kPdIdle) != 0;
+    const bool off = kTab ? ent == kPdIdle : (ent & kPdIdle) != 0;
     const uint32_t state = (ent >> 16) & 3u;
     const bool del_end = (ent & (kTab ? kPdTabDelEnd : (uint32_t)kPdDelEnd << 8)) != 0;
     double pr[RPL];
@@ -618,6 +619,7 @@ struct PdJob {
 
   // a column is special when it is entered in state INSIDE_DEL / AFTER_DEL or carries DEL_END
   static __device__ __forceinline__ bool any_special(uint32_t e) {
+    if (kTab) return __ballot((int32_t)e < 0) != 0;
     return __ballot((int)(e & kPdSpecial)) != 0;   // idle entries never carry the bit
   }
 
