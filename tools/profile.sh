@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
+CMD="python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace.err
 CMDS="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras"
 i=0

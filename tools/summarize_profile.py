@@ -44,7 +44,7 @@ with open(os.path.join(dst, f"{tag}_pmc.csv"), "w") as f:
 
 main = next((k for k in agg if "fwd_stream" in k), None)
 out = {"tag": tag}
-md = [f"# rocprofv3 summary `{tag}` (python bench.py --steps 10 --warmup 3, hc 10k x 128, 1x MI355X)", ""]
+md = [f"# rocprofv3 summary `{tag}` (python bench.py --steps 30 --warmup 5, hc 10k x 128, 1x MI355X)", ""]
 if rows:
     md += ["## kernel-trace --stats", "", "| kernel | calls | avg ns | total ns | % |", "|---|---|---|---|---|"]
     for r in rows[:8]:
