@@ -234,8 +234,8 @@ def in_library_probe(n_dev, reads, haps, workload, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hc", choices=["hc", "region", "mixed"])
     ap.add_argument("--reads", type=int, default=10000)
     ap.add_argument("--haps", type=int, default=128)
