@@ -297,7 +297,7 @@ constexpr int kRplF64 = GKL_RPL_F64;
 #endif
 constexpr int kRplF64Jobs = GKL_RPL_F64_JOBS;
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block
-constexpr int64_t kDirectPairs = 16384;        // calls up to this many pairs: policy + fp64 recomputation of one pair per wavefront in one launch
+constexpr int64_t kDirectPairs = 32768;        // calls up to this many pairs: policy + fp64 recomputation of one pair per wavefront in one launch (host calls of 24k / 32k pairs: 0.69 / 0.75 ms against 0.81 / 0.85 through the planned fp64 pass; equal at ~40k)
 constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the policy + planning kernel (a grid barrier costs ~50 ns per block)
 constexpr int kFallbackWantedJobs = 12288;     // the packed fp64 pass is cut into about this many jobs (4 per wavefront slot)
 constexpr int64_t kHostShardPairs = 400000;    // single-device host-buffer calls from this many pairs run as two half-batches (see gklhip_ctx::host_dev)
