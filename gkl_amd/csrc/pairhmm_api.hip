@@ -297,7 +297,8 @@ constexpr int kRplF64 = GKL_RPL_F64;
 #endif
 constexpr int kRplF64Jobs = GKL_RPL_F64_JOBS;
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block
-constexpr int64_t kDirectPairs = 32768;        // calls up to this many pairs: policy + fp64 recomputation of one pair per wavefront in one launch (host calls of 24k / 32k pairs: 0.69 / 0.75 ms against 0.81 / 0.85 through the planned fp64 pass; equal at ~40k)
+constexpr int64_t kDirectPairs = 65536;        // calls up to this many pairs: policy + fp64 recomputation of one pair per wavefront (host calls of 24k / 38k / 50k pairs: 0.64 / 0.74 / 0.96 ms against 0.81 / 0.82 / 1.09 through the planned fp64 pass; equal at 80k)
+constexpr int64_t kTwoStepFrom = 2048;         // ... from this many pairs in two launches: policy + list of the failing pairs, then their recomputation (10k / 16k / 32k pairs: 0.37 / 0.45-0.48 / 0.72-0.84 ms against 0.43 / 0.49-0.54 / 0.76-0.97 in one)
 constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the policy + planning kernel (a grid barrier costs ~50 ns per block)
 constexpr int kFallbackWantedJobs = 12288;     // the packed fp64 pass is cut into about this many jobs (4 per wavefront slot)
 constexpr int64_t kHostShardPairs = 400000;    // single-device host-buffer calls from this many pairs run as two half-batches (see gklhip_ctx::host_dev)
@@ -337,6 +338,20 @@ int pick_f32_rpl(int forced, int n_reads, int n_haps, const int64_t* read_off, c
   return 2;
 }
 
+// the per-pair policy of a mid-size call in two launches (pairhmm_pair_flag_kernel): `list` holds n_pairs entries
+void launch_pair_policy_two_step(const FwdArgs<double>& d, const PairPolicyArgs& q, int rows, int fma, int64_t n_pairs, int32_t* list, hipStream_t s) {
+  hipLaunchKernelGGL(pairhmm_pair_flag_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, q, (int32_t)n_pairs, list);
+  const dim3 grid((unsigned)std::max<int64_t>(256, n_pairs / 2)), block(64);
+  if (fma) {
+    if (rows == 2)      hipLaunchKernelGGL((pairhmm_pair_recompute_kernel<2, true>), grid, block, 0, s, d, q, list);
+    else if (rows == 4) hipLaunchKernelGGL((pairhmm_pair_recompute_kernel<4, true>), grid, block, 0, s, d, q, list);
+    else                hipLaunchKernelGGL((pairhmm_pair_recompute_kernel<kRplF64, true>), grid, block, 0, s, d, q, list);
+  } else {
+    if (rows == 2)      hipLaunchKernelGGL((pairhmm_pair_recompute_kernel<2, false>), grid, block, 0, s, d, q, list);
+    else if (rows == 4) hipLaunchKernelGGL((pairhmm_pair_recompute_kernel<4, false>), grid, block, 0, s, d, q, list);
+    else                hipLaunchKernelGGL((pairhmm_pair_recompute_kernel<kRplF64, false>), grid, block, 0, s, d, q, list);
+  }
+}
 void launch_main_f32(const FwdArgs<float>& a, int rpl_main, int fma, int n_blocks, hipStream_t s) {
   if (rpl_main == 2)      launch_stream<float, 2>(a, fma, n_blocks, s);
   else if (rpl_main == 4) launch_stream<float, 4>(a, fma, n_blocks, s);
@@ -493,7 +508,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   // (the one-pair-per-wavefront policy kernel holds at most 64 x kRplF64 - 1 rows)
   const bool per_pair_call = !use_double && n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
   const bool deferred_launch = defer && pull && inline_host && c->cfg.record_events == 0 && per_pair_call && n_long_main == 0 &&
-                               finalize_mode == kModePacked && plan.n_chunks > 0;
+                               finalize_mode == kModePacked && plan.n_chunks > 0 && n_pairs <= kTwoStepFrom;
   const unsigned char* hs_dev = nullptr;  // the staging block as the device sees it
   if (pull) {
     void* p = nullptr;
@@ -704,7 +719,12 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
         return GKLHIP_OK;
       }
       if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
-      launch_pair_policy(d, q, rows, fma, n_pairs, s);
+      if (n_pairs > kTwoStepFrom) {
+        if ((rc = c->fail_order.reserve((size_t)n_pairs * 4))) return rc;
+        launch_pair_policy_two_step(d, q, rows, fma, n_pairs, c->fail_order.as<int32_t>(), s);
+      } else {
+        launch_pair_policy(d, q, rows, fma, n_pairs, s);
+      }
       if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
       HIP_TRY(hipEventRecord(c->policy_done, s));
     } else {

@@ -763,6 +763,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
   pair_policy_block<RPL, FMA>(a, q, (int64_t)blockIdx.x, lds);
 }
 
+// Mid-size calls (thousands of pairs): the same per-pair policy in two launches.  One block per PAIR leaves the
+// dispatcher at ~150-200 blocks per microsecond, and the recomputing blocks scattered through a grid of 16 000 start up
+// to 100 us late (tools/small_scaling.py: 66 us for 1000 pairs, 165 us for 16 000 with the same share recomputing).
+// Here a thread per pair applies the policy and compacts the failing pairs into a list; the recomputing wavefronts
+// then sit at the FRONT of a grid half the size and start at once.
+__global__ __launch_bounds__(256) void pairhmm_pair_flag_kernel(PairPolicyArgs q, int32_t n_pairs, int32_t* list) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool fails = false;
+  if (p < n_pairs) {
+    const float v = q.raw32[p];
+    fails = v < 1e-28f;  // NaN compares false and stays fp32, like the reference (IntelPairHmm.cc:159)
+    q.used64[p] = fails ? 1 : 0;
+    if (!fails) {
+      if (q.mode == kModePackedWords) reinterpret_cast<uint64_t*>(q.out)[p] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
+      else if (q.mode == 1) q.out[p] = log10((double)v) - q.log10_init32_as_f64;                        // GKLHIP_FINALIZE_DEVICE_F64
+      else if (q.mode == 2) q.out[p] = (double)((float)log10((double)v) - q.log10_init_f);             // GKLHIP_FINALIZE_DEVICE_REF32
+    }
+  }
+  const uint64_t m = __ballot(fails);
+  if (m) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(q.count, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (fails) list[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+  }
+}
+template <int MAXR, bool FMA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pairhmm_pair_recompute_kernel(FwdArgs<double> a, PairPolicyArgs q,
+                                                                                                           const int32_t* list) {
+  constexpr int kLds2 = WaveJob<double, 2, FMA>::kLdsBytes, kLds4 = WaveJob<double, 4, FMA>::kLdsBytes, kLdsR = WaveJob<double, MAXR, FMA>::kLdsBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsR > kLds4 ? (kLdsR > kLds2 ? kLdsR : kLds2) : (kLds4 > kLds2 ? kLds4 : kLds2)];
+  const int n = *reinterpret_cast<const volatile int32_t*>(q.count);
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int64_t p = list[i];
+    const int r = (int)(p / a.b.n_haps), k = q.hap_sidx[(int)(p - (int64_t)r * a.b.n_haps)];
+    const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+    if (MAXR > 2 && R <= 2 * kLanes - 1)      pair_policy_recompute<2, FMA>(a, q, p, r, R, k, lds);
+    else if (MAXR > 4 && R <= 4 * kLanes - 1) pair_policy_recompute<4, FMA>(a, q, p, r, R, k, lds);
+    else                                      pair_policy_recompute<MAXR, FMA>(a, q, p, r, R, k, lds);
+    __syncthreads();  // (a block that takes a second pair reuses the prior table)
+  }
+}
+
 // Long-read pass: a read with more rows than one chunk holds is processed stripe by stripe by
 // one persistent wavefront per (read, haplotype run) job; `carry` is per-wavefront scratch for
 // the two ping-pong carry rows (2 x 3 x carry_len values).

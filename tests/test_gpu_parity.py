@@ -140,6 +140,33 @@ def test_hc_batch_policy_and_tolerance(native, ctx32, ctx64, oracle):
     assert np.mean(ref32 == out) > 0.9
 
 
+@pytest.mark.parametrize("shape", [(300, 8), (230, 60), (800, 30), (500, 128)])
+def test_mid_size_calls_policy_in_two_launches(native, oracle, shape):
+    """2049 .. 65536 pairs: the per-pair policy runs as a flag + compaction launch and a recomputation launch whose
+    wavefronts sit at the front of the grid (pairhmm_pair_flag_kernel); one launch below, the planned fp64 pass above."""
+    n_reads, n_haps = shape
+    b = make_batch("hc", n_reads, n_haps, seed=5 + n_reads)
+    assert 2048 < b.n_pairs <= 65536
+    for fma in (1, 0):
+        with native.PairHmmContext(fma_mode=fma) as c:
+            out, u = check_against_oracle(c, oracle, b, fma_mode=fma)
+            assert c.stats()["n_fallback"] == int(u.sum()) > 0
+    # the device finalisation modes write through the flag kernel too
+    import torch
+    db = native.DeviceBatch.upload(b)
+    with native.PairHmmContext(finalize=native.FINALIZE_DEVICE_F64) as c:
+        dev = c.compute_device(db)
+        torch.cuda.synchronize()
+        assert np.max(np.abs(dev.cpu().numpy() - out) / np.abs(out)) < REL_TOL
+    with native.PairHmmContext(finalize=native.FINALIZE_DEVICE_REF32) as c:
+        ref32 = c.compute_device(db).cpu().numpy()
+    assert np.max(np.abs(ref32 - out)) <= 3.9e-6
+    # reads of 384 bases or more do not fit the one-pair-per-wavefront kernel: such a call takes the planned pass
+    long_b = make_batch("hc", 120, 30, seed=9, read_len=(300, 450), hap_len=(400, 600))
+    with native.PairHmmContext() as c:
+        check_against_oracle(c, oracle, long_b)
+
+
 @pytest.mark.parametrize("rpl", [4, 8])
 def test_every_fp32_kernel_variant_bit_exact(native, oracle, rpl):
     """rows_per_lane 8 = the 8-row kernel (what auto picks for big batches), 4 = the 4-row kernel (what auto
