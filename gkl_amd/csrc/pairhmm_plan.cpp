@@ -46,7 +46,7 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   }
   if (target_cols < 256) target_cols = 256;
   int n_groups = (int)((total_cols + target_cols - 1) / target_cols);
-  bool equal_split = true;
+  bool equal_split = true, graded = false;
   if (rows_per_lane > 0) {
     // Small batches (one active region of GATK is a few hundred reads x a few dozen haplotypes): a job is one
     // (chunk, group) and the chip has 1024 SIMDs x 4 wavefront slots, so cut the stream finer -- down to one
@@ -65,8 +65,15 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
     }
     const int64_t chunks_est = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
     static const int wanted_env = [] { const char* v = getenv("GKLHIP_WANTED_JOBS"); return v ? atoi(v) : 0; }();
-    const int64_t wanted = wanted_env > 0 ? wanted_env : kWantedJobs;
-    const int64_t by_jobs = (wanted + chunks_est - 1) / chunks_est;
+    // Mid-size calls (a few hundred reads x tens of haplotypes: up to ~300 chunks) get three times as many, shorter
+    // jobs of GRADED length (below): 250 x 128 532 -> 320 us, 450 x 100 563 -> 435, 1000 x 50 583 -> 467 (fp32
+    // kernel; docs/NOTES.md 23).  A count just above one set of wavefront slots (4096 = 1024 SIMDs x 4) is cut back to
+    // one set: the few jobs of a second set would double the time.
+    const int64_t slots = kWantedJobs, chunks_hi = chunks_est + chunks_est / 100 + 1;  // (the packing may need a chunk more than the estimate)
+    const int64_t wanted = wanted_env > 0 ? wanted_env : (chunks_est <= 320 ? 3 * slots : slots);
+    int64_t by_jobs = std::min<int64_t>((wanted + chunks_est - 1) / chunks_est, n_haps);
+    if (chunks_hi * by_jobs > slots && chunks_hi * by_jobs * 10 <= slots * 13) by_jobs = std::max<int64_t>(1, slots / chunks_hi);
+    graded = chunks_hi * by_jobs > slots;
     if (by_jobs >= n_groups) n_groups = (int)by_jobs;
     else equal_split = false;
   }
@@ -78,6 +85,13 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
   if (equal_split || total_cols < 3 * (int64_t)target_cols) {
     const int64_t per_group = (total_cols + n_groups - 1) / n_groups;
     want.assign((size_t)n_groups, per_group);
+    // Graded sizes (1.35 x ... 0.65 x the mean, long ones first) when there is more than one set of jobs: jobs of ONE
+    // length fill the wavefront slots in lockstep -- every set ends at the same moment and the next one is dispatched
+    // and set up into an empty chip (two or three exact sets of 4096 equal jobs ran 1.3-1.65 x slower than 2.7 or 3.7
+    // sets); within a single set equal jobs are the shortest way through.
+    if (graded && equal_split && n_groups >= 4)
+      for (int i = 0; i < n_groups; i++)
+        want[(size_t)i] = std::max<int64_t>(1, (int64_t)((double)per_group * (1.35 - 0.7 * (double)i / (double)(n_groups - 1))));
   } else {
     const int64_t tail[4] = {target_cols / 2, target_cols / 4, target_cols / 8, target_cols / 8};
     const int64_t head = total_cols - target_cols;  // the tail sums to target_cols
