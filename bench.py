@@ -503,6 +503,10 @@ def main():
                 res["small_batch"] = {"c1_100x10": host_call_record(native, c1, dev_index, calls=60, warm=30),
                                       f"eighth_{eighth.n_reads}x{eighth.n_haps}": host_call_record(native, eighth, dev_index, calls=20, warm=10),
                                       "note": "through gklhip_compute, back-to-back single calls, median"}
+                # regions with many reads / haplotypes (4k..50k pairs): graded job lengths, two-launch per-pair policy
+                for mr, mh in ((400, 40), (250, 128), (1000, 50)):
+                    mid = make_batch(a.workload, mr, mh, seed=DEFAULT_SEED)
+                    res["small_batch"][f"mid_{mr}x{mh}"] = host_call_record(native, mid, dev_index, calls=30, warm=10)
                 try:
                     # the 8-GPU strong-scaling step on one GPU: an eighth of the batch, device-resident, pipelined -- on one
                     # stream, and on two streams through ONE context (the library gives each stream an engine) and through two
