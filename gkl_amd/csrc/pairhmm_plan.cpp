@@ -65,12 +65,13 @@ void build_plan(int n_reads, int n_haps, const int64_t* read_off, const int64_t*
     }
     const int64_t chunks_est = std::max<int64_t>(1, (blocks + kLanes - 1) / kLanes);
     static const int wanted_env = [] { const char* v = getenv("GKLHIP_WANTED_JOBS"); return v ? atoi(v) : 0; }();
-    // Mid-size calls (a few hundred reads x tens of haplotypes: up to ~650 chunks) get three times as many, shorter
+    // Mid-size calls (a few hundred reads x tens of haplotypes: up to ~650 chunks) and tall ones (thousands of reads x a
+    // few haplotypes: up to four full-size groups of columns; 5000 x 16: 938 -> 686 us) get three times as many, shorter
     // jobs of GRADED length (below): 250 x 128 532 -> 320 us, 450 x 100 563 -> 435, 1000 x 50 583 -> 467 (fp32
     // kernel; docs/NOTES.md 23).  A count just above one set of wavefront slots (4096 = 1024 SIMDs x 4) is cut back to
     // one set: the few jobs of a second set would double the time.
     const int64_t slots = kWantedJobs, chunks_hi = chunks_est + chunks_est / 100 + 1;  // (the packing may need a chunk more than the estimate)
-    const int64_t wanted = wanted_env > 0 ? wanted_env : (chunks_est <= 650 ? 3 * slots : slots);
+    const int64_t wanted = wanted_env > 0 ? wanted_env : (chunks_est <= 650 || total_cols <= 4 * (int64_t)target_cols ? 3 * slots : slots);
     int64_t by_jobs = std::min<int64_t>((wanted + chunks_est - 1) / chunks_est, n_haps);
     if (chunks_hi * by_jobs > slots && chunks_hi * by_jobs * 10 <= slots * 13) by_jobs = std::max<int64_t>(1, slots / chunks_hi);
     graded = chunks_hi * by_jobs > slots;
