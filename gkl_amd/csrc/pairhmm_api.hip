@@ -333,7 +333,8 @@ int pick_f32_rpl(int forced, int n_reads, int n_haps, const int64_t* read_off, c
                                                                         (4096 + chunks - 1) / chunks));
     return chunks * groups;
   };
-  if (jobs_at(kRplF32) * load >= 2048) return kRplF32;
+  // (a read of 256 bases or more does not fit 64 lanes x 4 rows: it would take the striped long-read kernel)
+  if (jobs_at(kRplF32) * load >= 2048 || max_len > 4 * kLanes - 1) return kRplF32;
   if (jobs_at(4) * load >= 1024 || max_len > 2 * kLanes - 1) return 4;
   return 2;
 }
@@ -626,7 +627,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   fa.log10_init_d = host_tables_f64().log10_initial;
 
   const int n_main_blocks = plan.n_chunks * (int)plan.groups.size();
-  const int n_long_waves = 512;  // persistent wavefronts of the striped long-read kernel
+  // persistent wavefronts of the striped long-read kernel: one per job up to two per SIMD (each owns two carry rows of
+  // the longest stream group: ~110 KB)
+  const int n_long_waves = (int)std::min<size_t>(2048, std::max<size_t>(512, std::max(long_jobs.size(), (size_t)n_long64 * plan.groups.size())));
   if (n_long_main > 0 || n_long64 > 0) {
     if ((rc = c->carry.reserve((size_t)n_long_waves * 2 * (3 * (size_t)carry_len + 64) * sizeof(double)))) return rc;
   }
