@@ -505,7 +505,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   if (c->have_call_done && c->last_stream != s) HIP_TRY(hipStreamWaitEvent(s, c->call_done, 0));
   // Big plans ride the upload stream (the copy overlaps the previous call's kernels); a small plan (GATK-sized
   // call) is PULLED from the pinned staging block by the prep kernel itself: no copy-engine hop at all.
-  const bool pull = L.total < (256u << 10);
+  const bool pull = L.total < (1u << 20);  // (256 KB .. 2 MB measure within 2 % on calls of 4k-50k pairs, 1 MB best)
   // (the one-pair-per-wavefront policy kernel holds at most 64 x kRplF64 - 1 rows)
   const bool per_pair_call = !use_double && n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
   const bool deferred_launch = defer && pull && inline_host && c->cfg.record_events == 0 && per_pair_call && n_long_main == 0 &&
