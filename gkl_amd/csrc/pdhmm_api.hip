@@ -98,6 +98,20 @@ struct Buf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   template <typename T> T* as() const { return static_cast<T*>(p); }
 };
+struct PinBuf {  // page-locked host memory, grow-only
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return GKLHIP_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = n + n / 4 + 256;
+    PD_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return GKLHIP_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
 }  // namespace
 
 struct gklhip_pdhmm_ctx {
@@ -107,6 +121,7 @@ struct gklhip_pdhmm_ctx {
   std::mutex mu;
   Buf tables, inputs, entries, entries_tab, sums, misc, carry, jobs;
   PackScratch pack_scratch;
+  PinBuf stage_in, stage_jobs, sums_pin;   // small calls: ONE copy per device buffer instead of one per array (9 + 17 of them)
   float last_ms = 0.f;
   int32_t last_routing[3] = {0, 0, 0};  // haplotype items of the last cross call: table kernel / predicate kernel / byte-comparing kernel
   int use_table = 1;                    // GKL_HIP_PDHMM_TABLE=0: never route to the table kernel
@@ -176,6 +191,7 @@ int gklhip_pdhmm_done(gklhip_pdhmm_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->entries_tab, &c->sums, &c->misc, &c->carry, &c->jobs}) b->release();
+  for (PinBuf* b : {&c->stage_in, &c->stage_jobs, &c->sums_pin}) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -271,6 +287,7 @@ int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   return rc;
 }
 
+constexpr size_t kPdStageBytes = (size_t)4 << 20;
 int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   static const bool timing = getenv("GKLHIP_TIMING") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -306,8 +323,22 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     cp(o_rd, q.read_del_qual, read_bytes); cp(o_gc, q.gcp, read_bytes);
     cp(o_hl, q.hap_lengths, nh * 8); cp(o_rl, q.read_lengths, nr * 8);
   };
-  if (hap_bytes + 5 * read_bytes >= ((size_t)8 << 20)) up_th.th = std::thread(do_uploads);
-  else do_uploads();
+  // A call of the fixture's size (276 reads x 48 haplotypes) spent half its time in two dozen small copies from
+  // pageable memory (~10 us each): up to kPdStageBytes the arrays are gathered in a pinned block and travel in ONE copy.
+  const bool staged = total <= kPdStageBytes;
+  if (staged) {
+    if ((rc = c->stage_in.reserve(total))) return rc;
+    unsigned char* h = c->stage_in.as<unsigned char>();
+    memcpy(h + o_hb, q.hap_bases, hap_bytes); memcpy(h + o_hp, q.hap_pdbases, hap_bytes);
+    memcpy(h + o_rb, q.read_bases, read_bytes); memcpy(h + o_rq, q.read_qual, read_bytes); memcpy(h + o_ri, q.read_ins_qual, read_bytes);
+    memcpy(h + o_rd, q.read_del_qual, read_bytes); memcpy(h + o_gc, q.gcp, read_bytes);
+    memcpy(h + o_hl, q.hap_lengths, nh * 8); memcpy(h + o_rl, q.read_lengths, nr * 8);
+    PD_HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
+  } else if (hap_bytes + 5 * read_bytes >= ((size_t)8 << 20)) {
+    up_th.th = std::thread(do_uploads);
+  } else {
+    do_uploads();
+  }
   const double ms_uploads = ms_since(t_begin);
   const int cross = q.cross_haps;
   auto read_len_of = [&](size_t p) { return (int)q.read_lengths[cross ? p / (size_t)cross : p]; };
@@ -507,8 +538,14 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   PD_HIP_TRY(up_th.err);
   if ((rc = c->jobs.reserve(jobs_total + 256))) return rc;
   unsigned char* dj = c->jobs.as<unsigned char>();
+  const bool staged_jobs = jobs_total <= kPdStageBytes;
+  if (staged_jobs && (rc = c->stage_jobs.reserve(jobs_total + 256))) return rc;
+  unsigned char* hj = c->stage_jobs.as<unsigned char>();
+  size_t staged_hi = 0;  // bytes of the staging block in use
   auto put = [&](size_t off, const void* src, size_t bytes) {
-    return bytes ? hipMemcpyAsync(dj + off, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+    if (!bytes) return hipSuccess;
+    if (staged_jobs) { memcpy(hj + off, src, bytes); staged_hi = std::max(staged_hi, off + bytes); return hipSuccess; }
+    return hipMemcpyAsync(dj + off, src, bytes, hipMemcpyHostToDevice, s);
   };
   PD_HIP_TRY(put(o_jp, job_pair.data(), (size_t)n_general * 4));
   PD_HIP_TRY(put(o_jn, job_steps.data(), (size_t)n_general * 4));
@@ -526,7 +563,10 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   PD_HIP_TRY(put(o_pc, place_chunk.data(), place_chunk.size() * 4));
   PD_HIP_TRY(put(o_pl, place_lane.data(), place_lane.size()));
   PD_HIP_TRY(put(o_cu, chunk_used.data(), chunk_used.size()));
-  if (n_general > 0) PD_HIP_TRY(hipMemsetAsync(dj + o_jf, 0, (size_t)n_general, s));
+  if (n_general > 0) {
+    if (staged_jobs) { memset(hj + o_jf, 0, (size_t)n_general); staged_hi = std::max(staged_hi, o_jf + (size_t)n_general); }
+    else PD_HIP_TRY(hipMemsetAsync(dj + o_jf, 0, (size_t)n_general, s));
+  }
   // the full launch's list of listed jobs: the striped ones (the first n_striped in the paired layout, all of them in
   // the cross layout) from here, flagged packed jobs appended by pdhmm_collect_kernel; its length lives in misc[5]
   const int32_t n_striped_listed = cross ? n_general : (int32_t)n_striped;   // (lives, like the vectors, until the stream is drained below)
@@ -534,6 +574,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   for (int32_t k = 0; k < n_striped_listed; k++) full_first[(size_t)k] = k;
   PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
   PD_HIP_TRY(put(o_fj, full_first.data(), full_first.size() * 4));
+  if (staged_jobs && staged_hi > 0) PD_HIP_TRY(hipMemcpyAsync(dj, hj, staged_hi, hipMemcpyHostToDevice, s));
   PD_HIP_TRY(hipMemcpyAsync(c->misc.as<int32_t>() + 5, &n_striped_listed, 4, hipMemcpyHostToDevice, s));
 
   const PdTables& t = pd_tables();
@@ -635,9 +676,10 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   }
   PD_HIP_TRY(hipEventRecord(c->ev1, s));
   PD_HIP_TRY(hipGetLastError());
-  std::vector<double> sums(n);
-  int32_t status[2] = {0, 0};
-  PD_HIP_TRY(hipMemcpyAsync(sums.data(), c->sums.p, n * 8, hipMemcpyDeviceToHost, s));
+  if ((rc = c->sums_pin.reserve(n * 8 + 16))) return rc;
+  double* sums = c->sums_pin.as<double>();
+  int32_t* status = reinterpret_cast<int32_t*>(sums + n);
+  PD_HIP_TRY(hipMemcpyAsync(sums, c->sums.p, n * 8, hipMemcpyDeviceToHost, s));
   PD_HIP_TRY(hipMemcpyAsync(status, c->misc.p, 8, hipMemcpyDeviceToHost, s));
   const double ms_launched = ms_since(t_begin);
   PD_HIP_TRY(hipStreamSynchronize(s));
