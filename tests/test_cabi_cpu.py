@@ -81,6 +81,38 @@ def test_planner_packs_every_read_once_and_routes_long_reads():
         assert rows / (n_chunks * 64 * rpl) > 0.88  # best-fit packing keeps the lanes full
 
 
+def test_planner_job_counts_avoid_a_sparse_second_set_of_wavefront_slots():
+    # jobs of the fp32 pass = chunks x haplotype groups on 4096 wavefront slots (1024 SIMDs x 4).  Mid-size and tall
+    # batches get about three sets of graded jobs; a count just above one set is cut back to one set (a handful of
+    # equal-length jobs in a second set doubled the kernel time: docs/NOTES.md 23, 24); big batches keep full-size groups.
+    from gkl_amd import native
+    from gkl_amd.synth import make_batch
+    lib = native.load_library()
+    lib.gklhip_plan_describe.restype = C.c_int
+
+    def jobs(n_reads, n_haps, rpl=8):
+        b = make_batch("hc", n_reads, n_haps, seed=11)
+        ng = C.c_int32()
+        n_chunks = lib.gklhip_plan_describe(n_reads, n_haps, np.ascontiguousarray(b.read_off).ctypes.data_as(C.c_void_p),
+                                            np.ascontiguousarray(b.hap_off).ctypes.data_as(C.c_void_p), rpl, None, C.c_int64(0),
+                                            C.byref(ng), None)
+        assert n_chunks > 0
+        return n_chunks, ng.value
+
+    for shape in ((100, 10), (150, 30), (400, 40), (250, 128), (450, 100), (500, 128), (1000, 50), (2000, 30), (5000, 16), (5000, 8)):
+        chunks, groups = jobs(*shape)
+        n = chunks * groups
+        assert groups <= shape[1]
+        assert not (4096 < n <= 4096 * 1.3), (shape, chunks, groups)       # never a set and a bit
+        if shape[0] * shape[1] >= 30000:
+            assert n > 2 * 4096, (shape, chunks, groups)                    # about three sets, graded
+    # a GATK-sized region: one haplotype per group (as many short jobs as there are)
+    assert jobs(100, 10, rpl=4)[1] >= 8
+    # the bench batch keeps its ~2048-column groups (+ the halving tail)
+    chunks, groups = jobs(10000, 128)
+    assert 18 <= groups <= 26 and chunks > 2500
+
+
 def test_tables_bit_identical_to_oracle(oracle):
     from gkl_amd import native
     for dt in (np.float32, np.float64):
