@@ -161,6 +161,17 @@ def test_mid_size_calls_policy_in_two_launches(native, oracle, shape):
     with native.PairHmmContext(finalize=native.FINALIZE_DEVICE_REF32) as c:
         ref32 = c.compute_device(db).cpu().numpy()
     assert np.max(np.abs(ref32 - out)) <= 3.9e-6
+    if n_reads == 300:
+        # more failing pairs than recomputing blocks (the grid is half the pairs: blocks take several), and none at all
+        rng = np.random.RandomState(3)
+        noisy = random_batch(rng, 120, 30, read_len=(200, 250), hap_len=(250, 300), qual_range=(20, 40), related=False)  # unrelated reads: every pair underflows in fp32
+        with native.PairHmmContext() as c:
+            _, u = check_against_oracle(c, oracle, noisy)
+            assert u.mean() > 0.5 and noisy.n_pairs > 2048
+        clean = make_batch("region", 250, 12, seed=8)
+        with native.PairHmmContext() as c:
+            _, u = check_against_oracle(c, oracle, clean)
+            assert clean.n_pairs > 2048
     # reads of 384 bases or more do not fit the one-pair-per-wavefront kernel: such a call takes the planned pass
     long_b = make_batch("hc", 120, 30, seed=9, read_len=(300, 450), hap_len=(400, 600))
     with native.PairHmmContext() as c:
