@@ -232,28 +232,6 @@ int validate(const gklhip_batch* b) {
   return GKLHIP_OK;
 }
 
-// policy_plan_kernel synchronises its blocks with hand-rolled grid barriers, so all of them must be resident at once.
-// One launch is kPlanBlocks (64) blocks of 1024 threads and a CU holds one such block: four launches fit the chip's
-// 256 CUs side by side.  Engines are many (JNI slots, twin engines of big host calls, several contexts per process),
-// and five half-resident launches from five queues could wait for each other's CUs for ever -- so at most
-// kPlanInFlight launches per device are in flight at any time, process-wide: a launch first waits (on the host) for
-// the end of the launch kPlanInFlight earlier.  In steady state that one finished long ago and the wait is a query.
-// (Other processes on the same GPU are outside this gate: run one process per GPU, as bench.py and the JNI shim do.)
-constexpr int kPlanInFlight = 3;
-struct PlanGate {
-  std::mutex mu;
-  hipEvent_t done[kPlanInFlight] = {};
-  int next = 0;
-};
-PlanGate* plan_gate(int device) {
-  static std::mutex mu;
-  static std::vector<PlanGate*> gates;
-  std::lock_guard<std::mutex> l(mu);
-  if ((int)gates.size() <= device) gates.resize((size_t)device + 1, nullptr);
-  if (!gates[(size_t)device]) gates[(size_t)device] = new PlanGate();  // lives as long as the process: the events are few
-  return gates[(size_t)device];
-}
-
 template <typename T, int RPL>
 void launch_stream(const FwdArgs<T>& a, int fma, int n_blocks, hipStream_t s) {
   if (fma) hipLaunchKernelGGL((pairhmm_fwd_stream_kernel<T, RPL, true>), dim3(n_blocks), dim3(64), 0, s, a);
@@ -299,7 +277,7 @@ constexpr int kRplF64Jobs = GKL_RPL_F64_JOBS;
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block
 constexpr int64_t kDirectPairs = 65536;        // calls up to this many pairs: policy + fp64 recomputation of one pair per wavefront (host calls of 24k / 38k / 50k pairs: 0.64 / 0.74 / 0.96 ms against 0.81 / 0.82 / 1.09 through the planned fp64 pass; equal at 80k)
 constexpr int64_t kTwoStepFrom = 2048;         // ... from this many pairs in two launches: policy + list of the failing pairs, then their recomputation (10k / 16k / 32k pairs: 0.37 / 0.45-0.48 / 0.72-0.84 ms against 0.43 / 0.49-0.54 / 0.76-0.97 in one)
-constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the policy + planning kernel (a grid barrier costs ~50 ns per block)
+constexpr int kPlanBlocks = 64;                // 1024-thread blocks of the packing / run-detection launches of the fp64 plan
 constexpr int kFallbackWantedJobs = 12288;     // the packed fp64 pass is cut into about this many jobs (4 per wavefront slot)
 constexpr int64_t kHostShardPairs = 400000;    // single-device host-buffer calls from this many pairs run as two half-batches (see gklhip_ctx::host_dev)
 constexpr int64_t kOnePassPairs = 65536;      // host-buffer calls up to this many pairs finalise in one pass after the last kernel
@@ -731,7 +709,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
       HIP_TRY(hipEventRecord(c->policy_done, s));
     } else {
-    // ---- precision policy + device-side planning of the fp64 recomputation (one launch) ----
+    // ---- precision policy + device-side planning of the fp64 recomputation (three launches, no host round trip) ----
     const size_t jobs_per_chunk = (size_t)n_haps;  // a job holds at least one haplotype and the jobs of a chunk do not overlap
     const size_t max_jobs = (size_t)n_reads * jobs_per_chunk;
     if ((rc = c->fail_order.reserve(((size_t)n_reads + (size_t)n_long64) * 4))) return rc;
@@ -766,20 +744,17 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       pa.wanted_jobs = wanted_env > 0 ? wanted_env : (int)std::min<int64_t>(kFallbackWantedJobs, std::max<int64_t>(4096, n_pairs / 100));
       pa.min_job_cols = 256;
       pa.packed_by_kernels = fold_packed ? 1 : 0;
-      // every block must be resident at once (grid barriers): far fewer than one per CU
+      // Three stream-ordered launches (pairhmm_aux_kernels.h): no block waits for another, so nothing limits how many
+      // of these are in flight per device or process.  The policy takes a block per 4096 pairs (up to one per CU), the
+      // packing a wavefront per window of affected reads, the run detection a wavefront per chunk (grid-stride).
       static const int blocks_env = [] { const char* v = getenv("GKLHIP_PLAN_BLOCKS"); return v ? atoi(v) : 0; }();
-      // (fewer blocks for smaller calls: the barriers get cheaper and the policy phase has less to share out -- an eighth of
-      //  the batch runs the same with 16 blocks as with 64)
-      const int auto_blocks = (int)std::min<int64_t>(kPlanBlocks, std::max<int64_t>(16, n_pairs / 8192));
-      const int grid = std::max(1, std::min(c->n_cus, blocks_env > 0 ? blocks_env : auto_blocks));
-      PlanGate* gate = plan_gate(c->device);
-      std::lock_guard<std::mutex> gl(gate->mu);
-      hipEvent_t& slot_done = gate->done[gate->next];
-      if (slot_done) HIP_TRY(hipEventSynchronize(slot_done));
-      else HIP_TRY(hipEventCreateWithFlags(&slot_done, hipEventDisableTiming));
-      hipLaunchKernelGGL(policy_plan_kernel, dim3((unsigned)grid), dim3(kPlanBlock), 0, s, pa);
-      HIP_TRY(hipEventRecord(slot_done, s));
-      gate->next = (gate->next + 1) % kPlanInFlight;
+      const int policy_grid = std::max(1, blocks_env > 0 ? blocks_env : (int)std::min<int64_t>(c->n_cus, std::max<int64_t>(16, n_pairs / 4096)));
+      const int64_t max_windows = ((int64_t)n_reads + kPackWindow - 1) / kPackWindow;
+      const int pack_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kPlanBlocks, (max_windows + kPlanBlock / 64 - 1) / (kPlanBlock / 64)));
+      const int jobs_grid = std::max(1, std::min(c->n_cus, blocks_env > 0 ? blocks_env : (int)std::min<int64_t>(kPlanBlocks, std::max<int64_t>(16, n_pairs / 8192))));
+      hipLaunchKernelGGL(plan_policy_kernel, dim3((unsigned)policy_grid), dim3(kPlanBlock), 0, s, pa);
+      hipLaunchKernelGGL(plan_pack_kernel, dim3((unsigned)pack_grid), dim3(kPlanBlock), 0, s, pa);
+      hipLaunchKernelGGL(plan_jobs_kernel, dim3((unsigned)jobs_grid), dim3(kPlanBlock), 0, s, pa);
     }
     HIP_TRY(hipEventRecord(c->policy_done, s));
     const bool side_finalize = finalize_mode == GKLHIP_FINALIZE_DEVICE_F64 || finalize_mode == GKLHIP_FINALIZE_DEVICE_REF32;
@@ -833,7 +808,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     if (timing && !use_double) {
       int32_t k[32];
       HIP_TRY(hipMemcpy(k, c->counters.p, sizeof k, hipMemcpyDeviceToHost));
-      fprintf(stderr, "[gklhip] policy+plan phases after the policy (us): hist %.1f scan %.1f scatter %.1f pack %.1f jobs %.1f sort %.1f | "
+      fprintf(stderr, "[gklhip] policy+plan phases, each from the start of its own launch (us): hist %.1f scan %.1f scatter %.1f pack %.1f jobs %.1f sort %.1f | "
               "%d affected reads, %d chunks, %d jobs | window 0: loaded %.1f ranked %.1f fitted %.1f cleared %.1f written %.1f\n",
               k[16] * 0.01, k[17] * 0.01, k[18] * 0.01, k[19] * 0.01, k[20] * 0.01, k[21] * 0.01,
               k[4], k[5], k[2], k[22] * 0.01, k[23] * 0.01, k[24] * 0.01, k[25] * 0.01, k[26] * 0.01);

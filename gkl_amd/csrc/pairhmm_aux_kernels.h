@@ -187,8 +187,8 @@ __global__ void finalize64_kernel(FinalizeArgs a, int all_pairs) {
   if (a.mode == kModePacked) reinterpret_cast<uint64_t*>(a.out)[p] = packed_word(a.raw64[p]);
 }
 
-// ---- precision policy + planning of the packed fp64 recomputation pass: ONE launch -------------------------
-// Phases, separated by grid barriers (the blocks of this kernel are all resident: at most one per CU):
+// ---- precision policy + planning of the packed fp64 recomputation pass: THREE stream-ordered launches -------
+// Phases:
 //   P  policy of IntelPairHmm.cc:157-165 on the raw fp32 sums: keep pairs with sum >= 1e-28f, flag the rest for
 //      the fp64 kernel and count, per read, how many haplotypes it failed against;
 //   H  histogram of those counts over the reads that fit a chunk;   S  bucket starts for DESCENDING count;
@@ -202,9 +202,15 @@ __global__ void finalize64_kernel(FinalizeArgs a, int all_pairs) {
 //      long for a chunk, which feed the striped kernel);
 //   O  the job list ordered by decreasing length (counting sort on columns / 128, one block), so that the
 //      persistent wavefronts of the jobs kernel start the long runs first and the kernel's tail is short.
-// These were eight launches with the chip idle in between (0.17 ms per call); the pass needs no host round trip.
+// Launches: plan_policy_kernel = P on the whole grid, then H S C by the block that finishes P LAST;
+// plan_pack_kernel = W; plan_jobs_kernel = J on the whole grid, then O by the block that finishes J last.
+// No block ever waits for another one: the single-block phases run in whichever block finds, on an arrival counter,
+// that every other block has already left its grid-wide phase (last_block_done).  Nothing therefore depends on the
+// blocks being resident together, on how many other launches share the device, or on the size of the device
+// (rounds 2-3 ran all seven phases in ONE launch with spinning grid barriers, which needed a process-wide gate on
+// concurrent launches and still could not cover several processes or a partitioned device).
 // None of the arrays written here is declared const/__restrict__: data produced in one phase is read in the next,
-// and the compiler must not move such reads to the scalar cache, which the barrier's fences do not invalidate.
+// and the compiler must not move such reads to the scalar cache, which the fences do not invalidate.
 constexpr int kPackWindow = 96;
 constexpr int kJobClasses = 64;
 constexpr int kPlanBlock = 1024;
@@ -216,7 +222,7 @@ struct PlanArgs {
   int32_t rpl;           // rows per lane of the fp64 kernel
   int32_t max_len;       // longest read that fits a chunk at that rpl
   int32_t* cnts;         // [0] fp64 pairs [2] jobs [3] next job [4] affected reads [5] chunks [8] long jobs [9] next long job
-                         // [10] grid barrier
+                         // [10] [11] arrival counters of plan_policy_kernel / plan_jobs_kernel
   int32_t* hist;         // [n_haps + 2]
   int32_t* pos;          // [n_haps + 2]
   int32_t* order;        // [n_reads]
@@ -238,19 +244,19 @@ struct PlanArgs {
   int32_t packed_by_kernels;  // the forward kernels wrote the packed words themselves (FwdArgs::packed_out)
 };
 
-// All threads of all blocks call this the same number of times.  `target` counts arrivals expected so far.
-__device__ __forceinline__ void grid_barrier(int32_t* bar, int32_t& target) {
+// Every thread of every block calls this once, after the block's share of a grid-wide phase.  True in exactly one
+// block: the one that arrives last, which then sees everything the other blocks wrote before arriving.
+__device__ __forceinline__ bool last_block_done(int32_t* arrivals) {
+  __shared__ int32_t s_is_last;
+  __threadfence();  // release this thread's writes (agent scope: writes back the XCD's L2)
   __syncthreads();
-  if (gridDim.x > 1) {
-    if (threadIdx.x == 0) {
-      target += (int32_t)gridDim.x;
-      __threadfence();  // release this block's writes (agent scope: writes back the XCD's L2)
-      atomicAdd(bar, 1);
-      while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
-      __threadfence();  // acquire the other blocks' writes
-    }
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t before = atomicAdd(arrivals, 1);
+    s_is_last = before == (int32_t)gridDim.x - 1 ? 1 : 0;
+    __threadfence();  // acquire the other blocks' writes (invalidates this CU's vector cache and the non-local L2 lines)
   }
+  __syncthreads();
+  return s_is_last != 0;
 }
 
 // counters are written with atomics (performed at the L2) and read back through it
@@ -323,13 +329,14 @@ __device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const La
   if (lane == 0) chunk_jobs[c] = n_jobs;
 }
 
-__global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
-  __shared__ int32_t s_i32[kPlanBlock];  // phase S: scan; O: class counters
+// stamps for GKLHIP_TIMING: cnts[16 + k] = 10 ns ticks since the start of the phase's own kernel
+#define GKLHIP_PLAN_STAMP(k) do { if (tid == 0) a.cnts[16 + (k)] = (int32_t)(wall_clock64() - clk0); } while (0)
+
+__global__ __launch_bounds__(kPlanBlock) void plan_policy_kernel(PlanArgs a) {
+  __shared__ int32_t s_i32[kPlanBlock];  // phase S: scan
   __shared__ int32_t s_wave[kPlanBlock / 64];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
-  int32_t target = 0;
-  int32_t* bar = a.cnts + 10;
 
   // ---- P: policy ----
   {
@@ -367,22 +374,23 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
       if (total) atomicAdd(a.cnts + 0, total);
     }
   }
-  grid_barrier(bar, target);
+  if (!last_block_done(a.cnts + 10)) return;
+  // ---- this block left the policy last: it alone sorts the affected reads (a few thousand of them) ----
   const int n_fail = ld_cnt(a.cnts + 0);
-  if (n_fail == 0) return;  // nothing underflowed (uniform across the grid: read after the barrier)
+  if (n_fail == 0) return;  // nothing underflowed: the next two launches see the same count and leave at once
   const uint64_t clk0 = wall_clock64();
-  auto stamp = [&](int k) { if (blk == 0 && tid == 0) a.cnts[16 + k] = (int32_t)(wall_clock64() - clk0); };
 
   // ---- H: histogram of fallback counts (reads longer than max_len take the striped long-read path) ----
-  for (int r = blk * kPlanBlock + tid; r < a.n_reads; r += nblk * kPlanBlock) {
+  for (int r = tid; r < a.n_reads; r += kPlanBlock) {
     const int f = a.fa.read_fail[r];
     if (f > 0 && a.read_off[r + 1] - a.read_off[r] <= a.max_len) atomicAdd(a.hist + f, 1);
   }
-  grid_barrier(bar, target);
-  stamp(0);
+  __threadfence();
+  __syncthreads();
+  GKLHIP_PLAN_STAMP(0);
 
-  // ---- S: bucket starts for DESCENDING count: pos[c] = #reads with count > c (block 0; the others go on) ----
-  if (blk == 0) {
+  // ---- S: bucket starts for DESCENDING count: pos[c] = #reads with count > c  ----
+  {
     // per-thread contiguous segments of the count range [1, n_haps], highest counts first
     const int n = a.n_haps;
     const int per = (n + kPlanBlock - 1) / kPlanBlock;
@@ -403,16 +411,23 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
     int acc = s_scan[tid];
     for (int c = hi; c > lo; c--) { a.pos[c] = acc; acc += a.hist[c]; }
   }
-  grid_barrier(bar, target);
-  stamp(1);
+  __threadfence();
+  __syncthreads();
+  GKLHIP_PLAN_STAMP(1);
 
   // ---- C: scatter ----
-  for (int r = blk * kPlanBlock + tid; r < a.n_reads; r += nblk * kPlanBlock) {
+  for (int r = tid; r < a.n_reads; r += kPlanBlock) {
     const int f = a.fa.read_fail[r];
     if (f > 0 && a.read_off[r + 1] - a.read_off[r] <= a.max_len) a.order[atomicAdd(a.pos + f, 1)] = r;
   }
-  grid_barrier(bar, target);
-  stamp(2);
+  GKLHIP_PLAN_STAMP(2);
+}
+
+__global__ __launch_bounds__(kPlanBlock) void plan_pack_kernel(PlanArgs a) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
+  if (ld_cnt(a.cnts + 0) == 0) return;
+  const uint64_t clk0 = wall_clock64();
 
   // ---- W: pack windows, one wavefront per window ----
   {
@@ -500,8 +515,16 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
       if (w == 0 && lane == 0) a.cnts[26] = (int32_t)(wall_clock64() - clk0);
     }
   }
-  grid_barrier(bar, target);
-  stamp(3);
+  if (blk == 0) GKLHIP_PLAN_STAMP(3);
+}
+
+__global__ __launch_bounds__(kPlanBlock) void plan_jobs_kernel(PlanArgs a) {
+  __shared__ int32_t s_i32[kPlanBlock];  // phase O: class counters
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
+  const int n_fail = ld_cnt(a.cnts + 0);
+  if (n_fail == 0) return;
+  const uint64_t clk0 = wall_clock64();
 
   // ---- J: jobs = needed haplotype runs per chunk, one wavefront per chunk ----
   {
@@ -520,11 +543,10 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
     for (int c = w; c < total; c += n_waves) build_jobs_for_chunk(a, a.lanes2, c, a.jobs, a.order, cut_cols, false, lane);
     for (int c = w; c < a.n_long; c += n_waves) build_jobs_for_chunk(a, a.long_lanes, c, a.jobs_long, a.long_chunk_jobs, 0x7fffffff, true, lane);
   }
-  grid_barrier(bar, target);
-  stamp(4);
+  if (!last_block_done(a.cnts + 11)) return;
+  GKLHIP_PLAN_STAMP(4);
 
   // ---- O: order the jobs longest first (block 0): counting sort over the chunks' job lists ----
-  if (blk != 0) return;
   {
     int32_t* cnt = s_i32;                // [kJobClasses]
     int32_t* base = s_i32 + kJobClasses; // [kJobClasses]
@@ -562,8 +584,9 @@ __global__ __launch_bounds__(kPlanBlock) void policy_plan_kernel(PlanArgs a) {
       a.cnts[8] = at;
     }
   }
-  stamp(5);
+  GKLHIP_PLAN_STAMP(5);
 }
+#undef GKLHIP_PLAN_STAMP
 
 // ---- diagnostics: the VALU issue ceiling of the forward recurrence's instruction mix ----------------------------
 // Eight "cells" of 4 multiplies + 4 fused multiply-adds per loop iteration, operands in registers chosen so that no

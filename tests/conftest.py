@@ -34,3 +34,21 @@ def reference():
 def golden_cases():
     from tests.golden_io import load_testdata
     return load_testdata()
+
+
+# `pytest -x` stops at the first failure, so the parity tests of the SURVEY 8 rows run BEFORE the robustness,
+# concurrency and fuzz tests: a failure in one of those can then no longer leave a row's parity unexamined.
+# Order: oracle / host logic -> PairHMM parity -> JNI parity -> PDHMM parity -> Smith-Waterman parity -> plugin
+# mirrors -> shards / multi-device -> robustness -> combiner -> context churn -> fuzz -> bench contract.
+_FILE_ORDER = [
+    "test_oracle.py", "test_cabi_cpu.py",
+    "test_gpu_parity.py", "test_jni_shim.py", "test_pdhmm.py", "test_sw.py", "test_plugin_mirror.py",
+    "test_long_reads.py",
+    "test_shard.py", "test_multi_device.py", "test_gpu_robustness.py", "test_small_call_combiner.py",
+    "test_context_churn.py", "test_fuzz_gpu.py", "test_bench_contract.py",
+]
+
+
+def pytest_collection_modifyitems(config, items):
+    rank = {name: i for i, name in enumerate(_FILE_ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), len(_FILE_ORDER) - 1.5))  # stable within a file
