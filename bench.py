@@ -141,7 +141,7 @@ def host_call_record(native, batch, dev_index, calls=30, warm=15, max_threads=1)
             "pairs": batch.n_pairs, "fallback_fraction": round(st["n_fallback"] / batch.n_pairs, 4)}
 
 
-def jni_records(batch, c1, host_ms):
+def jni_records(batch, c1, host_ms, host_ms_4=None):
     """computeLikelihoodsNative itself, driven through a mock JNIEnv (tests/native/mock_jni.cpp: -Xcheck:jni-style
     bookkeeping on every call, so its JNI functions cost several times a real JVM's): ms per call for the bench batch
     (C2) and a GATK-sized region (C1) with the shim's own split -- marshalling on the calling thread, waiting for
@@ -150,9 +150,9 @@ def jni_records(batch, c1, host_ms):
     from tests import mockjni
     rec = {}
 
-    def one(b, iters, warm, threads=1):
+    def one(b, iters, warm, threads=1, max_threads=1):
         t = []
-        rc, _, cls, msg, wall = mockjni.run_concurrent(b, threads, iters=iters, warm=warm, timing=t)
+        rc, _, cls, msg, wall = mockjni.run_concurrent(b, threads, iters=iters, warm=warm, timing=t, max_threads=max_threads)
         if rc != 0:
             raise RuntimeError(f"mock JNI run failed: {cls} {msg}")
         calls = max(t[4], 1)
@@ -163,6 +163,13 @@ def jni_records(batch, c1, host_ms):
                  "marshal_ms": round(t[0] / calls / 1e6, 3), "compute_wait_ms": round(t[1] / calls / 1e6, 3),
                  "writeback_ms": round(t[2] / calls / 1e6, 3), "pipelined": bool(t[5]),
                  "over_host_path": round(ms / host_ms, 3) if host_ms else None}
+    rec["c2"]["max_threads"] = 1
+    wall, t, calls = one(batch, 8, 4, max_threads=4)
+    ms = wall / 8
+    rec["c2_max_threads_4"] = {"ms_per_call": round(ms, 3), "gcups": round(batch.cells / ms / 1e6, 1),
+                               "marshal_ms": round(t[0] / calls / 1e6, 3), "compute_wait_ms": round(t[1] / calls / 1e6, 3),
+                               "writeback_ms": round(t[2] / calls / 1e6, 3), "pipelined": bool(t[5]), "max_threads": 4,
+                               "over_host_path": round(ms / host_ms_4, 3) if host_ms_4 else None}
     wall, t, calls = one(c1, 200, 30)
     ms = wall / 200
     rec["c1"] = {"ms_per_call": round(ms, 4), "gcups": round(c1.cells / ms / 1e6, 1),
@@ -192,7 +199,8 @@ def jni_records(batch, c1, host_ms):
     finally:
         os.environ.pop("GKL_HIP_SLOTS", None)
     rec["note"] = ("through Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative with a mock JNIEnv; big calls are "
-                   "pipelined (read ranges marshalled while earlier ranges compute on the slot's two engines)")
+                   "pipelined (read ranges marshalled while earlier ranges compute on the slot's two engines); initNative's "
+                   "maxNumberOfThreads caps the host log10 threads per engine: c2 = 1 (the reference's default), c2_max_threads_4 = GATK's")
     return rec, conc
 
 
@@ -285,6 +293,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # what the communicator itself says (the line's "comm" object): every rank contributes 1 to an all-reduce
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
+        if dist.get_world_size() != a.gpus or ranks_seen != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks and {ranks_seen} answered")
     strong = world > 1 and not a.weak
     whole = None
     if a.weak and world > 1:
@@ -453,6 +469,12 @@ def main():
                 "unit": "TFLOP/s", "frac": round(FLOP_PER_CELL * cells_fp64 / (fb_ms * 1e-3) / 1e12 / (PEAK_FP32_VECTOR_TFLOPS / 2), 4),
                 "issue_ceiling_tflops": round(FLOP_PER_CELL * mix64_cells_per_s / 1e12, 2) if mix64_cells_per_s else None,
                 "frac_of_issue_ceiling": round(cells_fp64 / (fb_ms * 1e-3) / mix64_cells_per_s, 4) if mix64_cells_per_s else None},
+            # who took part in the exchange step (checked above: the run exits non-zero when ranks_seen != --gpus)
+            "comm": {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else "none",
+                     "ranks_seen": ranks_seen, "world_size": dist.get_world_size() if world > 1 else 1,
+                     "gather": "dist.gather to rank 0, asynchronous, overlapped with the next step" if world > 1 else "none",
+                     "gather_bytes_per_rank": [int(r) * a.haps * 8 for r in rows] if world > 1 else [],
+                     "in_library_gather": None},   # filled from the in-library child below (N>1)
             "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(fb_ms, 3),
                            "device_total": round(dev_ms, 3), "from": kernel_times_from},
             # what a step costs beyond its two forward kernels (planning, policy, log10, launches, gaps); with
@@ -494,9 +516,12 @@ def main():
                 # end to end through gklhip_compute (H2D, D2H, reference-exact host log10)
                 res["host_path"] = {
                     "max_threads_1": host_call_record(native, batch, dev_index, calls=6, warm=2, max_threads=1),
-                    "max_threads_16": host_call_record(native, batch, dev_index, calls=6, warm=2, max_threads=16),
-                    "note": "gklhip_compute on host arrays = what computeLikelihoodsNative runs after marshalling; "
-                            "maxNumberOfThreads <= 1 means 'not set' to the finaliser (min(cores, 8) host threads)"}
+                    "max_threads_4": host_call_record(native, batch, dev_index, calls=6, warm=2, max_threads=4),
+                    "max_threads_auto": host_call_record(native, batch, dev_index, calls=6, warm=2, max_threads=0),
+                    "note": "gklhip_compute on host arrays = what computeLikelihoodsNative runs after marshalling. "
+                            "maxNumberOfThreads is honoured as a cap on the host threads of the reference-exact log10 pass: 1 "
+                            "(PairHMMNativeArguments' default) = ONE thread, 4 = GATK HaplotypeCaller's default "
+                            "--native-pair-hmm-threads, auto (C ABI max_threads <= 0) = min(cores, 8)"}
                 # per-call cost on the sizes GATK and an 8-GPU shard really send
                 c1 = make_batch(a.workload, 100, 10, seed=DEFAULT_SEED)
                 eighth = whole.read_slice(0, whole.n_reads // 8)
@@ -535,7 +560,8 @@ def main():
                 except Exception as e:
                     res["small_batch"]["eighth_device_resident"] = {"error": repr(e)}
                 try:
-                    jrec, conc = jni_records(batch, c1, res["host_path"]["max_threads_1"]["ms_per_call"])
+                    jrec, conc = jni_records(batch, c1, res["host_path"]["max_threads_1"]["ms_per_call"],
+                                             res["host_path"]["max_threads_4"]["ms_per_call"])
                     res["jni_path"] = jrec
                     res["small_batch"]["concurrent"] = conc
                 except Exception as e:
@@ -579,6 +605,10 @@ def main():
                 res["in_library"] = json.loads(line) if line else {"error": (p.stderr or p.stdout)[-300:]}
             except Exception as e:
                 res["in_library"] = {"error": repr(e)}
+            # gklhip_gather_backend of the one-process multi-device context after its calls: "rccl", "peer" or
+            # "peer-after-rccl-failure" (+ the devices it drove)
+            res["comm"]["in_library_gather"] = {"backend": res["in_library"].get("gather"), "devices": res["in_library"].get("devices"),
+                                                "note": res["in_library"].get("gather_note") or res["in_library"].get("error")}
         print(json.dumps(res), flush=True)
 
 

@@ -117,8 +117,13 @@ struct Pipeline {
         RangeTask* t = todo.front();
         todo.pop_front();
         l.unlock();
-        t->status = gklhip_compute(ctx, &t->batch, t->out);
-        if (t->status != GKLHIP_OK) { const char* d = gklhip_last_error(); t->error = d ? d : ""; }  // (thread-local detail)
+        // (gklhip_compute itself lets no exception out; the string below can still fail to allocate)
+        try {
+          t->status = gklhip_compute(ctx, &t->batch, t->out);
+          if (t->status != GKLHIP_OK) { const char* d = gklhip_last_error(); t->error = d ? d : ""; }  // (thread-local detail)
+        } catch (...) {
+          t->status = GKLHIP_ERR_OOM;
+        }
         l.lock();
         done.push_back(t);
         has_done.notify_all();
@@ -157,6 +162,7 @@ struct Slot {
   std::vector<double> out;
   bool busy = false;
   int gen = 0;  // configuration generation (initNative with other arguments starts a new one)
+  gklhip_config cfg;  // what `ctx` was created with: the second engine of a pipelined call gets the same
   ~Slot() {
     pipe.reset();
     if (ctx2) gklhip_done(ctx2);
@@ -272,6 +278,7 @@ Slot* acquire_slot(JNIEnv* env) {
         continue;
       }
       s->gen = gen;
+      s->cfg = cfg;
       if (gen != g.gen) {  // re-configured meanwhile: the new slot (old arguments) is dropped -- outside the lock
         lock.unlock();
         s.reset();
@@ -351,6 +358,7 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
   lock.lock();
   g.cfg = cfg;
   g.max_slots = max_slots;
+  first->cfg = cfg;
   first->gen = ++g.gen;   // (two racing initNative calls: the later one's generation wins, the other's slot retires like any old one)
   g.slots.push_back(std::move(first));
   g.ready = true;
@@ -420,7 +428,22 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     };
     const char* pv = getenv("GKL_HIP_JNI_PIPELINE_PAIRS");   // (read per call: tests switch it)
     const int64_t pipeline_from = pv && *pv ? atoll(pv) : 160000LL;   // (a 4000 x 50 call: 3.5 -> 3.2 ms pipelined; below ~150k pairs one range is all there is)
-    if (n_pairs < pipeline_from || n_reads < 64 || pipeline_from <= 0) {
+    bool pipelined = !(n_pairs < pipeline_from || n_reads < 64 || pipeline_from <= 0);
+    if (pipelined && !sl->pipe) {
+      // first big call of this slot: second engine (same configuration as the slot's first, whatever initNative has
+      // been told since) and the compute threads.  If they cannot be had -- device memory, thread limit -- the call
+      // runs in one shot like a small one.
+      try {
+        if (!sl->ctx2 && gklhip_init(&sl->cfg, &sl->ctx2) != GKLHIP_OK) sl->ctx2 = nullptr;   // one engine
+        std::unique_ptr<Pipeline> p(new Pipeline());
+        p->start(sl->ctx);
+        if (sl->ctx2) { try { p->start(sl->ctx2); } catch (const std::exception&) {} }        // one compute thread
+        sl->pipe = std::move(p);
+      } catch (const std::exception&) {
+        pipelined = false;
+      }
+    }
+    if (!pipelined) {
       // ---- one shot (a GATK active region): marshal, compute, write back ----
       if (!marshal_reads(sl->whole, 0, n_reads)) return;
       const int64_t t_m = now_ns();
@@ -437,17 +460,6 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     }
     // ---- pipelined: read ranges of ~150k pairs (100k..320k measure the same); range k+1 is marshalled while the ranges before it compute on the
     // slot's two engines, finished ranges go back to the Java array in between ----
-    if (!sl->pipe) {
-      if (!sl->ctx2) {
-        gklhip_config cfg;
-        { std::lock_guard<std::mutex> lock(g.mu); cfg = g.cfg; }   // (a re-configuration meanwhile retires this slot when it comes back)
-        const int st = gklhip_init(&cfg, &sl->ctx2);
-        if (st != GKLHIP_OK) sl->ctx2 = nullptr;          // e.g. out of device memory: one engine
-      }
-      sl->pipe.reset(new Pipeline());
-      sl->pipe->start(sl->ctx);
-      if (sl->ctx2) sl->pipe->start(sl->ctx2);
-    }
     const char* rv = getenv("GKL_HIP_JNI_RANGE_PAIRS");
     const int64_t range_pairs = rv && atoll(rv) > 0 ? atoll(rv) : 150000LL;
     // Range boundaries: the first range is small (its marshalling is the only part nothing overlaps with), the later ones
@@ -516,6 +528,10 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     g_timing[0] += ns_marshal; g_timing[1] += ns_wait; g_timing[2] += ns_write; g_timing[3] += now_ns() - t_call; g_timing[4]++; g_timing[5]++;
   } catch (const std::bad_alloc&) {
     throw_java(env, kOOM, "Unable to allocate the PairHMM batch");
+  } catch (const std::exception& e) {   // nothing may unwind into the JVM
+    char msg[300];
+    snprintf(msg, sizeof msg, "GKL-HIP PairHMM: %s", e.what());
+    throw_java(env, kRTE, msg);
   }
 }
 

@@ -128,7 +128,8 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_initNative(JNIEnv* en
     if (!id) { throw_java(env, kIAE, "Unable to get field ID"); return; }  // JavaData.h:282-290
     *f.dst = id;
   }
-  g.max_memory_mb = maxMemoryInMB > 0 ? maxMemoryInMB : 512;
+  // (the free-RAM cap is applied here, once -- pdhmm-implementation.h:204-235 -- not per call)
+  g.max_memory_mb = gklhip_pdhmm_available_memory_mb(maxMemoryInMB > 0 ? maxMemoryInMB : 512);
   g.initialised = true;
   // a second initialize() keeps the context (calls of other threads may be running on it); the first one creates it
   // here so that "no GPU" surfaces from initNative

@@ -49,6 +49,20 @@ int fail(int status, const char* fmt, ...) {
   return status;
 }
 
+// No C++ exception leaves the C ABI or a helper thread of this library (a std::bad_alloc from a plan vector inside a
+// JVM would otherwise be std::terminate): entry points and thread bodies run their work through guarded().
+int fail_noexcept(int status, const char* msg) noexcept {
+  try { g_err = msg; } catch (...) {}
+  return status;
+}
+template <typename F>
+int guarded(F&& body) noexcept {
+  try { return body(); }
+  catch (const std::bad_alloc&) { return fail_noexcept(GKLHIP_ERR_OOM, "host memory allocation failed"); }
+  catch (const std::exception& e) { return fail_noexcept(GKLHIP_ERR_HIP, e.what()); }
+  catch (...) { return fail_noexcept(GKLHIP_ERR_HIP, "unexpected C++ exception"); }
+}
+
 #define HIP_TRY(expr)                                                                        \
   do {                                                                                       \
     hipError_t e__ = (expr);                                                                 \
@@ -900,12 +914,13 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
 }
 
 // Host threads of the reference-exact finalisation.  maxNumberOfThreads caps the OpenMP compute threads of the
-// reference's OMP build and is ignored by its plain build (IntelPairHmm.cc:72-89, IntelPairHmm.java:114-118); here the
-// compute is on the device and the only host work is log10f/log10 over the results.  A value > 1 is honoured as given.
-// The value 1 (GATK's default) means "not set": the host-buffer calls in flight in this process SHARE a budget of
-// min(cores, 8) threads -- one call alone takes all of it, the two engines of a pipelined or twin-engine call half each,
-// eight concurrent JNI slots one each -- so the process never runs more than that many finaliser threads at a time,
-// however many slots and engines exist.  GKL_HIP_FINALIZE_THREADS overrides (per call).
+// reference's OMP build (IntelPairHmm.cc:72-89; 1 is the default of PairHMMNativeArguments, IntelPairHmm.java:86-90);
+// here the compute is on the device and the only host work it can cap is log10f/log10 over the results.  It IS a cap:
+// a value >= 1 is honoured as given -- an explicit 1 means ONE finalisation thread per call (bench.py reports what
+// that costs a 1.28 M-pair call in host_path.max_threads_1).  Only <= 0 (C ABI: "not set") picks a number here: the
+// host-buffer calls in flight in this process then SHARE a budget of min(cores, 8) threads -- one call alone takes all
+// of it, the two engines of a pipelined or twin-engine call half each, eight concurrent slots one each.
+// GKL_HIP_FINALIZE_THREADS overrides both (per call).
 struct HostCallInFlight {
   int share;
   HostCallInFlight() : share(g_host_calls_in_flight.fetch_add(1) + 1) {}
@@ -916,7 +931,7 @@ int finalize_threads(const DevCtx* c, int share) {
   if (env > 0) return env;
   const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
   int threads = c->cfg.max_threads;
-  if (threads <= 1) threads = std::max(1, std::min(hw, 8) / std::max(1, share));
+  if (threads <= 0) threads = std::max(1, std::min(hw, 8) / std::max(1, share));
   return std::max(1, std::min(threads, 64));
 }
 
@@ -1023,6 +1038,10 @@ struct SmallCombiner {
       if (rc == GKLHIP_OK) rc = n == 1 ? launch_single(mine.call, own_stream) : launch_multi(batch, n, mine.call.fma, sl);
       const std::string err = rc == GKLHIP_OK ? std::string() : g_err;
       const int64_t t_launched = now_ns();
+      // a launch that failed part-way may have left kernels on the stream that still read the calls' staging blocks and
+      // write their result buffers: drain it BEFORE any of the calls is told about the failure (and returns to a caller
+      // that is free to reuse those buffers)
+      if (rc != GKLHIP_OK) { (void)(n == 1 ? hipStreamSynchronize(own_stream) : hipStreamSynchronize(sl.stream)); (void)hipGetLastError(); }
       if (n > 1) {
         l.lock();
         // (the others wait on the set's event themselves; letting them sleep until this thread has seen the end
@@ -1036,7 +1055,6 @@ struct SmallCombiner {
       }
       hipError_t e = hipSuccess;
       if (rc == GKLHIP_OK) e = n == 1 ? hipStreamSynchronize(own_stream) : hipEventSynchronize(sl.ev);
-      else (void)(n == 1 ? hipStreamSynchronize(own_stream) : hipStreamSynchronize(sl.stream));
       l.lock();
       {
         const int64_t t_end = now_ns();
@@ -1217,11 +1235,12 @@ class DevWorker {
       pending_ = false;
       std::function<int()> f = std::move(task_);
       l.unlock();
-      const int rc = f();
-      const std::string e = g_err;  // the detail message is thread-local: carry it to the caller
+      const int rc = guarded(f);
+      std::string e;
+      try { e = g_err; } catch (...) {}  // the detail message is thread-local: carry it to the caller
       l.lock();
       rc_ = rc;
-      err_ = e;
+      err_.swap(e);
       done_ = true;
       done_cv_.notify_all();
     }
@@ -1599,12 +1618,12 @@ int gklhip_device_count(void) {
   return n;
 }
 
-int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_t n_devices, gklhip_ctx** out_ctx) {
+static int init_devices_impl(const gklhip_config* cfg, const int32_t* devices, int32_t n_devices, gklhip_ctx** out_ctx) {
   if (!out_ctx) return fail(GKLHIP_ERR_INVALID_ARG, "out_ctx is NULL");
   *out_ctx = nullptr;
   gklhip_config c0;
   memset(&c0, 0, sizeof c0);
-  c0.abi_version = GKLHIP_ABI_VERSION; c0.device = -1; c0.max_threads = 1; c0.fma_mode = 1; c0.finalize = -1;
+  c0.abi_version = GKLHIP_ABI_VERSION; c0.device = -1; c0.max_threads = 0; c0.fma_mode = 1; c0.finalize = -1;
   if (cfg) {
     if (cfg->abi_version != GKLHIP_ABI_VERSION)
       return fail(GKLHIP_ERR_INVALID_ARG, "ABI version %d, library is %d", cfg->abi_version, GKLHIP_ABI_VERSION);
@@ -1676,14 +1695,14 @@ int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_
   return GKLHIP_OK;
 }
 
-int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
+static int init_impl(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
   // GKL_HIP_DEVICES=0,1,...: shard every call over these devices (used when the config does not pin one)
   std::vector<int32_t> list;
   if (!cfg || cfg->device < 0) {
     const int rc = parse_device_list(getenv("GKL_HIP_DEVICES"), &list);
     if (rc) { if (out_ctx) *out_ctx = nullptr; return rc; }
   }
-  return gklhip_init_devices(cfg, list.empty() ? nullptr : list.data(), (int32_t)list.size(), out_ctx);
+  return init_devices_impl(cfg, list.empty() ? nullptr : list.data(), (int32_t)list.size(), out_ctx);
 }
 
 int gklhip_done(gklhip_ctx* c) {
@@ -1702,9 +1721,14 @@ int gklhip_gather_backend(gklhip_ctx* c) {
 }
 
 const char* gklhip_gather_note(gklhip_ctx* c) {
-  if (!c) return "";
+  // a copy per calling thread, valid until that thread's next call (the context's own string may be rewritten by a
+  // concurrent compute call as soon as the lock is dropped)
+  static thread_local char note[512];
+  note[0] = 0;
+  if (!c) return note;
   std::lock_guard<std::mutex> lock(c->mu);
-  return c->rccl_note.c_str();
+  snprintf(note, sizeof note, "%s", c->rccl_note.c_str());
+  return note;
 }
 
 int gklhip_partition_reads(int32_t n_reads, const int64_t* read_off, int32_t n_parts, int32_t* bounds_out) {
@@ -1713,7 +1737,7 @@ int gklhip_partition_reads(int32_t n_reads, const int64_t* read_off, int32_t n_p
   return GKLHIP_OK;
 }
 
-int gklhip_compute_device(gklhip_ctx* c, const gklhip_batch* dev_batch, double* out_dev, void* hip_stream) {
+static int compute_device_impl(gklhip_ctx* c, const gklhip_batch* dev_batch, double* out_dev, void* hip_stream) {
   if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
   int rc = validate(dev_batch);
   if (rc) return rc;
@@ -1766,7 +1790,7 @@ int gklhip_compute_device(gklhip_ctx* c, const gklhip_batch* dev_batch, double* 
   return multi_compute_device(c, set, dev_batch, out_dev, mode, s);
 }
 
-int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
+static int compute_impl(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
   if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
   int rc = validate(hb);
   if (rc) return rc;
@@ -1811,7 +1835,7 @@ void gklhip_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
-int gklhip_get_step_times(gklhip_ctx* ctx, int32_t steps_back, float* ms_main, float* ms_fallback, float* ms_total) {
+static int get_step_times_impl(gklhip_ctx* ctx, int32_t steps_back, float* ms_main, float* ms_fallback, float* ms_total) {
   if (!ctx) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
   std::lock_guard<std::mutex> lock(ctx->mu);
   DevCtx* c = ctx->dev[0];  // (several devices: device 0's shard)
@@ -1837,7 +1861,7 @@ int gklhip_get_stats(gklhip_ctx* c, gklhip_stats* out) {
   return GKLHIP_OK;
 }
 
-int gklhip_get_raw(gklhip_ctx* ctx, float* raw32, double* raw64, uint8_t* used64) {
+static int get_raw_impl(gklhip_ctx* ctx, float* raw32, double* raw64, uint8_t* used64) {
   if (!ctx) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL");
   std::lock_guard<std::mutex> lock(ctx->mu);
   int64_t n_fallback = 0;
@@ -1960,7 +1984,7 @@ int gklhip_measure_issue_ceiling(gklhip_ctx* ctx, int use_double, double ms_budg
 
 // Diagnostics: load RCCL and run one send/recv pair inside one group on a one-device communicator (what the
 // multi-device gather does per extra device).  0 = ok.
-int gklhip_rccl_selftest(int32_t device) {
+static int rccl_selftest_impl(int32_t device) {
   std::lock_guard<std::mutex> l(g_rccl_mu);
   if (!g_rccl.load()) return fail(GKLHIP_ERR_HIP, "librccl.so cannot be loaded: %s", dlerror());
   HIP_TRY(hipSetDevice(device));
@@ -1990,5 +2014,14 @@ int gklhip_rccl_selftest(int32_t device) {
   if (memcmp(h.data(), back.data(), n * 8) != 0) return fail(GKLHIP_ERR_HIP, "RCCL self send/recv returned different data");
   return GKLHIP_OK;
 }
+
+// ---- the guarded entry points (see guarded()) ----
+int gklhip_init_devices(const gklhip_config* cfg, const int32_t* devices, int32_t n_devices, gklhip_ctx** out_ctx) { return guarded([&] { return init_devices_impl(cfg, devices, n_devices, out_ctx); }); }
+int gklhip_compute_device(gklhip_ctx* c, const gklhip_batch* dev_batch, double* out_dev, void* hip_stream) { return guarded([&] { return compute_device_impl(c, dev_batch, out_dev, hip_stream); }); }
+int gklhip_compute(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) { return guarded([&] { return compute_impl(c, hb, out_host); }); }
+int gklhip_get_raw(gklhip_ctx* ctx, float* raw32, double* raw64, uint8_t* used64) { return guarded([&] { return get_raw_impl(ctx, raw32, raw64, used64); }); }
+int gklhip_get_step_times(gklhip_ctx* ctx, int32_t steps_back, float* ms_main, float* ms_fallback, float* ms_total) { return guarded([&] { return get_step_times_impl(ctx, steps_back, ms_main, ms_fallback, ms_total); }); }
+int gklhip_rccl_selftest(int32_t device) { return guarded([&] { return rccl_selftest_impl(device); }); }
+int gklhip_init(const gklhip_config* cfg, gklhip_ctx** out_ctx) { return guarded([&] { return init_impl(cfg, out_ctx); }); }
 
 }  // extern "C"

@@ -332,9 +332,88 @@ __device__ __forceinline__ void build_jobs_for_chunk(const PlanArgs& a, const La
 // stamps for GKLHIP_TIMING: cnts[16 + k] = 10 ns ticks since the start of the phase's own kernel
 #define GKLHIP_PLAN_STAMP(k) do { if (tid == 0) a.cnts[16 + (k)] = (int32_t)(wall_clock64() - clk0); } while (0)
 
+// Phases H S C by ONE block (the last one to leave the policy): counting sort of the affected reads by DESCENDING
+// fallback count.  `hist` / `pos` are LDS arrays when n_haps + 2 entries fit (kInLds: cleared here; every atomic with a
+// returned value is then an LDS operation of ~0.1 us instead of a ~2 us round trip to the L2) and the context's global
+// arrays (cleared by prep_kernel) otherwise.  Loads are issued four reads per thread at a time so their latencies overlap.
+constexpr int kPlanLdsBins = 4096;
+template <bool kInLds>
+__device__ __forceinline__ void order_affected_reads(const PlanArgs& a, int32_t* hist, int32_t* pos, int32_t* s_wave_tot,
+                                                     int tid, uint64_t clk0) {
+  constexpr int kBatch = 4;
+  const int n = a.n_haps, lane = tid & 63, wave = tid >> 6;
+  if (kInLds) {
+    for (int c = tid; c < n + 2; c += kPlanBlock) hist[c] = 0;
+    __syncthreads();
+  }
+  // ---- H: histogram of fallback counts (reads longer than max_len take the striped long-read path) ----
+  for (int r0 = tid; r0 < a.n_reads; r0 += kBatch * kPlanBlock) {
+    int f[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+      const int r = r0 + k * kPlanBlock;
+      const bool in = r < a.n_reads;
+      const int fr = in ? a.fa.read_fail[r] : 0;
+      const int64_t len = in ? a.read_off[r + 1] - a.read_off[r] : 0;
+      f[k] = (fr > 0 && len <= a.max_len) ? fr : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; k++)
+      if (f[k] > 0) atomicAdd(hist + f[k], 1);
+  }
+  __threadfence();
+  __syncthreads();
+  GKLHIP_PLAN_STAMP(0);
+
+  // ---- S: bucket starts for DESCENDING count: pos[c] = #reads with count > c ----
+  {
+    // per-thread contiguous segments of the count range [1, n_haps], highest counts first
+    const int per = (n + kPlanBlock - 1) / kPlanBlock;
+    const int hi = n - tid * per, lo = max(hi - per, 0);  // this thread owns counts (lo, hi]
+    int sum = 0;
+    for (int c = hi; c > lo; c--) sum += hist[c];
+    int inc = sum;  // inclusive scan over the wavefront, then over the wavefronts' totals
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave_tot[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < kPlanBlock / 64; w++) {
+      const int t = s_wave_tot[w];
+      base += w < wave ? t : 0;
+      total += t;
+    }
+    if (tid == 0) __hip_atomic_store(a.cnts + 4, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int acc = base + inc - sum;
+    for (int c = hi; c > lo; c--) { pos[c] = acc; acc += hist[c]; }
+  }
+  __threadfence();
+  __syncthreads();
+  GKLHIP_PLAN_STAMP(1);
+
+  // ---- C: scatter ----
+  for (int r0 = tid; r0 < a.n_reads; r0 += kBatch * kPlanBlock) {
+    int f[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) {
+      const int r = r0 + k * kPlanBlock;
+      const bool in = r < a.n_reads;
+      const int fr = in ? a.fa.read_fail[r] : 0;
+      const int64_t len = in ? a.read_off[r + 1] - a.read_off[r] : 0;
+      f[k] = (fr > 0 && len <= a.max_len) ? fr : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; k++)
+      if (f[k] > 0) a.order[atomicAdd(pos + f[k], 1)] = r0 + k * kPlanBlock;
+  }
+}
+
 __global__ __launch_bounds__(kPlanBlock) void plan_policy_kernel(PlanArgs a) {
-  __shared__ int32_t s_i32[kPlanBlock];  // phase S: scan
+  __shared__ int32_t s_i32[kPlanBlock / 64];  // phase S: scan
   __shared__ int32_t s_wave[kPlanBlock / 64];
+  __shared__ int32_t s_hist[2 * kPlanLdsBins];  // phases H S C: histogram and bucket positions when they fit
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nblk = (int)gridDim.x, blk = (int)blockIdx.x;
 
@@ -380,46 +459,8 @@ __global__ __launch_bounds__(kPlanBlock) void plan_policy_kernel(PlanArgs a) {
   if (n_fail == 0) return;  // nothing underflowed: the next two launches see the same count and leave at once
   const uint64_t clk0 = wall_clock64();
 
-  // ---- H: histogram of fallback counts (reads longer than max_len take the striped long-read path) ----
-  for (int r = tid; r < a.n_reads; r += kPlanBlock) {
-    const int f = a.fa.read_fail[r];
-    if (f > 0 && a.read_off[r + 1] - a.read_off[r] <= a.max_len) atomicAdd(a.hist + f, 1);
-  }
-  __threadfence();
-  __syncthreads();
-  GKLHIP_PLAN_STAMP(0);
-
-  // ---- S: bucket starts for DESCENDING count: pos[c] = #reads with count > c  ----
-  {
-    // per-thread contiguous segments of the count range [1, n_haps], highest counts first
-    const int n = a.n_haps;
-    const int per = (n + kPlanBlock - 1) / kPlanBlock;
-    const int hi = n - tid * per, lo = max(hi - per, 0);  // this thread owns counts (lo, hi]
-    int sum = 0;
-    for (int c = hi; c > lo; c--) sum += a.hist[c];
-    int32_t* s_scan = s_i32;
-    s_scan[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      const int used = min(kPlanBlock, (n + per - 1) / per);  // threads that own a non-empty segment
-      for (int t = 0; t < used; t++) { const int v = s_scan[t]; s_scan[t] = acc; acc += v; }
-      for (int t = used; t < kPlanBlock; t++) s_scan[t] = acc;
-      __hip_atomic_store(a.cnts + 4, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    int acc = s_scan[tid];
-    for (int c = hi; c > lo; c--) { a.pos[c] = acc; acc += a.hist[c]; }
-  }
-  __threadfence();
-  __syncthreads();
-  GKLHIP_PLAN_STAMP(1);
-
-  // ---- C: scatter ----
-  for (int r = tid; r < a.n_reads; r += kPlanBlock) {
-    const int f = a.fa.read_fail[r];
-    if (f > 0 && a.read_off[r + 1] - a.read_off[r] <= a.max_len) a.order[atomicAdd(a.pos + f, 1)] = r;
-  }
+  if (a.n_haps + 2 <= kPlanLdsBins) order_affected_reads<true>(a, s_hist, s_hist + kPlanLdsBins, s_i32, tid, clk0);
+  else                             order_affected_reads<false>(a, a.hist, a.pos, s_i32, tid, clk0);
   GKLHIP_PLAN_STAMP(2);
 }
 

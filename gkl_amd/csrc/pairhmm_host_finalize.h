@@ -7,7 +7,9 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <functional>
+#include <new>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -26,20 +28,33 @@ namespace gklhip {
 class WorkerPool {
  public:
   ~WorkerPool() { stop(); }
+  // Exceptions (a slice's vector growing under memory pressure, a thread that cannot be created) never unwind
+  // through a worker thread: the pool runs with the threads it has, a failing slice is remembered, every slice is
+  // waited for, and the failure is re-thrown on the calling thread (the C ABI maps it to GKLHIP_ERR_OOM).
   void parallel_for(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn) {
     if (threads <= 1 || n < 16384) { fn(0, n); return; }
-    ensure(threads - 1);
+    try { ensure(threads - 1); } catch (...) {}
+    threads = std::min(threads, (int)workers_.size() + 1);
+    if (threads <= 1) { fn(0, n); return; }
     const int64_t per = (n + threads - 1) / threads;
     {
       std::lock_guard<std::mutex> l(mu_);
       fn_ = &fn; n_ = n; per_ = per; slices_ = threads; next_ = 1; pending_ = threads - 1;
+      failed_ = false;
       gen_++;
     }
     cv_.notify_all();
-    fn(0, std::min(n, per));
-    std::unique_lock<std::mutex> l(mu_);
-    done_.wait(l, [&] { return pending_ == 0; });
-    fn_ = nullptr;
+    std::exception_ptr mine;
+    try { fn(0, std::min(n, per)); } catch (...) { mine = std::current_exception(); }
+    bool failed;
+    {
+      std::unique_lock<std::mutex> l(mu_);
+      done_.wait(l, [&] { return pending_ == 0; });
+      fn_ = nullptr;
+      failed = failed_;
+    }
+    if (mine) std::rethrow_exception(mine);
+    if (failed) throw std::bad_alloc();
   }
   void stop() {
     {
@@ -67,8 +82,10 @@ class WorkerPool {
         const int64_t lo = k * per_, hi = std::min(n_, lo + per_);
         const auto* fn = fn_;
         l.unlock();
-        if (lo < hi) (*fn)(lo, hi);
+        bool threw = false;
+        try { if (lo < hi) (*fn)(lo, hi); } catch (...) { threw = true; }
         l.lock();
+        failed_ |= threw;
         if (--pending_ == 0) done_.notify_all();
       }
       seen = gen_;
@@ -81,7 +98,7 @@ class WorkerPool {
   int64_t n_ = 0, per_ = 0;
   int slices_ = 0, next_ = 0, pending_ = 0;
   uint64_t gen_ = 0;
-  bool quit_ = false;
+  bool quit_ = false, failed_ = false;
 };
 }  // namespace gklhip
 

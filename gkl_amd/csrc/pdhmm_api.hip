@@ -720,14 +720,21 @@ int gklhip_pdhmm_compute_cross(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_cross* x,
   return gklhip_pdhmm_compute_cross_batched(c, x, 0, out_host);
 }
 
-int64_t gklhip_pdhmm_reference_batch_pairs(int32_t max_memory_mb, int32_t max_read_len, int32_t max_hap_len, int64_t total_pairs) {
-  // JavaData.h:86-101 + pdhmm-implementation.h:204-235 (the limit is also capped by the free RAM of the host)
-  if (max_memory_mb <= 0 || max_read_len <= 0 || max_hap_len <= 0 || total_pairs <= 0) return 0;
+int32_t gklhip_pdhmm_available_memory_mb(int32_t max_memory_mb) {
+  // pdhmm-implementation.h:204-235 (getMaxMemoryAvailable): min(maxMemoryInMB, free RAM of the host) -- taken ONCE, by
+  // initNative, like the reference does; the batch cut of every later call then depends on its arguments only
+  if (max_memory_mb <= 0) return 0;
   int64_t mb = max_memory_mb;
   struct sysinfo info;
-  if (sysinfo(&info) == 0) mb = std::min<int64_t>(mb, (int64_t)(info.freeram / (1024 * 1024)));
+  if (sysinfo(&info) == 0) mb = std::min<int64_t>(mb, (int64_t)info.freeram * (int64_t)info.mem_unit / (1024 * 1024));
+  return (int32_t)std::max<int64_t>(mb, 0);
+}
+
+int64_t gklhip_pdhmm_reference_batch_pairs(int32_t max_memory_mb, int32_t max_read_len, int32_t max_hap_len, int64_t total_pairs) {
+  // JavaData.h:86-101: min(totalPairs, maxMemory / memoryPerPair), maxMemory = what initNative kept (above)
+  if (max_memory_mb <= 0 || max_read_len <= 0 || max_hap_len <= 0 || total_pairs <= 0) return 0;
   const int64_t per_pair = ((int64_t)max_read_len * 5 + (int64_t)max_hap_len * 2) + 8 + 16;
-  return std::min(total_pairs, mb * 1024 * 1024 / per_pair);
+  return std::min(total_pairs, (int64_t)max_memory_mb * 1024 * 1024 / per_pair);
 }
 
 int gklhip_pdhmm_compute_cross_batched(gklhip_pdhmm_ctx* c, const gklhip_pdhmm_cross* x, int64_t ref_batch_pairs, double* out_host) {

@@ -227,7 +227,7 @@ class PairHmmContext:
     """One gklhip context (= one initNative).  `devices` = a list of device ordinals: every call is sharded over
     them inside the library (a device may appear twice)."""
 
-    def __init__(self, use_double: bool = False, max_threads: int = 1, device: int = -1,
+    def __init__(self, use_double: bool = False, max_threads: int = 0, device: int = -1,
                  fma_mode: int = 1, finalize: int = -1, record_events: bool = False,
                  rows_per_lane: int = 0, lib_path: Optional[str] = None, devices=None):
         self.lib = load_library(lib_path)
@@ -389,6 +389,8 @@ def load_pdhmm_library(path: Optional[str] = None):
     lib.gklhip_pdhmm_compute_cross_batched.restype = C.c_int
     lib.gklhip_pdhmm_reference_batch_pairs.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64]
     lib.gklhip_pdhmm_reference_batch_pairs.restype = C.c_int64
+    lib.gklhip_pdhmm_available_memory_mb.argtypes = [C.c_int32]
+    lib.gklhip_pdhmm_available_memory_mb.restype = C.c_int32
     lib.gklhip_pdhmm_done.argtypes = [C.c_void_p]
     lib.gklhip_pdhmm_done.restype = C.c_int
     lib.gklhip_pdhmm_last_kernel_ms.argtypes = [C.c_void_p]
@@ -414,6 +416,11 @@ def pdhmm_host_table(which: int) -> np.ndarray:
 def pdhmm_reference_batch_pairs(max_memory_mb: int, max_read_len: int, max_hap_len: int, total_pairs: int) -> int:
     """Pairs per batch of the reference's computeLikelihoodsNative (pdhmm/JavaData.h:83-101)."""
     return int(load_pdhmm_library().gklhip_pdhmm_reference_batch_pairs(max_memory_mb, max_read_len, max_hap_len, total_pairs))
+
+
+def pdhmm_available_memory_mb(max_memory_mb: int) -> int:
+    """min(maxMemoryInMB, free RAM of the host): what the reference's initNative keeps (pdhmm-implementation.h:204-235)."""
+    return int(load_pdhmm_library().gklhip_pdhmm_available_memory_mb(max_memory_mb))
 
 
 class PdhmmContext:

@@ -58,7 +58,7 @@ class IntelPDHMM:
     def initialize(self, args: Optional[PDHMMNativeArguments]) -> None:
         if args is None:
             args = PDHMMNativeArguments()
-        self._max_memory_mb = args.maxMemoryInMB
+        self._max_memory_mb = native.pdhmm_available_memory_mb(args.maxMemoryInMB)   # capped once, here (pdhmm-implementation.h:204-235)
         if self._ctx is not None:
             self._ctx.close()
         self._ctx = native.PdhmmContext()

@@ -71,8 +71,9 @@ typedef struct {
   int32_t abi_version;  /* GKLHIP_ABI_VERSION */
   int32_t device;       /* HIP device ordinal, -1 = current device */
   int32_t use_double;   /* PairHMMNativeArguments.useDoublePrecision (IntelPairHmm.cc:70) */
-  int32_t max_threads;  /* maxNumberOfThreads: host threads for the reference-exact finalize; <= 1 (the reference's
-                           default) = not set: min(cores, 8), or GKL_HIP_FINALIZE_THREADS */
+  int32_t max_threads;  /* maxNumberOfThreads (IntelPairHmm.cc:72-89): a CAP on the host threads of the reference-exact
+                           finalize, honoured as given -- 1 (the reference's default) = one thread per call;
+                           <= 0 = not set: the calls in flight share min(cores, 8).  GKL_HIP_FINALIZE_THREADS overrides */
   int32_t fma_mode;     /* 1 = arithmetic of GKL's AVX-512 objects (gcc-contracted FMA; default),
                            0 = arithmetic of GKL's AVX objects (separate mul/add) */
   int32_t finalize;     /* gklhip_finalize for gklhip_compute_device; -1 = default */

@@ -81,9 +81,12 @@ int gklhip_pdhmm_compute_cross(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_cross* 
 /* The reference's computeLikelihoodsNative cuts the read-major pair list into batches of
  * min(total, maxMemoryInMB / memoryPerPair) pairs (pdhmm/JavaData.h:83-101) and every batch ends in its own scalar tail.
  * ref_batch_pairs replays that cut in tail mode 1 (0: one batch); gklhip_pdhmm_reference_batch_pairs computes the
- * reference's number from maxMemoryInMB (capped by the host's free RAM, pdhmm-implementation.h:204-235) and the two
- * maximum lengths.  What the JNI shim's computeLikelihoodsNative calls. */
+ * reference's number from the memory limit and the two maximum lengths.  The limit is what initNative kept:
+ * gklhip_pdhmm_available_memory_mb(maxMemoryInMB) = min(maxMemoryInMB, the host's free RAM), taken once at
+ * initialisation like the reference's getMaxMemoryAvailable (pdhmm-implementation.h:204-235), so that identical calls
+ * are cut -- and therefore rounded -- identically.  What the JNI shim's computeLikelihoodsNative calls. */
 int gklhip_pdhmm_compute_cross_batched(gklhip_pdhmm_ctx* ctx, const gklhip_pdhmm_cross* batch, int64_t ref_batch_pairs, double* out_host);
+int32_t gklhip_pdhmm_available_memory_mb(int32_t max_memory_mb);
 int64_t gklhip_pdhmm_reference_batch_pairs(int32_t max_memory_mb, int32_t max_read_len, int32_t max_hap_len, int64_t total_pairs);
 /* HIP-event time of the forward kernel of the last call, milliseconds. */
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* ctx);

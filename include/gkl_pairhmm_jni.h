@@ -58,7 +58,7 @@ JNIEXPORT jint JNICALL JNI_OnLoad(struct JavaVM_* vm, void* reserved);
  * over the calls of the process since the last reset, in nanoseconds -- [0] marshalling the holders on the calling
  * thread, [1] waiting for compute that marshalling did not cover (a small call: all of gklhip_compute), [2] writing the
  * likelihoods back, [3] whole calls, [4] number of calls, [5] calls that were pipelined (read ranges marshalled while
- * earlier ranges compute; GKL_HIP_JNI_PIPELINE_PAIRS, default 262144 pairs, sets the size from which that happens). */
+ * earlier ranges compute; GKL_HIP_JNI_PIPELINE_PAIRS, default 160000 pairs, sets the size from which that happens). */
 void gkl_pairhmm_jni_timing(int64_t out[6], int reset);
 
 #ifdef __cplusplus

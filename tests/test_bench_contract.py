@@ -48,8 +48,11 @@ def test_bench_line_single_gpu():
     # computeLikelihoodsNative itself (mock JNIEnv): per-call time and its split; concurrent small callers
     j = d["jni_path"]
     assert "error" not in j, j
-    for k in ("c2", "c1"):
+    for k in ("c2", "c2_max_threads_4", "c1"):
         assert j[k]["ms_per_call"] > 0 and j[k]["marshal_ms"] >= 0 and j[k]["compute_wait_ms"] >= 0 and j[k]["writeback_ms"] >= 0
+    # maxNumberOfThreads is a cap on the host log10 threads: the line says what each setting costs
+    assert all(d["host_path"][k]["ms_per_call"] > 0 for k in ("max_threads_1", "max_threads_4", "max_threads_auto"))
+    assert d["comm"]["ranks_seen"] == 1 and d["comm"]["backend"] == "none" and d["comm"]["gather_bytes_per_rank"] == []
     conc = d["small_batch"]["concurrent"]
     assert all(conc[f"callers_{n}"]["aggregate_gcups"] > 0 for n in (1, 4, 16))
     er = d["small_batch"]["eighth_device_resident"]
@@ -74,3 +77,18 @@ def test_bench_line_two_ranks_on_one_gpu():
     lib = d["in_library"]
     assert "error" not in lib, lib
     assert lib["devices"] == 2 and lib["bit_identical_to_single_device"] is True
+    # the line says who took part in the exchange step; a short-handed group is a non-zero exit, not a smaller number
+    c = d["comm"]
+    assert c["backend"] == "gloo" and c["ranks_seen"] == 2 and c["world_size"] == 2
+    assert len(c["gather_bytes_per_rank"]) == 2 and sum(c["gather_bytes_per_rank"]) == 600 * 24 * 8
+    assert c["in_library_gather"]["backend"] == "peer" and c["in_library_gather"]["devices"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, GKL_BENCH_SAME_DEVICE="1", GKL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--reads", "200", "--haps", "8",
+                        "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

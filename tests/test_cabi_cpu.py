@@ -151,12 +151,14 @@ def test_null_context_is_invalid_argument():
 def test_pdhmm_reference_batch_size_formula():
     """gklhip_pdhmm_reference_batch_pairs = the reference's batchSize of computeLikelihoodsNative
     (pdhmm/JavaData.h:86-101): min(totalPairs, maxMemory / ((maxRead * 5 + maxHap * 2) + 8 + 16)), maxMemory in MB capped
-    by the host's free RAM (pdhmm-implementation.h:204-235) -- no device needed."""
+    by the host's free RAM at initNative (pdhmm-implementation.h:204-235) -- no device needed."""
     from gkl_amd import native
     f = native.pdhmm_reference_batch_pairs
     per = 151 * 5 + 300 * 2 + 8 + 16
     assert f(1, 151, 300, 10**9) == 1024 * 1024 // per
     assert f(1, 151, 300, 17) == 17                      # fewer pairs than a batch holds
     assert f(0, 151, 300, 17) == 0 and f(1, 0, 300, 17) == 0 and f(1, 151, 300, 0) == 0
-    big = f(10**6, 151, 300, 10**12)                     # more than any host has free: the free-RAM cap applies
-    assert 0 < big < 10**6 * 1024 * 1024 // per
+    # the free-RAM cap is applied once, by initNative (gklhip_pdhmm_available_memory_mb), not per call
+    assert native.pdhmm_available_memory_mb(1) == 1 and native.pdhmm_available_memory_mb(0) == 0
+    assert 0 < native.pdhmm_available_memory_mb(10**9) < 10**9   # more than any host has free
+    assert f(10**6, 151, 300, 10**12) == 10**6 * 1024 * 1024 // per
