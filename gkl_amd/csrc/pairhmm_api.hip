@@ -607,6 +607,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     a.jobs = c->jobs.as<FwdJob>();
     a.job_count = c->counters.as<int32_t>() + 2;
     a.job_next = c->counters.as<int32_t>() + 3;
+    const char* ag = getenv("GKLHIP_ASM_GENERAL");   // (read per call: the parity tests switch it)
+    a.asm_general = ag ? atoi(ag) : 1;
   };
 
   FinalizeArgs fa;
@@ -687,7 +689,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     d.raw = c->raw64.as<double>();
     d.stream = stream_flat;
     d.hap_pos = reinterpret_cast<const int32_t*>(dp + L.hap_pos_flat);
-    d.packed_out = fold_packed ? reinterpret_cast<uint64_t*>(out_dev) : nullptr;
+    // (the planned fp64 pass leaves the packed words of the recomputed pairs to finalize64_kernel: its jobs run as whole-job
+    //  asm programs that store the raw sums only)
+    d.packed_out = nullptr;
     d.packed_only_flagged = c->used64.as<uint8_t>();
     int32_t* cnts = c->counters.as<int32_t>();
     // Small calls (one GATK region): policy + fp64 recomputation + finalisation of one pair per wavefront in ONE launch
@@ -794,8 +798,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       launch_long<double, kRplF64>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
-    // (host-buffer calls: the fp64 kernels stored the packed words of the recomputed pairs themselves)
-    if (!fold_packed) hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
+    // (log10 of the recomputed pairs / host-buffer calls: their packed words)
+    hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 0);
     if (side_finalize) HIP_TRY(hipStreamWaitEvent(s, c->early_copy_done, 0));  // join the side stream
     }  // !per_pair
   }

@@ -46,7 +46,7 @@ constexpr int kLanes = 64;
 // compiler treat plain global memory as clobbered (there the entries came through global_load_dwordx4 + vmcnt waits).
 typedef const uint32_t __attribute__((address_space(4))) StreamWord;
 }  // namespace gklhip
-#include "pairhmm_fwd_fast_asm.h"  // fwd_fast_asm_f32r8: the fp32 / 8-row / FMA fast loop, hand-allocated (generated)
+#include "pairhmm_fwd_asm.h"  // generated: fwd_asm_run_f32r8 / fwd_asm_run_f64r10 (whole jobs, hand-allocated), fwd_fast_asm_f32r8 (fast blocks only)
 #ifndef GKLHIP_FAST_ASM
 #define GKLHIP_FAST_ASM 1  // 0: the C++ fast step everywhere (A/B and parity cross-check builds)
 #endif
@@ -112,6 +112,7 @@ struct FwdArgs {
   const FwdJob* jobs;
   const int32_t* job_count;
   int32_t* job_next;
+  int32_t asm_general;  // whole jobs in the generated asm programs (GKLHIP_ASM_GENERAL=0: C++ general steps around the fp32 fast block, C++ fp64 -- A/B and cross-checks)
 };
 
 // Host finalisation (reference-exact log10f / log10 of the host libm) needs, per pair, either the raw
@@ -224,6 +225,8 @@ struct WaveJob {
   static constexpr int kLdsBytes = kCodes * kRowBytes;  // idle columns are handled in step_any
   // fp32, 8 rows per lane, the AVX-512 object's FMA pattern (the default arithmetic): the unrolled loop is the generated asm block
   static constexpr bool kAsmFast = GKLHIP_FAST_ASM && sizeof(T) == 4 && RPL == 8 && FMA;
+  // fp64, 10 rows per lane (the packed recomputation pass and the all-fp64 mode), same arithmetic: whole jobs in asm
+  static constexpr bool kAsm64 = GKLHIP_FAST_ASM && sizeof(T) == 8 && RPL == 10 && FMA;
   static_assert(RPL % kPerVec == 0, "RPL must fill whole 16-byte vectors");
   using Vec = T __attribute__((ext_vector_type(kPerVec)));
 
@@ -526,6 +529,25 @@ struct WaveJob {
   // Stream haplotypes [hap_begin, hap_end) (stream order) through the loaded rows.
   __device__ __forceinline__ void run(const FwdArgs<T>& a, int lane, int hap_begin, int hap_end) {
     constexpr int U = 8;
+    if constexpr (kAsmFast || kAsm64) {
+      // the whole job in the generated asm program (tools/gen_fwd_asm.py) when only one separator can be in flight at a
+      // time: every haplotype of the job longer than the array is deep (stream order is by ascending length); fp64: no
+      // haplotype with an 'N' (four prior planes: such columns gather their priors row by row, see step_win)
+      bool whole = a.asm_general && a.hap_len[hap_begin] > skew_max;
+      if constexpr (kAsm64) {
+        if (whole) {
+          if (a.packed_out) whole = false;
+          bool any_n = false;
+          for (int k = hap_begin + lane; k < hap_end; k += kLanes) any_n |= a.hap_has_n[k] != 0;
+          if (__ballot(any_n) != 0) whole = false;
+        }
+      }
+      if (whole) {
+        if constexpr (kAsm64) fwd_asm_run_f64r10(*this, a, lane, hap_begin, hap_end);
+        else                  fwd_asm_run_f32r8(*this, a, lane, hap_begin, hap_end);
+        return;
+      }
+    }
     const int sb = a.hap_pos[hap_begin];
     StreamWord* sp = (StreamWord*)(a.stream + sb);
     reset_state(a.y0[hap_begin]);

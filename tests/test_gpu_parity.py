@@ -293,8 +293,8 @@ def test_full_size_batch_properties(native, oracle):
 
 
 def test_asm_fast_loop_matches_the_cxx_build_and_the_oracle(native, oracle):
-    """The fp32 / 8-row fast loop is a generated asm block (pairhmm_fwd_fast_asm.h); libgklhip_pairhmm_cxxfast.so is the
-    same library with the C++ step in its place.  Both must give the oracle's bits -- long haplotypes so that most
+    """The fp32 / 8-row jobs run as generated asm programs (pairhmm_fwd_asm.h); libgklhip_pairhmm_cxxfast.so is the
+    same library with the C++ steps in their place.  Both must give the oracle's bits -- long haplotypes so that most
     columns run in the unrolled loop, N and odd bytes included, one read overflowing next to healthy ones."""
     import os
     cxx = os.path.join(os.path.dirname(native.LIB_PATH), "libgklhip_pairhmm_cxxfast.so")
@@ -323,6 +323,46 @@ def test_asm_fast_loop_matches_the_cxx_build_and_the_oracle(native, oracle):
         others[3 * bad.n_haps:4 * bad.n_haps] = False
         assert np.array_equal(bits(ra32[others]), bits(o32[others])) and np.array_equal(bits(oa[others]), bits(oo[others]))
         assert np.array_equal(bits(oa[others]), bits(oc[others]))
+
+
+@pytest.mark.parametrize("use_double", [False, True])
+def test_whole_job_asm_programs_match_the_cxx_build(native, oracle, use_double, monkeypatch):
+    """Round 4: whole jobs -- fill, columns, separator windows, drain -- run as ONE generated asm program per haplotype
+    (tools/gen_fwd_asm.py), fp32 at 8 rows per lane and fp64 at 10 (the packed recomputation pass and the all-fp64 mode).
+    Three builds / modes must give the same bits as the oracle: the asm programs (default), the round-3 arrangement
+    (GKLHIP_ASM_GENERAL=0: asm fast blocks inside C++ general steps; fp64 all C++) and the all-C++ cross-check library.
+    Batches: the bench shape; haplotypes shorter than the array is deep (the job fails the program's precondition and
+    takes the C++ steps inside the asm build); haplotypes with N (fp64: four prior planes); lower case and odd bytes;
+    reads of one base up to the longest a chunk holds; single-lane reads (every lane feeds the separator itself)."""
+    import os
+    cxx = os.path.join(os.path.dirname(native.LIB_PATH), "libgklhip_pairhmm_cxxfast.so")
+    rng = np.random.RandomState(4242)
+    batches = [make_batch("hc", 1400, 50, seed=19),   # > 65 536 pairs: the planned fp64 pass (pairhmm_fwd_jobs_kernel)
+               make_batch("mixed", 300, 24, seed=20),
+               random_batch(rng, 80, 12, read_len=(1, 500), hap_len=(1, 60), alphabet=b"ACGT"),          # short haplotypes
+               random_batch(rng, 70, 10, read_len=(60, 500), hap_len=(80, 700), alphabet=b"ACGTNacgtRY"),  # N, odd bytes
+               random_batch(rng, 200, 8, read_len=(1, 7), hap_len=(10, 300)),                            # one lane per read
+               random_batch(rng, 30, 5, read_len=(480, 511), hap_len=(520, 900), qual_range=(0, 255))]
+    res = {}
+    for mode in ("asm", "round3", "cxx"):
+        if mode == "round3":
+            monkeypatch.setenv("GKLHIP_ASM_GENERAL", "0")
+        else:
+            monkeypatch.delenv("GKLHIP_ASM_GENERAL", raising=False)
+        with native.PairHmmContext(use_double=use_double, rows_per_lane=8, lib_path=cxx if mode == "cxx" else None) as c:
+            for i, b in enumerate(batches):
+                out = c.compute(b)
+                r32, r64, u = c.raw(b.n_pairs)
+                res[mode, i] = (out.copy(), r32.copy(), r64.copy(), u.copy())
+    for i, b in enumerate(batches):
+        oo, o32, o64, ou = oracle.batch(b, use_double=use_double, want_raw=True, n_threads=8)
+        for mode in ("asm", "round3", "cxx"):
+            out, r32, r64, u = res[mode, i]
+            assert np.array_equal(u, ou), (mode, i)
+            if not use_double:
+                assert np.array_equal(bits(r32), bits(o32)), (mode, i)
+            assert np.array_equal(bits(r64[u == 1]), bits(o64[ou == 1])), (mode, i)
+            assert np.array_equal(bits(out), bits(oo)), (mode, i)
 
 
 def test_region_batch_no_fallback(ctx32, oracle):
