@@ -363,6 +363,13 @@ void launch_pair_policy(const FwdArgs<double>& d, const PairPolicyArgs& q, int r
   }
 }
 
+// tiny calls: fp32 + policy + fp64 of ONE pair per wavefront in one launch (pairhmm_pair_fused_kernel)
+void launch_pair_fused(const FwdArgs<float>& f, const FwdArgs<double>& d, const PairPolicyArgs& q, int fma, int64_t n_pairs, hipStream_t s) {
+  const dim3 grid((unsigned)n_pairs), block(64);
+  if (fma) hipLaunchKernelGGL((pairhmm_pair_fused_kernel<kRplF64, true>), grid, block, 0, s, f, d, q);
+  else     hipLaunchKernelGGL((pairhmm_pair_fused_kernel<kRplF64, false>), grid, block, 0, s, f, d, q);
+}
+
 // The whole device-side pipeline on stream `s`: 5 launches in the policy mode (prep, fp32 forward, policy + planning
 // of the fp64 pass, fp64 forward over the job list, log10 of the recomputed pairs; + the log10 of the kept pairs on a
 // side stream in the device finalisation modes), no host synchronisation.  `db` holds host offsets and DEVICE byte
@@ -500,6 +507,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   const bool pull = L.total < (1u << 20);  // (256 KB .. 2 MB measure within 2 % on calls of 4k-50k pairs, 1 MB best)
   // (the one-pair-per-wavefront policy kernel holds at most 64 x kRplF64 - 1 rows)
   const bool per_pair_call = !use_double && n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
+  // ... the tiny ones (one GATK active region) with the fp32 recurrence in the same wavefront and launch as the policy
+  static const bool fused_env = [] { const char* v = getenv("GKLHIP_FUSED_PAIRS"); return !v || atoi(v) != 0; }();
+  const bool fused_call = per_pair_call && fused_env && n_pairs <= kTwoStepFrom && n_long_main == 0 && c->cfg.rows_per_lane == 0;
   const bool deferred_launch = defer && pull && inline_host && c->cfg.record_events == 0 && per_pair_call && n_long_main == 0 &&
                                finalize_mode == kModePacked && plan.n_chunks > 0 && n_pairs <= kTwoStepFrom;
   const unsigned char* hs_dev = nullptr;  // the staging block as the device sees it
@@ -667,7 +677,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       defer->call.f = a;
       defer->call.rpl_main = rpl_main;
       defer->call.main_blocks = n_main_blocks;
-    } else if (n_main_blocks > 0) {
+      defer->call.fused = fused_call ? 1 : 0;
+    } else if (n_main_blocks > 0 && !fused_call) {
       launch_main_f32(a, rpl_main, fma, n_main_blocks, s);
     }
     if (n_long_main > 0) {
@@ -718,7 +729,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
         return GKLHIP_OK;
       }
       if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
-      if (n_pairs > kTwoStepFrom) {
+      if (fused_call) {
+        launch_pair_fused(a, d, q, fma, n_pairs, s);
+      } else if (n_pairs > kTwoStepFrom) {
         if ((rc = c->fail_order.reserve((size_t)n_pairs * 4))) return rc;
         launch_pair_policy_two_step(d, q, rows, fma, n_pairs, c->fail_order.as<int32_t>(), s);
       } else {
@@ -974,8 +987,12 @@ struct SmallCombiner {
 
   int launch_single(const SmallCall& k, hipStream_t s) {
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)k.prep_grid), dim3(kPrepBlock), 0, s, k.prep);
-    launch_main_f32(k.f, k.rpl_main, k.fma, k.main_blocks, s);
-    launch_pair_policy(k.d, k.q, k.rows, k.fma, k.n_pairs, s);
+    if (k.fused) {
+      launch_pair_fused(k.f, k.d, k.q, k.fma, k.n_pairs, s);
+    } else {
+      launch_main_f32(k.f, k.rpl_main, k.fma, k.main_blocks, s);
+      launch_pair_policy(k.d, k.q, k.rows, k.fma, k.n_pairs, s);
+    }
     HIP_TRY(hipGetLastError());
     return GKLHIP_OK;
   }
@@ -990,7 +1007,10 @@ struct SmallCombiner {
       mq.begin[i + 1] = mq.begin[i] + L.call.n_pairs;
     }
     hipLaunchKernelGGL(prep_multi_kernel, dim3((unsigned)mp.begin[n]), dim3(kPrepBlock), 0, sl.stream, mp);
-    if (fma) {
+    if (batch[0]->sl->call.fused) {  // (every call of a set is of one kind: the leader only takes calls like its own)
+      if (fma) hipLaunchKernelGGL((pair_fused_multi_kernel<true, kRplF64>), dim3((unsigned)mq.begin[n]), dim3(64), 0, sl.stream, mq);
+      else     hipLaunchKernelGGL((pair_fused_multi_kernel<false, kRplF64>), dim3((unsigned)mq.begin[n]), dim3(64), 0, sl.stream, mq);
+    } else if (fma) {
       hipLaunchKernelGGL((fwd_stream_multi_kernel<true, kRplF32>), dim3((unsigned)mf.begin[n]), dim3(64), 0, sl.stream, mf);
       hipLaunchKernelGGL((pair_policy_multi_kernel<true, kRplF64>), dim3((unsigned)mq.begin[n]), dim3(64), 0, sl.stream, mq);
     } else {
@@ -1020,7 +1040,7 @@ struct SmallCombiner {
       batch[n++] = &t;
       for (auto it = queue.begin(); it != queue.end();) {
         if (*it == &t) { it = queue.erase(it); continue; }
-        if (n < kMultiMax && (*it)->sl->call.fma == mine.call.fma) {
+        if (n < kMultiMax && (*it)->sl->call.fma == mine.call.fma && (*it)->sl->call.fused == mine.call.fused) {
           (*it)->state = 4;  // taken: its owner keeps sleeping until this thread reports the launch (or the end)
           ns_queued += t_lead - (*it)->t_in;
           batch[n++] = *it;

@@ -105,6 +105,7 @@ struct SmallCall {
   FwdArgs<double> d;
   PairPolicyArgs q;
   int32_t prep_grid, rpl_main, main_blocks, rows, n_pairs, fma;
+  int32_t fused;  // the whole pair in one wavefront (pair_fused_block) instead of the packed fp32 pass + per-pair policy
 };
 constexpr int kMultiMax = 16;
 struct MultiArgs {
@@ -148,6 +149,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
   const FwdArgs<double> d = c->d;
   const PairPolicyArgs q = c->q;
   pair_policy_block<kRplF64, FMA>(d, q, p, lds);  // (rows per lane by the pair's own read)
+}
+
+template <bool FMA, int kRplF64>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pair_fused_multi_kernel(MultiArgs m) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PairFusedLds<kRplF64, FMA>::bytes];
+  const int r = multi_find(m, (int)blockIdx.x);
+  const SmallCall* c = m.call[r];
+  const int64_t p = (int)blockIdx.x - m.begin[r];
+  const FwdArgs<float> f = c->f;
+  const FwdArgs<double> d = c->d;
+  const PairPolicyArgs q = c->q;
+  pair_fused_block<kRplF64, FMA>(f, d, q, p, lds);
 }
 
 constexpr int kModePacked = kModePackedWords;  // FinalizeArgs::mode: `out` receives packed raw sums (kPackedF32Tag, pairhmm_fwd_kernel.h)

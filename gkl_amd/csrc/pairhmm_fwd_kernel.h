@@ -785,6 +785,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
   pair_policy_block<RPL, FMA>(a, q, (int64_t)blockIdx.x, lds);
 }
 
+// Tiny calls (one GATK active region, up to a couple of thousand pairs): the WHOLE pair in one wavefront and one launch
+// behind the preparation -- the pair's fp32 recurrence with the read alone in the wavefront (lanes 0 .. ceil((R+1)/RPL)-1,
+// rows per lane by the read's length), the policy on its own sum and, when that fails, the fp64 recomputation right
+// away.  Against the packed fp32 pass + per-pair policy launch this wastes lanes (irrelevant: the chip is mostly idle)
+// and saves a launch, a dispatch of one block per pair and the chaining of several haplotypes per fp32 job: the
+// dependent chain of a 100 x 10 region is one pair's ~350 steps at two rows per lane instead of a chunk's at four.
+template <int RPL, bool FMA>
+__device__ __forceinline__ float pair_fp32_alone(const FwdArgs<float>& f, int64_t p, int r, int R, int k, unsigned char* lds) {
+  using Job = WaveJob<float, RPL, FMA>;
+  const int lane = threadIdx.x;
+  LaneSlot slot;
+  slot.read = lane < (R + RPL) / RPL ? r : -1;
+  slot.block = lane;
+  Job job;
+  job.lds = lds;
+  job.setup(f, lane, slot);
+  __syncthreads();
+  job.run(f, lane, k, k + 1);
+  // the lane holding the read's last row stored the sum (emit_result / the asm program): it reads its own store back
+  // (past the vector cache: another wavefront of this CU may have pulled the line in before the store) and broadcasts it
+  float v = 0.0f;
+  if (job.out_read >= 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    v = __hip_atomic_load(f.raw + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const uint64_t m = __ballot(job.out_read >= 0);
+  return read_lane(v, (int)__builtin_ctzll(m));
+}
+template <int MAXR64, bool FMA>
+__device__ __forceinline__ void pair_fused_block(const FwdArgs<float>& f, const FwdArgs<double>& d, const PairPolicyArgs& q, int64_t p,
+                                                 unsigned char* lds) {
+  const int lane = threadIdx.x;
+  const int r = (int)(p / f.b.n_haps), k = q.hap_sidx[(int)(p - (int64_t)r * f.b.n_haps)];
+  const int R = (int)(f.b.read_off[r + 1] - f.b.read_off[r]);
+  float v;
+  if (R <= 2 * kLanes - 1)      v = pair_fp32_alone<2, FMA>(f, p, r, R, k, lds);
+  else if (R <= 4 * kLanes - 1) v = pair_fp32_alone<4, FMA>(f, p, r, R, k, lds);
+  else                          v = pair_fp32_alone<8, FMA>(f, p, r, R, k, lds);
+  const bool fails = v < 1e-28f;  // NaN compares false and stays fp32, like the reference (IntelPairHmm.cc:159)
+  if (lane == 0) {
+    q.used64[p] = fails ? 1 : 0;
+    if (fails) atomicAdd(q.count, 1);
+    else if (q.mode == kModePackedWords) reinterpret_cast<uint64_t*>(q.out)[p] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
+    else if (q.mode == 1) q.out[p] = log10((double)v) - q.log10_init32_as_f64;                        // GKLHIP_FINALIZE_DEVICE_F64
+    else if (q.mode == 2) q.out[p] = (double)((float)log10((double)v) - q.log10_init_f);             // GKLHIP_FINALIZE_DEVICE_REF32
+  }
+  if (!fails) return;
+  __syncthreads();  // the fp32 table's readers are done: the fp64 table takes its place
+  if (MAXR64 > 2 && R <= 2 * kLanes - 1)      pair_policy_recompute<2, FMA>(d, q, p, r, R, k, lds);
+  else if (MAXR64 > 4 && R <= 4 * kLanes - 1) pair_policy_recompute<4, FMA>(d, q, p, r, R, k, lds);
+  else                                        pair_policy_recompute<MAXR64, FMA>(d, q, p, r, R, k, lds);
+}
+template <int MAXR64, bool FMA>
+struct PairFusedLds {
+  static constexpr int a = WaveJob<float, 8, FMA>::kLdsBytes, b = WaveJob<double, 2, FMA>::kLdsBytes, c = WaveJob<double, 4, FMA>::kLdsBytes,
+                       d = WaveJob<double, MAXR64, FMA>::kLdsBytes;
+  static constexpr int ab = a > b ? a : b, cd = c > d ? c : d, bytes = ab > cd ? ab : cd;
+};
+template <int MAXR64, bool FMA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pairhmm_pair_fused_kernel(FwdArgs<float> f, FwdArgs<double> d,
+                                                                                                       PairPolicyArgs q) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PairFusedLds<MAXR64, FMA>::bytes];
+  pair_fused_block<MAXR64, FMA>(f, d, q, (int64_t)blockIdx.x, lds);
+}
+
 // Mid-size calls (thousands of pairs): the same per-pair policy in two launches.  One block per PAIR leaves the
 // dispatcher at ~150-200 blocks per microsecond, and the recomputing blocks scattered through a grid of 16 000 start up
 // to 100 us late (tools/small_scaling.py: 66 us for 1000 pairs, 165 us for 16 000 with the same share recomputing).
