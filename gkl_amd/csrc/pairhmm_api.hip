@@ -263,6 +263,19 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
   else     hipLaunchKernelGGL((pairhmm_fwd_long_kernel<T, RPL, false>), dim3(n_blocks), dim3(64), 0, s, a, carry, carry_len);
 }
 
+// long reads: workgroups of kWideWaves wavefronts per (read, haplotype run) job (pairhmm_fwd_wide_kernel: the asm programs'
+// arithmetic only); the unfused arithmetic keeps the one-wavefront striped kernel
+template <typename T, int RPL, int RPL_STRIPED>
+void launch_long_jobs(const FwdArgs<T>& a, int fma, int n_blocks, int max_read_len, T* carry, int carry_len, hipStream_t s) {
+  static const bool wide_env = [] { const char* v = getenv("GKLHIP_WIDE_LONG"); return !v || atoi(v) != 0; }();
+  if (!fma || !wide_env) { launch_long<T, RPL_STRIPED>(a, fma, n_blocks, carry, carry_len, s); return; }
+  // wavefronts per workgroup: what the call's longest read needs, at most kWideWavesMax (longer reads are striped in-kernel)
+  const int waves = std::max(2, std::min(kWideWavesMax, (blocks_for(max_read_len, RPL) + kLanes - 1) / kLanes));
+  if (waves == 2)      hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 2>), dim3(n_blocks), dim3(128), 0, s, a, carry, carry_len);
+  else if (waves == 3) hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 3>), dim3(n_blocks), dim3(192), 0, s, a, carry, carry_len);
+  else                 hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 4>), dim3(n_blocks), dim3(256), 0, s, a, carry, carry_len);
+}
+
 // A small host-buffer call, planned and staged but not launched: SmallCombiner decides how it reaches the device (on
 // its own, or in one set of launches with the calls of other threads).
 struct SmallLaunch {
@@ -658,7 +671,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       la.jobs = reinterpret_cast<const FwdJob*>(dp + L.long_jobs);
       la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
       la.job_next = c->counters.as<int32_t>() + 7;
-      launch_long<double, kRplF64>(la, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
+      launch_long_jobs<double, kRplF64Jobs, kRplF64>(la, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
@@ -688,7 +701,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
       la.job_next = c->counters.as<int32_t>() + 7;
       if (rpl_main <= 4) launch_long<float, 4>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);  // (2 is only chosen without long reads)
-      else               launch_long<float, kRplF32>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);
+      else               launch_long_jobs<float, kRplF32, kRplF32>(la, fma, n_long_waves, plan.max_read_len, c->carry.as<float>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
 
@@ -808,7 +821,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       ld.jobs = c->jobs_long.as<FwdJob>();
       ld.job_count = cnts + 8;
       ld.job_next = cnts + 9;
-      launch_long<double, kRplF64>(ld, fma, n_long_waves, c->carry.as<double>(), carry_len, s);
+      launch_long_jobs<double, kRplF64Jobs, kRplF64>(ld, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
     // (log10 of the recomputed pairs / host-buffer calls: their packed words)

@@ -898,42 +898,115 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
 // one persistent wavefront per (read, haplotype run) job; `carry` is per-wavefront scratch for
 // the two ping-pong carry rows (2 x 3 x carry_len values).
 template <typename T, int RPL, bool FMA>
+__device__ __forceinline__ void long_job_striped(const FwdArgs<T>& a, const FwdJob& j, T* my, int carry_len, unsigned char* lds) {
+  using Job = WaveJob<T, RPL, FMA>;
+  const int lane = threadIdx.x & 63;
+  const int64_t cstride = 3 * (int64_t)carry_len + 64;  // (M,X,Y) rows + the column-0 triple
+  Job job;
+  job.lds = lds;
+  const int r = a.chunk_lanes[(int64_t)j.chunk * kLanes].read;  // pseudo-chunk: lane 0 names the read
+  const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+  const int n_blocks = (R + RPL) / RPL;
+  const int n_stripes = (n_blocks + kLanes - 1) / kLanes;
+  const int first_cnt = n_blocks - kLanes * (n_stripes - 1);  // lanes of the first (partial) stripe
+  for (int st = 0; st < n_stripes; st++) {
+    LaneSlot slot;
+    if (st == 0) {
+      slot.read = lane >= kLanes - first_cnt ? r : -1;
+      slot.block = lane - (kLanes - first_cnt);
+    } else {
+      slot.read = r;
+      slot.block = first_cnt + (st - 1) * kLanes + lane;
+    }
+    __builtin_amdgcn_wave_barrier();  // (one wavefront owns this table: LDS operations of a wavefront execute in order)
+    job.setup(a, lane, slot, /*full_skew=*/true);
+    __builtin_amdgcn_wave_barrier();
+    const T* cin = st > 0 ? my + (int64_t)((st + 1) & 1) * cstride : nullptr;
+    T* cout = st + 1 < n_stripes ? my + (int64_t)(st & 1) * cstride : nullptr;
+    job.run_stripe(a, lane, j.hap_begin, j.hap_end, cin, cout, carry_len);
+    __threadfence_block();  // this stripe's carry stores before the next stripe's carry loads
+  }
+}
+template <typename T, int RPL, bool FMA>
 __global__ __launch_bounds__(64) void pairhmm_fwd_long_kernel(FwdArgs<T> a, T* carry, int carry_len) {
   using Job = WaveJob<T, RPL, FMA>;
   __shared__ __attribute__((aligned(16))) unsigned char lds[Job::kLdsBytes];
   const int lane = threadIdx.x;
   const int n = *a.job_count;
-  const int64_t cstride = 3 * (int64_t)carry_len + 64;  // (M,X,Y) rows + the column-0 triple
+  const int64_t cstride = 3 * (int64_t)carry_len + 64;
   T* my = carry + (int64_t)blockIdx.x * 2 * cstride;
-  Job job;
-  job.lds = lds;
   for (;;) {
     int idx = 0;
     if (lane == 0) idx = atomicAdd(a.job_next, 1);
     idx = __builtin_amdgcn_readfirstlane(idx);
     if (idx >= n) break;
     const FwdJob j = a.jobs[idx];
-    const int r = a.chunk_lanes[(int64_t)j.chunk * kLanes].read;  // pseudo-chunk: lane 0 names the read
+    long_job_striped<T, RPL, FMA>(a, j, my, carry_len, lds);
+  }
+}
+
+// Long reads at speed (round 4): a read of more rows than one wavefront holds spans the kWideWaves wavefronts of ONE
+// workgroup -- lanes 64 w .. 64 w + 63 of one systolic array, the bottom row of a wavefront's lane 63 reaching the next
+// wavefront's lane 0 through a ring in LDS (the reference's stripes with their carry row, avx-pairhmm-template.h:249,
+// 291-323, side by side instead of one after the other) -- and every wavefront runs the generated whole-job asm program
+// (fwd_asm_run_wide_*).  Reads of up to 4 x 64 x RPL - 1 bases; a job that fails the program's preconditions (longer
+// reads, a haplotype no longer than a wavefront is deep, fp64: a haplotype with an 'N', the unfused arithmetic) is
+// striped through memory by the workgroup's first wavefront as before.
+// W = wavefronts per workgroup (2..4), chosen per call from its longest read: the workgroup's LDS is W prior tables, and
+// a call whose reads need two wavefronts should not pay for four (fp64: 20 KB each -- one workgroup per CU at W = 4,
+// three at W = 2).
+constexpr int kWideWavesMax = 4;
+template <typename T, int RPL, bool FMA, int kWideWaves>
+__global__ __launch_bounds__(64 * kWideWaves) void pairhmm_fwd_wide_kernel(FwdArgs<T> a, T* carry, int carry_len) {
+  using Job = WaveJob<T, RPL, FMA>;
+  constexpr int kSlot = sizeof(T) == 8 ? 32 : 16;   // one (M, X, Y) triple
+  constexpr int kRingSlots = 64;                    // = RING of tools/gen_fwd_asm.py
+  __shared__ __attribute__((aligned(16))) unsigned char tables[kWideWaves][Job::kLdsBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char rings[kWideWaves - 1][kRingSlots * kSlot];
+  __shared__ uint32_t flags[kWideWaves];
+  __shared__ int32_t s_job;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = *a.job_count;
+  const int64_t cstride = 3 * (int64_t)carry_len + 64;
+  T* my = carry + (int64_t)blockIdx.x * 2 * cstride;
+  for (;;) {
+    __syncthreads();  // the previous job is done in every wavefront: rings and flags are free
+    if (threadIdx.x == 0) s_job = atomicAdd(a.job_next, 1);
+    if (threadIdx.x < kWideWaves) flags[threadIdx.x] = 0;
+    __syncthreads();
+    const int idx = __builtin_amdgcn_readfirstlane(s_job);
+    if (idx >= n) break;
+    const FwdJob j = a.jobs[idx];
+    const int r = a.chunk_lanes[(int64_t)j.chunk * kLanes].read;
     const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
     const int n_blocks = (R + RPL) / RPL;
-    const int n_stripes = (n_blocks + kLanes - 1) / kLanes;
-    const int first_cnt = n_blocks - kLanes * (n_stripes - 1);  // lanes of the first (partial) stripe
-    for (int st = 0; st < n_stripes; st++) {
+    const int n_waves = (n_blocks + kLanes - 1) / kLanes;
+    bool wide = (Job::kAsmFast || Job::kAsm64) && a.asm_general && n_waves <= kWideWaves && a.hap_len[j.hap_begin] > kLanes - 1;
+    if (Job::kAsm64 && wide) {
+      if (a.packed_out) wide = false;
+      bool any_n = false;
+      for (int k = j.hap_begin + lane; k < j.hap_end; k += kLanes) any_n |= a.hap_has_n[k] != 0;
+      if (__ballot(any_n) != 0) wide = false;
+    }
+    if (!wide) {
+      if (wave == 0) long_job_striped<T, RPL, FMA>(a, j, my, carry_len, tables[0]);
+      continue;
+    }
+    if (wave >= n_waves) continue;
+    if constexpr (Job::kAsmFast || Job::kAsm64) {
       LaneSlot slot;
-      if (st == 0) {
-        slot.read = lane >= kLanes - first_cnt ? r : -1;
-        slot.block = lane - (kLanes - first_cnt);
-      } else {
-        slot.read = r;
-        slot.block = first_cnt + (st - 1) * kLanes + lane;
-      }
-      __syncthreads();
+      slot.block = wave * kLanes + lane;
+      slot.read = slot.block < n_blocks ? r : -1;
+      Job job;
+      job.lds = tables[wave];
       job.setup(a, lane, slot, /*full_skew=*/true);
-      __syncthreads();
-      const T* cin = st > 0 ? my + (int64_t)((st + 1) & 1) * cstride : nullptr;
-      T* cout = st + 1 < n_stripes ? my + (int64_t)(st & 1) * cstride : nullptr;
-      job.run_stripe(a, lane, j.hap_begin, j.hap_end, cin, cout, carry_len);
-      __threadfence_block();  // this stripe's carry stores before the next stripe's carry loads
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t ring_in = wave > 0 ? (uint32_t)(uintptr_t)rings[wave - 1] : 0u;
+      const uint32_t ring_out = wave + 1 < kWideWaves ? (uint32_t)(uintptr_t)rings[wave < kWideWaves - 1 ? wave : 0] : 0u;
+      const uint32_t f_own = (uint32_t)(uintptr_t)&flags[wave], f_prod = (uint32_t)(uintptr_t)&flags[wave > 0 ? wave - 1 : 0],
+                     f_cons = (uint32_t)(uintptr_t)&flags[wave + 1 < kWideWaves ? wave + 1 : wave];
+      if constexpr (Job::kAsm64) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+      else                       fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
     }
   }
 }

@@ -40,7 +40,9 @@ S_E0 = 72          # s[72:79]: eight stream entries (s_load_dwordx8: 4-aligned)
 S_SENT, S_ORIG, S_CNT, S_PH, S_BT, S_TMP = "s80", "s81", "s82", "s83", "s84", "s85"
 S_SAVE = "s[86:87]"
 S_SRC = 88         # s[88:89]: the stream pointer (operand src, pinned there)
+S_T, S_NEED = "s90", "s91"   # wide variant: steps this wavefront has completed (operand st, pinned there); scratch
 S_CLOB = [f"s{i}" for i in range(72, 88)]
+RING = 64          # wide variant: slots of a hand-off ring
 
 
 class Cfg:
@@ -63,7 +65,8 @@ class Cfg:
             (self.SM, self.SX, self.ENT, self.EAB, self.LMASK, self.DIRECT, self.NDIRECT, self.LOFF, self.ADDR, self.NSEP, self.VAL,
              self.OUTIDX, self.PADSLOT, self.Y0N, self.A, self.P) = 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 120
             self.KREG = None
-            self.last = 121
+            self.WADDR, self.FV = 122, 123      # wide variant: ring address, flag value
+            self.last = 123
             self.codes, self.planes, self.plane_stride, self.code_shift = 5, 2, 1024, 11
         else:
             b = 16
@@ -81,7 +84,8 @@ class Cfg:
             self.SM, self.SX = 216, 218
             (self.ENT, self.EAB, self.LMASK, self.DIRECT, self.NDIRECT, self.LOFF, self.ADDR, self.NSEP) = 220, 221, 222, 223, 224, 225, 226, 227
             self.VAL, self.OUTIDX, self.PADSLOT, self.Y0N, self.A, self.P, self.KREG = 228, 230, 231, 232, 234, 236, 238
-            self.last = 238
+            self.WADDR, self.FV = 239, 240
+            self.last = 240
             self.codes, self.planes, self.plane_stride, self.code_shift = 4, 5, 1024, None   # code * 5120 via KREG
 
     # operand text
@@ -166,7 +170,88 @@ def recurrence(c, yo, yn, d, r, general):
     return o
 
 
-def fast_step(c, u, last, e):
+def wide_handoff(c, target, y_reg, lab):
+    """wide variant, end of a step: the bottom row of lane 63 goes to the next wavefront's ring slot of this step, the
+    previous wavefront's slot of this step lands in lane 0's row-above registers `target` (= the DPP fetch's target)."""
+    R = c.R
+    sz = 8 if c.f64 else 4
+    slot_shift = 5 if c.f64 else 4
+    o = []
+    o.append("s_cmp_eq_u32 %[has_out], 0")
+    o.append(f"s_cbranch_scc1 {lab}f")
+    o.append(f"s_and_b32 {S_NEED}, {S_T}, {RING - 1}")
+    o.append(f"s_lshl_b32 {S_NEED}, {S_NEED}, {slot_shift}")
+    o.append(f"s_add_u32 {S_NEED}, {S_NEED}, %[ring_out]")
+    o.append(f"v_mov_b32 v{c.WADDR}, {S_NEED}")
+    o.append("s_mov_b32 exec_lo, 0")
+    o.append("s_brev_b32 exec_hi, 1")                          # lane 63 alone
+    w = "ds_write_b64" if c.f64 else "ds_write_b32"
+    for k, reg in enumerate((c.M(R - 1), c.X(R - 1), y_reg)):
+        off = f" offset:{k * sz}" if k else ""
+        o.append(f"{w} v{c.WADDR}, {c.v(reg)}{off}")
+    o.append("s_mov_b64 exec, -1")
+    o.append(f"{lab}:")
+    o.append("s_cmp_eq_u32 %[has_in], 0")
+    o.append(f"s_cbranch_scc1 {lab + 1}f")
+    o.append(f"s_and_b32 {S_NEED}, {S_T}, {RING - 1}")
+    o.append(f"s_lshl_b32 {S_NEED}, {S_NEED}, {slot_shift}")
+    o.append(f"s_add_u32 {S_NEED}, {S_NEED}, %[ring_in]")
+    o.append(f"v_mov_b32 v{c.WADDR}, {S_NEED}")
+    o.append("s_mov_b64 exec, 1")                              # lane 0 alone
+    if c.f64:
+        for k in range(3):
+            off = f" offset:{k * 8}" if k else ""
+            o.append(f"ds_read_b64 {c.v(target[k])}, v{c.WADDR}{off}")
+    else:
+        o.append(f"ds_read_b96 v[{target[0]}:{target[0] + 2}], v{c.WADDR}")
+    o.append("s_mov_b64 exec, -1")
+    o.append(f"{lab + 1}:")
+    o.append(f"s_add_u32 {S_T}, {S_T}, 1")
+    return o
+
+
+def wide_wait(c, lab):
+    """wide variant, before a group of up to 8 steps: the previous wavefront must have finished the steps whose rows this
+    group fetches; the next wavefront must have fetched the ring slots this group overwrites."""
+    o = []
+    o.append("s_cmp_eq_u32 %[has_in], 0")
+    o.append(f"s_cbranch_scc1 {lab + 1}f")
+    o.append(f"s_add_u32 {S_NEED}, {S_T}, 8")
+    o.append(f"s_min_u32 {S_NEED}, {S_NEED}, %[t_end]")
+    o.append(f"{lab}:")
+    o.append(f"v_mov_b32 v{c.FV}, %[flag_prod]")
+    o.append(f"ds_read_b32 v{c.FV}, v{c.FV}")
+    o.append("s_waitcnt lgkmcnt(0)")
+    o.append(f"v_readfirstlane_b32 {S_TMP}, v{c.FV}")
+    o.append(f"s_cmp_ge_u32 {S_TMP}, {S_NEED}")
+    o.append(f"s_cbranch_scc1 {lab + 1}f")
+    o.append("s_sleep 1")
+    o.append(f"s_branch {lab}b")
+    o.append(f"{lab + 1}:")
+    o.append("s_cmp_eq_u32 %[has_out], 0")
+    o.append(f"s_cbranch_scc1 {lab + 3}f")
+    o.append(f"s_add_u32 {S_NEED}, {S_T}, 8")
+    o.append(f"{lab + 2}:")
+    o.append(f"v_mov_b32 v{c.FV}, %[flag_cons]")
+    o.append(f"ds_read_b32 v{c.FV}, v{c.FV}")
+    o.append("s_waitcnt lgkmcnt(0)")
+    o.append(f"v_readfirstlane_b32 {S_TMP}, v{c.FV}")
+    o.append(f"s_add_u32 {S_TMP}, {S_TMP}, {RING}")
+    o.append(f"s_cmp_ge_u32 {S_TMP}, {S_NEED}")
+    o.append(f"s_cbranch_scc1 {lab + 3}f")
+    o.append("s_sleep 1")
+    o.append(f"s_branch {lab + 2}b")
+    o.append(f"{lab + 3}:")
+    return o
+
+
+def wide_publish(c):
+    """wide variant, after a group: tell the neighbours how many steps this wavefront has completed"""
+    return [f"v_mov_b32 v{c.FV}, {S_T}", f"v_mov_b32 v{c.WADDR}, %[flag_own]", "s_mov_b64 exec, 1",
+            f"ds_write_b32 v{c.WADDR}, v{c.FV}", "s_mov_b64 exec, -1"]
+
+
+def fast_step(c, u, last, e, wide=False, lab=0):
     """one stream column, every lane inside a haplotype.  fp32: Y ping-pongs between Ya and Yb (VOP2 v_fmac); fp64: in place."""
     R = c.R
     if c.f64:
@@ -184,17 +269,19 @@ def fast_step(c, u, last, e):
     o += dpp_recv(c, d[2], yn(R - 1))
     o += dpp_recv(c, d[1], c.X(R - 1))
     o.append(f"{fp(c, 'add')} {c.v(c.SX)}, {c.v(c.SX)}, {c.v(c.X(R - 1))}")
+    if wide:
+        o += wide_handoff(c, d, yn(R - 1), lab)
     return o
 
 
-def fast_block(c, ents):
+def fast_block(c, ents, wide=False):
     o = ["s_nop 1", f"v_and_b32_dpp v{c.EAB}, v{c.ENT}, v{c.NDIRECT} {DPP}"]
     for u in range(U):
-        o += fast_step(c, u, u == U - 1, ents[u])
+        o += fast_step(c, u, u == U - 1, ents[u], wide, 300 + 4 * u)
     return o
 
 
-def general_step(c, e, lab):
+def general_step(c, e, lab, wide=False):
     """one stream column, any entry kind; parity-neutral (Y in Ya in place, row-above set in RS[0], diagonal set in RS[1]).
     `lab`: base of this copy's local labels.  Scalar state: S_CNT steps left in this run (counted here), S_BT = the value of
     S_CNT at which the step feeds the haplotype's separator (0xffffffff: never), S_SENT / S_ORIG the separator in flight."""
@@ -264,10 +351,12 @@ def general_step(c, e, lab):
     o += dpp_recv(c, r[0], c.M(R - 1))
     o += dpp_recv(c, r[2], c.YA(R - 1))
     o += dpp_recv(c, r[1], c.X(R - 1))
+    if wide:
+        o += wide_handoff(c, r, c.YA(R - 1), lab + 5)
     return o
 
 
-def program(c):
+def program(c, wide=False):
     """the asm statement: general(%[n_pre]) -> fast(%[n_blk] blocks) -> general(%[n_post], its last step feeding the
     separator when %[has_sep])."""
     ents = [f"s{S_E0 + u}" for u in range(U)]
@@ -281,8 +370,12 @@ def program(c):
     o.append("s_cbranch_scc1 70f")
     o.append("61:")
     o += load
+    if wide:
+        o += wide_wait(c, 200)
     for u in range(U):
-        o += general_step(c, ents[u], 100 + 10 * u)
+        o += general_step(c, ents[u], 100 + 10 * u, wide)
+        if wide and u == U - 1:
+            o += wide_publish(c)
         o.append(f"s_sub_u32 {S_CNT}, {S_CNT}, 1")
         o.append(f"s_cmp_eq_u32 {S_CNT}, 0")
         if u < U - 1:
@@ -297,6 +390,8 @@ def program(c):
         if u < U - 2:
             o.append("s_branch 70f")
     o.append("70:")
+    if wide:
+        o += wide_publish(c)
     o.append(f"s_cmp_lg_u32 {S_PH}, 0")
     o.append("s_cbranch_scc1 99f")
     o.append(f"s_mov_b32 {S_CNT}, %[n_blk]")                   # ---- fast blocks
@@ -304,7 +399,11 @@ def program(c):
     o.append(f"s_cmp_eq_u32 {S_CNT}, 0")
     o.append("s_cbranch_scc1 81f")
     o += load
-    o += fast_block(c, ents)
+    if wide:
+        o += wide_wait(c, 210)
+    o += fast_block(c, ents, wide)
+    if wide:
+        o += wide_publish(c)
     o.append(f"s_sub_u32 {S_CNT}, {S_CNT}, 1")
     o.append("s_branch 80b")
     o.append("81:")
@@ -366,14 +465,23 @@ def clobbers(c):
     return [f"v{x}" for x in sorted(cl)] + S_CLOB + ["vcc", "scc", "memory"]
 
 
-def driver(c, o):
+def driver(c, o, wide=False):
     T = "double" if c.f64 else "float"
     CT = "ConstF64" if c.f64 else "ConstF32"
     o.append("")
     o.append(f"// One whole job (haplotypes [hap_begin, hap_end) streamed through the loaded rows) of WaveJob<{T}, {c.R}, true> in pinned")
     o.append("// registers: see tools/gen_fwd_asm.py for the structure, the register map and the preconditions the caller checks.")
     o.append("template <class Job, class Args>")
-    o.append(f"__device__ __forceinline__ void fwd_asm_run_{c.name}(Job& j, const Args& a, int lane, int hap_begin, int hap_end) {{")
+    if wide:
+        o.append("// WIDE variant: the read spans the n_waves wavefronts of a workgroup (lanes 64 * wave .. 64 * wave + 63 of one systolic")
+        o.append("// array); the bottom row of a wavefront's lane 63 reaches the next wavefront's lane 0 through a ring in LDS, a step")
+        o.append("// counter per wavefront (flags) keeps producer and consumer within the ring of each other.  Every wavefront runs the")
+        o.append("// same number of steps: 64 * wave steps of pre-roll first (its lanes' skew), pre-roll words after its last separator.")
+        o.append(f"__device__ __forceinline__ void fwd_asm_run_wide_{c.name}(Job& j, const Args& a, int lane, int hap_begin, int hap_end, int wave, int n_waves,")
+        o.append("                                                       uint32_t ring_in, uint32_t ring_out, uint32_t flag_own, uint32_t flag_prod, uint32_t flag_cons) {")
+        o.append("  wave = __builtin_amdgcn_readfirstlane(wave); n_waves = __builtin_amdgcn_readfirstlane(n_waves);")
+    else:
+        o.append(f"__device__ __forceinline__ void fwd_asm_run_{c.name}(Job& j, const Args& a, int lane, int hap_begin, int hap_end) {{")
     o.append("  hap_begin = __builtin_amdgcn_readfirstlane(hap_begin); hap_end = __builtin_amdgcn_readfirstlane(hap_end);")
     o.append("  ConstI32* hap_pos = (ConstI32*)a.hap_pos;")
     o.append("  ConstI32* hap_len = (ConstI32*)a.hap_len;")
@@ -401,11 +509,28 @@ def driver(c, o):
     o.append("  uint64_t src = (uint64_t)(uintptr_t)(a.stream + sb);")
     o.append("  uint32_t sent_old = kEntNoEmit, orig_old = 0;")
     o.append("  int t = 0, fast_from = skew;   // the fill: the most skewed lane meets its first column at t = skew")
-    o.append("  for (int k = hap_begin; k <= hap_end; k++) {")
+    if wide:
+        o.append("  const int delay = 64 * wave;")
+        o.append("  const int t_end = 64 * (n_waves - 1) + (hap_pos[hap_end - 1] - sb + hap_len[hap_end - 1]) + 64;   // steps of every wavefront")
+        o.append("  const uint32_t has_in = wave > 0 ? 1u : 0u, has_out = wave + 1 < n_waves ? 1u : 0u;")
+        o.append("  uint32_t st = 0;")
+        o.append("  const uint64_t stream0 = src;")
+        o.append("  for (int k = hap_begin - 1; k <= hap_end; k++) {")
+    else:
+        o.append("  for (int k = hap_begin; k <= hap_end; k++) {")
     o.append("    int n_pre, n_blk, n_post, has_sep;")
     o.append("    uint32_t sent = kEntNoEmit, orig = 0;")
     o.append(f"    {T} y0n = 0;")
-    o.append("    if (k < hap_end) {")
+    if wide:
+        o.append("    if (k < hap_begin) {")
+        o.append("      // this wavefront's lanes start 64 * wave steps after the first wavefront's: pre-roll until then")
+        o.append("      if (delay == 0) continue;")
+        o.append("      n_pre = delay; n_blk = 0; n_post = 0; has_sep = 0;")
+        o.append("      src = (uint64_t)(uintptr_t)kPrerollWords;")
+        o.append("    } else if (k < hap_end) {")
+        o.append("      if (k == hap_begin) src = stream0;")
+    else:
+        o.append("    if (k < hap_end) {")
     o.append("      const int sep_at = hap_pos[k] - sb + hap_len[k];   // stream-relative position of this haplotype's separator")
     o.append("      n_pre = fast_from - t;                              // the window of the previous separator (the fill)")
     o.append("      if (n_pre < 0) n_pre = 0;")
@@ -421,7 +546,10 @@ def driver(c, o):
     o.append("      fast_from = sep_at + skew + 1;")
     o.append("    } else {")
     o.append("      // drain: the last separator travels down the array, nothing new enters")
-    o.append("      n_pre = skew; n_blk = 0; n_post = 0; has_sep = 0;")
+    if wide:
+        o.append("      n_pre = t_end - (delay + t); n_blk = 0; n_post = 0; has_sep = 0;")
+    else:
+        o.append("      n_pre = skew; n_blk = 0; n_post = 0; has_sep = 0;")
     o.append("      src = (uint64_t)(uintptr_t)kPrerollWords;")
     o.append("    }")
     o.append("    // (wave-uniform by construction; said explicitly so that they are SGPR operands in every kernel this is inlined into)")
@@ -440,13 +568,22 @@ def driver(c, o):
         o.append("    const uint32_t y0n_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(y0n));")
         y0in = "[y0n] \"s\"(y0n_b)"
     outs = ", ".join(f"\"+{hard(c, reg)}\"({name})" for _, reg, name in inout) + f", \"+{hard(c, c.ENT, 1)}\"(ent), " \
-        f"\"+{{s[{S_SRC}:{S_SRC + 1}]}}\"(src)"
+        f"\"+&{{s[{S_SRC}:{S_SRC + 1}]}}\"(src)"   # (early clobber: the program advances it while it still reads its scalar inputs)
     inp = ", ".join(f"\"{hard(c, reg)}\"({name})" for _, reg, name in consts) + ", " + extra_v + \
         ", [sent] \"s\"(sent), [orig] \"s\"(orig), [sent_old] \"s\"(sent_old), [orig_old] \"s\"(orig_old), [outmask] \"s\"(outmask), " \
         "[raw] \"s\"(raw), " + ("" if c.f64 else "[packed] \"s\"(packed), [minacc] \"s\"(minacc), ") + y0in + \
         ", [n_pre] \"s\"(n_pre), [n_blk] \"s\"(n_blk), [n_post] \"s\"(n_post), [has_sep] \"s\"(has_sep)"
-    prog = program(c)
-    emit_asm(o, prog, outs, inp, clobbers(c), "    ")
+    clob = clobbers(c)
+    if wide:
+        # early clobber: without it the compiler may keep an input of the same VALUE (orig = 0, n_blk = 0 in the pre-roll
+        # call, where st is 0 too) in the very register the program counts its steps in
+        outs += f", \"+&{{{S_T}}}\"(st)"
+        for nm in ("has_in", "has_out", "ring_in", "ring_out", "flag_own", "flag_prod", "flag_cons", "t_end"):
+            o.append(f"    const uint32_t {nm}_s = (uint32_t)__builtin_amdgcn_readfirstlane((int){nm});")
+            inp += f", [{nm}] \"s\"({nm}_s)"
+        clob = clob + [f"v{c.WADDR}", f"v{c.FV}", S_NEED]
+    prog = program(c, wide)
+    emit_asm(o, prog, outs, inp, clob, "    ")
     o.append("    sent_old = sent; orig_old = orig;")
     o.append("  }")
     o.append("}")
@@ -492,9 +629,9 @@ def main(path):
     o.append("namespace gklhip {")
     o.append("constexpr uint32_t kEntPreroll = 0xBFFFFFFFu;   // separator-type entry that no haplotype owns (fill and drain)")
     o.append("constexpr uint32_t kEntNoEmit = 0xBFFFFFFEu;    // separator \"in flight\" while there is none: matches no entry")
-    o.append("// the drain's entries: up to 63 steps of pre-roll words, read eight at a time")
-    o.append("__device__ const uint32_t kPrerollWords[72] = {")
-    for _ in range(9):
+    o.append("// the drain's entries (and a wide job's pre-roll and tail: up to 64 * 3 + 64 steps), read eight at a time")
+    o.append("__device__ const uint32_t kPrerollWords[264] = {")
+    for _ in range(33):
         o.append("    kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll,")
     o.append("};")
     o.append("typedef const int32_t __attribute__((address_space(4))) ConstI32;   // plan arrays: written by an earlier kernel, s_load here")
@@ -504,6 +641,7 @@ def main(path):
     stats = []
     for c in (Cfg("f32r8", False, 8), Cfg("f64r10", True, 10)):
         driver(c, o)
+        driver(c, o, wide=True)
         fb = fast_block(c, [f"s{S_E0 + u}" for u in range(U)])
         gs = general_step(c, "s72", 100)
         nv = lambda ins: sum(1 for i in ins if i.startswith("v_"))
