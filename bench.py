@@ -124,7 +124,7 @@ def _median_ms(fn, calls, warm):
     return float(np.median(ts)) * 1e3
 
 
-def host_call_record(native, batch, dev_index, calls=30, warm=15, max_threads=1):
+def host_call_record(native, batch, dev_index, calls=30, warm=15, max_threads=0):
     """One batch through gklhip_compute (what computeLikelihoodsNative calls after marshalling): host arrays in,
     host doubles out, H2D/D2H and the reference-exact host log10 included.  Latency of back-to-back single calls."""
     out = np.empty(batch.n_pairs)
@@ -527,7 +527,8 @@ def main():
                 eighth = whole.read_slice(0, whole.n_reads // 8)
                 res["small_batch"] = {"c1_100x10": host_call_record(native, c1, dev_index, calls=60, warm=30),
                                       f"eighth_{eighth.n_reads}x{eighth.n_haps}": host_call_record(native, eighth, dev_index, calls=20, warm=10),
-                                      "note": "through gklhip_compute, back-to-back single calls, median"}
+                                      "note": "through gklhip_compute (host threads: the library's own choice, max_threads = 0), back-to-back single calls, "
+                                              "median; calls of up to 2048 pairs run fp32 + policy + fp64 of a pair in one wavefront and one launch"}
                 # regions with many reads / haplotypes (4k..50k pairs): graded job lengths, two-launch per-pair policy
                 for mr, mh in ((400, 40), (250, 128), (1000, 50)):
                     mid = make_batch(a.workload, mr, mh, seed=DEFAULT_SEED)
@@ -566,6 +567,25 @@ def main():
                     res["small_batch"]["concurrent"] = conc
                 except Exception as e:
                     res["jni_path"] = {"error": repr(e)}
+                # reads longer than one wavefront's rows (fp32 > 511 bases, fp64 > 639): workgroups of 2-4 wavefronts per read
+                try:
+                    lb = make_batch(a.workload, 1000, 32, seed=DEFAULT_SEED, read_len=(600, 1000), hap_len=(900, 1100))
+                    dlb = native.DeviceBatch.upload(lb, dev)
+                    lout = torch.empty(lb.n_pairs, dtype=torch.float64, device=dev)
+                    with native.PairHmmContext(device=dev_index, record_events=1) as lc:
+                        def long_call():
+                            lc.compute_device(dlb, lout)
+                            torch.cuda.synchronize(dev)
+                        lms = _median_ms(long_call, 5, 2)
+                        lst = lc.stats()
+                    res["long_reads"] = {"workload": "1000 reads of 600-1000 bases x 32 haplotypes of 900-1100", "ms_per_call": round(lms, 3),
+                                         "gcups": round(lb.cells / lms / 1e6, 1), "fp32_kernel_ms": round(lst["ms_fwd_main"], 3),
+                                         "fp32_kernel_gcups": round(lb.cells / lst["ms_fwd_main"] / 1e6, 1),
+                                         "fp64_pass_ms": round(lst["ms_fwd_fallback"], 3),
+                                         "fallback_fraction": round(lst["n_fallback"] / lb.n_pairs, 4),
+                                         "note": "long reads mostly underflow in fp32 (2^120 scaling), so the fp64 pass dominates the call"}
+                except Exception as e:
+                    res["long_reads"] = {"error": repr(e)}
                 # the same shape without fallback pairs (one real active region)
                 reg = make_batch("region", a.reads, a.haps, seed=DEFAULT_SEED)
                 dreg = native.DeviceBatch.upload(reg, dev)
