@@ -162,3 +162,14 @@ def test_pdhmm_reference_batch_size_formula():
     assert native.pdhmm_available_memory_mb(1) == 1 and native.pdhmm_available_memory_mb(0) == 0
     assert 0 < native.pdhmm_available_memory_mb(10**9) < 10**9   # more than any host has free
     assert f(10**6, 151, 300, 10**12) == 10**6 * 1024 * 1024 // per
+
+
+def test_generated_asm_header_is_what_its_generator_writes(tmp_path):
+    """gkl_amd/csrc/pairhmm_fwd_asm.h (the whole-job asm programs of the forward kernels) is generator output kept in the
+    tree so that the build needs no Python: it must be exactly what tools/gen_fwd_asm.py writes today."""
+    import subprocess
+    import sys
+    out = tmp_path / "pairhmm_fwd_asm.h"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_fwd_asm.py"), str(out)], check=True, capture_output=True)
+    assert out.read_bytes() == open(os.path.join(ROOT, "gkl_amd", "csrc", "pairhmm_fwd_asm.h"), "rb").read(), \
+        "regenerate: python tools/gen_fwd_asm.py"
