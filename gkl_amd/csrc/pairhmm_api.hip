@@ -301,6 +301,9 @@ constexpr int kRplF64 = GKL_RPL_F64;
 #define GKL_RPL_F64_JOBS 10
 #endif
 constexpr int kRplF64Jobs = GKL_RPL_F64_JOBS;
+// The wide long-read kernel (several wavefronts of a workgroup per read) runs fp64 at 8 rows per lane: 16 KB of prior planes
+// per wavefront instead of 20 -- four / three / two workgroups per CU at two / three / four wavefronts each instead of three / two / one.
+constexpr int kRplF64Wide = 8;
 constexpr size_t kSmallBatchBytes = 1 << 20;  // host-buffer calls up to this size send their inputs inside the plan block
 constexpr int64_t kDirectPairs = 65536;        // calls up to this many pairs: policy + fp64 recomputation of one pair per wavefront (host calls of 24k / 38k / 50k pairs: 0.64 / 0.74 / 0.96 ms against 0.81 / 0.82 / 1.09 through the planned fp64 pass; equal at 80k)
 constexpr int64_t kTwoStepFrom = 2048;         // ... from this many pairs in two launches: policy + list of the failing pairs, then their recomputation (10k / 16k / 32k pairs: 0.37 / 0.45-0.48 / 0.72-0.84 ms against 0.43 / 0.49-0.54 / 0.76-0.97 in one)
@@ -671,7 +674,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       la.jobs = reinterpret_cast<const FwdJob*>(dp + L.long_jobs);
       la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
       la.job_next = c->counters.as<int32_t>() + 7;
-      launch_long_jobs<double, kRplF64Jobs, kRplF64>(la, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s);
+      launch_long_jobs<double, kRplF64Wide, kRplF64>(la, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
@@ -821,7 +824,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       ld.jobs = c->jobs_long.as<FwdJob>();
       ld.job_count = cnts + 8;
       ld.job_next = cnts + 9;
-      launch_long_jobs<double, kRplF64Jobs, kRplF64>(ld, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s);
+      launch_long_jobs<double, kRplF64Wide, kRplF64>(ld, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
     // (log10 of the recomputed pairs / host-buffer calls: their packed words)

@@ -226,7 +226,8 @@ struct WaveJob {
   // fp32, 8 rows per lane, the AVX-512 object's FMA pattern (the default arithmetic): the unrolled loop is the generated asm block
   static constexpr bool kAsmFast = GKLHIP_FAST_ASM && sizeof(T) == 4 && RPL == 8 && FMA;
   // fp64, 10 rows per lane (the packed recomputation pass and the all-fp64 mode), same arithmetic: whole jobs in asm
-  static constexpr bool kAsm64 = GKLHIP_FAST_ASM && sizeof(T) == 8 && RPL == 10 && FMA;
+  // (and 8: the wide long-read kernel, whose workgroups hold several wavefronts' prior tables)
+  static constexpr bool kAsm64 = GKLHIP_FAST_ASM && sizeof(T) == 8 && (RPL == 10 || RPL == 8) && FMA;
   static_assert(RPL % kPerVec == 0, "RPL must fill whole 16-byte vectors");
   using Vec = T __attribute__((ext_vector_type(kPerVec)));
 
@@ -543,8 +544,9 @@ struct WaveJob {
         }
       }
       if (whole) {
-        if constexpr (kAsm64) fwd_asm_run_f64r10(*this, a, lane, hap_begin, hap_end);
-        else                  fwd_asm_run_f32r8(*this, a, lane, hap_begin, hap_end);
+        if constexpr (kAsm64 && RPL == 10) fwd_asm_run_f64r10(*this, a, lane, hap_begin, hap_end);
+        else if constexpr (kAsm64)         fwd_asm_run_f64r8(*this, a, lane, hap_begin, hap_end);
+        else                               fwd_asm_run_f32r8(*this, a, lane, hap_begin, hap_end);
         return;
       }
     }
@@ -1005,8 +1007,9 @@ __global__ __launch_bounds__(64 * kWideWaves) void pairhmm_fwd_wide_kernel(FwdAr
       const uint32_t ring_out = wave + 1 < kWideWaves ? (uint32_t)(uintptr_t)rings[wave < kWideWaves - 1 ? wave : 0] : 0u;
       const uint32_t f_own = (uint32_t)(uintptr_t)&flags[wave], f_prod = (uint32_t)(uintptr_t)&flags[wave > 0 ? wave - 1 : 0],
                      f_cons = (uint32_t)(uintptr_t)&flags[wave + 1 < kWideWaves ? wave + 1 : wave];
-      if constexpr (Job::kAsm64) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
-      else                       fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+      if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+      else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+      else                                    fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
     }
   }
 }

@@ -2,6 +2,7 @@
 """Generates gkl_amd/csrc/pairhmm_fwd_asm.h: whole-job asm drivers of the forward recurrence,
   fwd_asm_run_f32r8   fp32, 8 rows per lane   (pairhmm_fwd_stream_kernel<float, 8, true> and the other float/8/FMA kernels)
   fwd_asm_run_f64r10  fp64, 10 rows per lane  (pairhmm_fwd_jobs_kernel<double, 10, true>, ..stream_kernel<double, 10, true>)
+  fwd_asm_run_f64r8   fp64, 8 rows per lane   (the wide long-read kernel: 16 KB of prior planes per wavefront instead of 20)
 Arithmetic (operation order, FMA pattern) = WaveJob::advance, i.e. the reference's compute_full_prob with the gcc-11
 contraction of the AVX-512 object (reference avx-pairhmm-template.h:208-223); tests/test_gpu_parity.py pins the asm drivers
 to the C++ steps and to the oracle bit for bit.
@@ -69,24 +70,28 @@ class Cfg:
             self.last = 123
             self.codes, self.planes, self.plane_stride, self.code_shift = 5, 2, 1024, 11
         else:
-            b = 16
+            b, W2 = 16, 2 * R                                # ten-row map: v16..v240; eight rows: v16..v200
             self.M = lambda s: b + 2 * s
-            self.X = lambda s: b + 20 + 2 * s
-            self.YA = lambda s: b + 40 + 2 * s
-            self.PMM = lambda s: b + 60 + 2 * s
-            self.GAPM = lambda s: b + 80 + 2 * s
-            self.PMX = lambda s: b + 100 + 2 * s
-            self.PXX = lambda s: b + 120 + 2 * s
-            self.PMY = lambda s: b + 140 + 2 * s
-            self.PR = lambda s: b + 160 + 2 * s            # v176..v195: five ds_read_b128
-            self.YB = lambda s: b + 180 + 2 * (s % 4)      # v196..v203: four rotating product temporaries
-            self.RS = [(204, 206, 208), (210, 212, 214)]
-            self.SM, self.SX = 216, 218
-            (self.ENT, self.EAB, self.LMASK, self.DIRECT, self.NDIRECT, self.LOFF, self.ADDR, self.NSEP) = 220, 221, 222, 223, 224, 225, 226, 227
-            self.VAL, self.OUTIDX, self.PADSLOT, self.Y0N, self.A, self.P, self.KREG = 228, 230, 231, 232, 234, 236, 238
-            self.WADDR, self.FV = 239, 240
-            self.last = 240
-            self.codes, self.planes, self.plane_stride, self.code_shift = 4, 5, 1024, None   # code * 5120 via KREG
+            self.X = lambda s: b + W2 + 2 * s
+            self.YA = lambda s: b + 2 * W2 + 2 * s
+            self.PMM = lambda s: b + 3 * W2 + 2 * s
+            self.GAPM = lambda s: b + 4 * W2 + 2 * s
+            self.PMX = lambda s: b + 5 * W2 + 2 * s
+            self.PXX = lambda s: b + 6 * W2 + 2 * s
+            self.PMY = lambda s: b + 7 * W2 + 2 * s
+            self.PR = lambda s: b + 8 * W2 + 2 * s         # R / 2 ds_read_b128 (v176..v195 at ten rows: 4-aligned)
+            t0 = b + 9 * W2
+            self.YB = lambda s: t0 + 2 * (s % 4)             # four rotating product temporaries
+            r0 = t0 + 8
+            self.RS = [(r0, r0 + 2, r0 + 4), (r0 + 6, r0 + 8, r0 + 10)]
+            self.SM, self.SX = r0 + 12, r0 + 14
+            m0 = r0 + 16
+            (self.ENT, self.EAB, self.LMASK, self.DIRECT, self.NDIRECT, self.LOFF, self.ADDR, self.NSEP) = [m0 + i for i in range(8)]
+            self.VAL, self.OUTIDX, self.PADSLOT, self.Y0N, self.A, self.P, self.KREG = m0 + 8, m0 + 10, m0 + 11, m0 + 12, m0 + 14, m0 + 16, m0 + 18
+            self.WADDR, self.FV = m0 + 19, m0 + 20
+            self.last = m0 + 20
+            assert self.PR(0) % 4 == 0 and self.last < 256
+            self.codes, self.planes, self.plane_stride, self.code_shift = 4, R // 2, 1024, None   # code * kRowBytes via KREG
 
     # operand text
     def v(self, n):
@@ -639,7 +644,7 @@ def main(path):
     o.append("typedef const double __attribute__((address_space(4))) ConstF64;")
     legacy_fast(o)
     stats = []
-    for c in (Cfg("f32r8", False, 8), Cfg("f64r10", True, 10)):
+    for c in (Cfg("f32r8", False, 8), Cfg("f64r10", True, 10), Cfg("f64r8", True, 8)):
         driver(c, o)
         driver(c, o, wide=True)
         fb = fast_block(c, [f"s{S_E0 + u}" for u in range(U)])
