@@ -380,7 +380,17 @@ void launch_pair_policy(const FwdArgs<double>& d, const PairPolicyArgs& q, int r
 }
 
 // tiny calls: fp32 + policy + fp64 of ONE pair per wavefront in one launch (pairhmm_pair_fused_kernel)
-void launch_pair_fused(const FwdArgs<float>& f, const FwdArgs<double>& d, const PairPolicyArgs& q, int fma, int64_t n_pairs, hipStream_t s) {
+// `alone`: nothing else is on the device -- the fp64 recomputation of every pair runs beside its fp32 recurrence
+// (pairhmm_pair_spec_kernel) and the call takes max(fp32, fp64) instead of fp32 + fp64
+void launch_pair_fused(const FwdArgs<float>& f, const FwdArgs<double>& d, const PairPolicyArgs& q, int fma, int64_t n_pairs, hipStream_t s,
+                       bool alone = false) {
+  static const bool spec_env = [] { const char* v = getenv("GKLHIP_SPECULATE_FP64"); return !v || atoi(v) != 0; }();
+  if (alone && spec_env) {
+    const dim3 grid((unsigned)n_pairs), block(128);
+    if (fma) hipLaunchKernelGGL((pairhmm_pair_spec_kernel<kRplF64, true>), grid, block, 0, s, f, d, q);
+    else     hipLaunchKernelGGL((pairhmm_pair_spec_kernel<kRplF64, false>), grid, block, 0, s, f, d, q);
+    return;
+  }
   const dim3 grid((unsigned)n_pairs), block(64);
   if (fma) hipLaunchKernelGGL((pairhmm_pair_fused_kernel<kRplF64, true>), grid, block, 0, s, f, d, q);
   else     hipLaunchKernelGGL((pairhmm_pair_fused_kernel<kRplF64, false>), grid, block, 0, s, f, d, q);
@@ -525,7 +535,8 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   const bool per_pair_call = !use_double && n_pairs <= kDirectPairs && n_long64 == 0 && plan.max_read_len <= kLanes * kRplF64 - 1;
   // ... the tiny ones (one GATK active region) with the fp32 recurrence in the same wavefront and launch as the policy
   static const bool fused_env = [] { const char* v = getenv("GKLHIP_FUSED_PAIRS"); return !v || atoi(v) != 0; }();
-  const bool fused_call = per_pair_call && fused_env && n_pairs <= kTwoStepFrom && n_long_main == 0 && c->cfg.rows_per_lane == 0;
+  static const int64_t fused_max = [] { const char* v = getenv("GKLHIP_FUSED_MAX_PAIRS"); return v ? atoll(v) : (long long)kTwoStepFrom; }();
+  const bool fused_call = per_pair_call && fused_env && n_pairs <= fused_max && n_long_main == 0 && c->cfg.rows_per_lane == 0;
   const bool deferred_launch = defer && pull && inline_host && c->cfg.record_events == 0 && per_pair_call && n_long_main == 0 &&
                                finalize_mode == kModePacked && plan.n_chunks > 0 && n_pairs <= kTwoStepFrom;
   const unsigned char* hs_dev = nullptr;  // the staging block as the device sees it
@@ -746,7 +757,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       }
       if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
       if (fused_call) {
-        launch_pair_fused(a, d, q, fma, n_pairs, s);
+        launch_pair_fused(a, d, q, fma, n_pairs, s, g_host_calls_in_flight.load(std::memory_order_relaxed) <= 1);
       } else if (n_pairs > kTwoStepFrom) {
         if ((rc = c->fail_order.reserve((size_t)n_pairs * 4))) return rc;
         launch_pair_policy_two_step(d, q, rows, fma, n_pairs, c->fail_order.as<int32_t>(), s);
@@ -1001,10 +1012,10 @@ struct SmallCombiner {
   std::atomic<int64_t> ns_stage{0}, ns_run{0}, ns_finalize{0};  // per call, outside the lock
   static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-  int launch_single(const SmallCall& k, hipStream_t s) {
+  int launch_single(const SmallCall& k, hipStream_t s, bool alone) {
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)k.prep_grid), dim3(kPrepBlock), 0, s, k.prep);
     if (k.fused) {
-      launch_pair_fused(k.f, k.d, k.q, k.fma, k.n_pairs, s);
+      launch_pair_fused(k.f, k.d, k.q, k.fma, k.n_pairs, s, alone);
     } else {
       launch_main_f32(k.f, k.rpl_main, k.fma, k.main_blocks, s);
       launch_pair_policy(k.d, k.q, k.rows, k.fma, k.n_pairs, s);
@@ -1069,13 +1080,14 @@ struct SmallCombiner {
       while (slot[si].busy) si++;
       Slot& sl = slot[si];
       sl.busy = true;
+      const bool alone = flights == 0 && queue.empty() && n == 1;   // no other small call on the device or waiting for it
       flights++;
       n_launch_sets++;
       if (n > 1) n_combined += n;
       int rc = GKLHIP_OK;
       if (n > 1 && !sl.stream) rc = fail(GKLHIP_ERR_HIP, "no stream for combined small calls");
       l.unlock();
-      if (rc == GKLHIP_OK) rc = n == 1 ? launch_single(mine.call, own_stream) : launch_multi(batch, n, mine.call.fma, sl);
+      if (rc == GKLHIP_OK) rc = n == 1 ? launch_single(mine.call, own_stream, alone) : launch_multi(batch, n, mine.call.fma, sl);
       const std::string err = rc == GKLHIP_OK ? std::string() : g_err;
       const int64_t t_launched = now_ns();
       // a launch that failed part-way may have left kernels on the stream that still read the calls' staging blocks and

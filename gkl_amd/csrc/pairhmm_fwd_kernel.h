@@ -224,10 +224,10 @@ struct WaveJob {
   static constexpr int kCodes = sizeof(T) == 8 ? 4 : 5;
   static constexpr int kLdsBytes = kCodes * kRowBytes;  // idle columns are handled in step_any
   // fp32, 8 rows per lane, the AVX-512 object's FMA pattern (the default arithmetic): the unrolled loop is the generated asm block
-  static constexpr bool kAsmFast = GKLHIP_FAST_ASM && sizeof(T) == 4 && RPL == 8 && FMA;
+  static constexpr bool kAsmFast = GKLHIP_FAST_ASM && sizeof(T) == 4 && (RPL == 8 || RPL == 4 || RPL == 2) && FMA;
   // fp64, 10 rows per lane (the packed recomputation pass and the all-fp64 mode), same arithmetic: whole jobs in asm
   // (and 8: the wide long-read kernel, whose workgroups hold several wavefronts' prior tables)
-  static constexpr bool kAsm64 = GKLHIP_FAST_ASM && sizeof(T) == 8 && (RPL == 10 || RPL == 8) && FMA;
+  static constexpr bool kAsm64 = GKLHIP_FAST_ASM && sizeof(T) == 8 && (RPL == 10 || RPL == 8 || RPL == 6 || RPL == 4 || RPL == 2) && FMA;
   static_assert(RPL % kPerVec == 0, "RPL must fill whole 16-byte vectors");
   using Vec = T __attribute__((ext_vector_type(kPerVec)));
 
@@ -544,9 +544,14 @@ struct WaveJob {
         }
       }
       if (whole) {
-        if constexpr (kAsm64 && RPL == 10) fwd_asm_run_f64r10(*this, a, lane, hap_begin, hap_end);
-        else if constexpr (kAsm64)         fwd_asm_run_f64r8(*this, a, lane, hap_begin, hap_end);
-        else                               fwd_asm_run_f32r8(*this, a, lane, hap_begin, hap_end);
+        if constexpr (kAsm64 && RPL == 10)     fwd_asm_run_f64r10(*this, a, lane, hap_begin, hap_end);
+        else if constexpr (kAsm64 && RPL == 8) fwd_asm_run_f64r8(*this, a, lane, hap_begin, hap_end);
+        else if constexpr (kAsm64 && RPL == 6) fwd_asm_run_f64r6(*this, a, lane, hap_begin, hap_end);
+        else if constexpr (kAsm64 && RPL == 4) fwd_asm_run_f64r4(*this, a, lane, hap_begin, hap_end);
+        else if constexpr (kAsm64)             fwd_asm_run_f64r2(*this, a, lane, hap_begin, hap_end);
+        else if constexpr (RPL == 8)           fwd_asm_run_f32r8(*this, a, lane, hap_begin, hap_end);
+        else if constexpr (RPL == 4)           fwd_asm_run_f32r4(*this, a, lane, hap_begin, hap_end);
+        else                                   fwd_asm_run_f32r2(*this, a, lane, hap_begin, hap_end);
         return;
       }
     }
@@ -562,7 +567,7 @@ struct WaveJob {
       if (kCodes == 4 && a.hap_has_n[k]) fast_from = sep_at;  // an 'N' somewhere in it: general steps throughout
       const int slow_end = fast_from < sep_at ? fast_from : sep_at;
       run_any(a, sp, t, slow_end, lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
-      if constexpr (kAsmFast) {
+      if constexpr (kAsmFast && RPL == 8) {
         fwd_fast_asm_f32r8(*this, sp, t, sep_at, lane);
       } else {
         for (; t + U <= sep_at; t += U) {
@@ -753,14 +758,14 @@ template <int RPL, bool FMA>
 __device__ __forceinline__ void pair_policy_recompute(const FwdArgs<double>& a, const PairPolicyArgs& q, int64_t p, int r, int R, int k,
                                                       unsigned char* lds) {
   using Job = WaveJob<double, RPL, FMA>;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   LaneSlot slot;
   slot.read = lane < (R + RPL) / RPL ? r : -1;
   slot.block = lane;
   Job job;
   job.lds = lds;
   job.setup(a, lane, slot);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // (the table is this wavefront's own: LDS operations of a wavefront execute in order)
   job.run(a, lane, k, k + 1);
   if (job.out_read >= 0) {  // the lane that stored the pair's sum
     const double sum = a.raw[p];
@@ -796,14 +801,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
 template <int RPL, bool FMA>
 __device__ __forceinline__ float pair_fp32_alone(const FwdArgs<float>& f, int64_t p, int r, int R, int k, unsigned char* lds) {
   using Job = WaveJob<float, RPL, FMA>;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   LaneSlot slot;
   slot.read = lane < (R + RPL) / RPL ? r : -1;
   slot.block = lane;
   Job job;
   job.lds = lds;
   job.setup(f, lane, slot);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // (the table is this wavefront's own: LDS operations of a wavefront execute in order)
   job.run(f, lane, k, k + 1);
   // the lane holding the read's last row stored the sum (emit_result / the asm program): it reads its own store back
   // (past the vector cache: another wavefront of this CU may have pulled the line in before the store) and broadcasts it
@@ -850,6 +855,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
                                                                                                        PairPolicyArgs q) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[PairFusedLds<MAXR64, FMA>::bytes];
   pair_fused_block<MAXR64, FMA>(f, d, q, (int64_t)blockIdx.x, lds);
+}
+
+// The same with the fp64 recomputation SPECULATED: two wavefronts per pair, one runs the fp32 recurrence, the other the
+// fp64 one at the same time; the policy then picks.  Five times the fp64 work a call needs (16 % of the pairs fail) --
+// chosen only when the call is alone on the device (one HaplotypeCaller thread sending region after region: the usual
+// way GATK runs), where nothing else wants those SIMDs and the call's latency is its longest dependent chain:
+// max(fp32, fp64) instead of fp32 + fp64.
+template <int MAXR64, bool FMA>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void pairhmm_pair_spec_kernel(FwdArgs<float> f, FwdArgs<double> d,
+                                                                                                        PairPolicyArgs q) {
+  constexpr int kL2 = WaveJob<double, 2, FMA>::kLdsBytes, kL4 = WaveJob<double, 4, FMA>::kLdsBytes, kLR = WaveJob<double, MAXR64, FMA>::kLdsBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds32[WaveJob<float, 8, FMA>::kLdsBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char lds64[kLR > kL4 ? (kLR > kL2 ? kLR : kL2) : (kL4 > kL2 ? kL4 : kL2)];
+  __shared__ float s_v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t p = blockIdx.x;
+  const int r = (int)(p / f.b.n_haps), k = q.hap_sidx[(int)(p - (int64_t)r * f.b.n_haps)];
+  const int R = (int)(f.b.read_off[r + 1] - f.b.read_off[r]);
+  if (wave == 0) {
+    float v;
+    if (R <= 2 * kLanes - 1)      v = pair_fp32_alone<2, FMA>(f, p, r, R, k, lds32);
+    else if (R <= 4 * kLanes - 1) v = pair_fp32_alone<4, FMA>(f, p, r, R, k, lds32);
+    else                          v = pair_fp32_alone<8, FMA>(f, p, r, R, k, lds32);
+    if (lane == 0) s_v = v;
+  } else {
+    PairPolicyArgs none = q;
+    none.mode = -1;   // the raw fp64 sum only: whether it is wanted is decided below
+    if (MAXR64 > 2 && R <= 2 * kLanes - 1)      pair_policy_recompute<2, FMA>(d, none, p, r, R, k, lds64);
+    else if (MAXR64 > 4 && R <= 4 * kLanes - 1) pair_policy_recompute<4, FMA>(d, none, p, r, R, k, lds64);
+    else                                        pair_policy_recompute<MAXR64, FMA>(d, none, p, r, R, k, lds64);
+    __threadfence();  // the sum (a global store of this wavefront's last lane) before the barrier
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = s_v;
+    const bool fails = v < 1e-28f;  // NaN compares false and stays fp32, like the reference (IntelPairHmm.cc:159)
+    q.used64[p] = fails ? 1 : 0;
+    if (fails) {
+      atomicAdd(q.count, 1);
+      const double sum = __hip_atomic_load(d.raw + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q.mode == kModePackedWords) reinterpret_cast<uint64_t*>(q.out)[p] = packed_word(sum);
+      else if (q.mode >= 0) q.out[p] = log10(sum) - q.log10_init_d;
+    } else if (q.mode == kModePackedWords) reinterpret_cast<uint64_t*>(q.out)[p] = kPackedF32Tag | (uint64_t)__float_as_uint(v);
+    else if (q.mode == 1) q.out[p] = log10((double)v) - q.log10_init32_as_f64;                        // GKLHIP_FINALIZE_DEVICE_F64
+    else if (q.mode == 2) q.out[p] = (double)((float)log10((double)v) - q.log10_init_f);             // GKLHIP_FINALIZE_DEVICE_REF32
+  }
 }
 
 // Mid-size calls (thousands of pairs): the same per-pair policy in two launches.  One block per PAIR leaves the
@@ -983,7 +1034,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void pairhmm_fwd_wide_kernel(FwdAr
     const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
     const int n_blocks = (R + RPL) / RPL;
     const int n_waves = (n_blocks + kLanes - 1) / kLanes;
-    bool wide = (Job::kAsmFast || Job::kAsm64) && a.asm_general && n_waves <= kWideWaves && a.hap_len[j.hap_begin] > kLanes - 1;
+    bool wide = (Job::kAsmFast || Job::kAsm64) && RPL >= 8 && a.asm_general && n_waves <= kWideWaves && a.hap_len[j.hap_begin] > kLanes - 1;
     if (Job::kAsm64 && wide) {
       if (a.packed_out) wide = false;
       bool any_n = false;
@@ -995,7 +1046,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void pairhmm_fwd_wide_kernel(FwdAr
       continue;
     }
     if (wave >= n_waves) continue;
-    if constexpr (Job::kAsmFast || Job::kAsm64) {
+    if constexpr ((Job::kAsmFast || Job::kAsm64) && RPL >= 8) {
       LaneSlot slot;
       slot.block = wave * kLanes + lane;
       slot.read = slot.block < n_blocks ? r : -1;

@@ -3,6 +3,7 @@
   fwd_asm_run_f32r8   fp32, 8 rows per lane   (pairhmm_fwd_stream_kernel<float, 8, true> and the other float/8/FMA kernels)
   fwd_asm_run_f64r10  fp64, 10 rows per lane  (pairhmm_fwd_jobs_kernel<double, 10, true>, ..stream_kernel<double, 10, true>)
   fwd_asm_run_f64r8   fp64, 8 rows per lane   (the wide long-read kernel: 16 KB of prior planes per wavefront instead of 20)
+  fwd_asm_run_f32r4 / f32r2 / f64r6 / f64r4 / f64r2   the narrow kernels of small and mid-size calls
 Arithmetic (operation order, FMA pattern) = WaveJob::advance, i.e. the reference's compute_full_prob with the gcc-11
 contraction of the AVX-512 object (reference avx-pairhmm-template.h:208-223); tests/test_gpu_parity.py pins the asm drivers
 to the C++ steps and to the oracle bit for bit.
@@ -44,6 +45,7 @@ S_SRC = 88         # s[88:89]: the stream pointer (operand src, pinned there)
 S_T, S_NEED = "s90", "s91"   # wide variant: steps this wavefront has completed (operand st, pinned there); scratch
 S_CLOB = [f"s{i}" for i in range(72, 88)]
 RING = 64          # wide variant: slots of a hand-off ring
+OOB_PLANE = 512    # fp32 general step: a prior "plane" beyond the CU's 160 KB of LDS whatever the plane size (512 x 512 B = 256 KB)
 
 
 class Cfg:
@@ -68,9 +70,17 @@ class Cfg:
             self.KREG = None
             self.WADDR, self.FV = 122, 123      # wide variant: ring address, flag value
             self.last = 123
-            self.codes, self.planes, self.plane_stride, self.code_shift = 5, 2, 1024, 11
+            # prior table [code][plane][lane][min(R, 4) floats] (WaveJob::kVecBytes, kPlanes, kRowBytes): 2 rows per lane read
+            # one ds_read_b64 per step, 4 rows one ds_read_b128, 8 rows two
+            assert R in (2, 4, 8)
+            self.vec_bytes = 8 if R == 2 else 16
+            self.planes = 2 if R == 8 else 1
+            self.plane_stride = 64 * self.vec_bytes
+            self.code_shift = {2: 9, 4: 10, 8: 11}[R]   # log2(kRowBytes)
+            self.codes = 5
         else:
-            b, W2 = 16, 2 * R                                # ten-row map: v16..v240; eight rows: v16..v200
+            b, W2 = (8 if R == 6 else 16), 2 * R              # ten-row map: v16..v240; eight rows: v16..v204; six: v8..v160 (three
+                                                             # wavefronts per SIMD in the one-pair-per-wavefront kernels)
             self.M = lambda s: b + 2 * s
             self.X = lambda s: b + W2 + 2 * s
             self.YA = lambda s: b + 2 * W2 + 2 * s
@@ -92,6 +102,7 @@ class Cfg:
             self.last = m0 + 20
             assert self.PR(0) % 4 == 0 and self.last < 256
             self.codes, self.planes, self.plane_stride, self.code_shift = 4, R // 2, 1024, None   # code * kRowBytes via KREG
+            self.vec_bytes = 16
 
     # operand text
     def v(self, n):
@@ -132,7 +143,10 @@ def prior_loads(c, code_reg):
     for pl in range(c.planes):
         d = c.PR(0) + 4 * pl
         off = f" offset:{pl * c.plane_stride}" if pl else ""
-        o.append(f"ds_read_b128 v[{d}:{d + 3}], v{c.ADDR}{off}")
+        if c.vec_bytes == 8:
+            o.append(f"ds_read_b64 v[{d}:{d + 1}], v{c.ADDR}{off}")
+        else:
+            o.append(f"ds_read_b128 v[{d}:{d + 3}], v{c.ADDR}{off}")
     return o
 
 
@@ -305,10 +319,10 @@ def general_step(c, e, lab, wide=False):
     if c.f64:
         o.append(f"v_and_b32 v{c.VAL}, v{c.ENT}, v{c.NSEP}") # base code (plane 0 for separator-type entries: any valid address)
     else:
-        # base code; 31 for separator-type entries: plane 31 starts 62 KB into a 10 KB allocation, and a DS read beyond the
-        # workgroup's allocation returns 0 (ISA manuals since GCN3; tools/ubench_lds_oob.hip checks it on this chip) --
+        # base code; OOB_PLANE for separator-type entries: that plane starts beyond the CU's whole LDS, and a DS read beyond
+        # the workgroup's allocation returns 0 (ISA manuals since GCN3; tools/ubench_lds_oob.hip checks it on this chip) --
         # the zero prior the column needs, without touching the eight products afterwards
-        o.append(f"v_min_u32 v{c.VAL}, 31, v{c.ENT}")
+        o.append(f"v_min_u32 v{c.VAL}, {OOB_PLANE}, v{c.ENT}")
     o += prior_loads(c, c.VAL)
     o += recurrence(c, c.YA, c.YA, d, r, True)
     o.append(f"{fp(c, 'add')} {c.v(c.SX)}, {c.v(c.SX)}, {c.v(c.X(R - 1))}")
@@ -497,7 +511,7 @@ def driver(c, o, wide=False):
     inout, consts = decls(c, o)
     o.append("  uint32_t ent = kEntPreroll;")
     o.append("  const uint32_t lmask = j.lmask, direct = j.direct, ndirect = ~j.direct;")
-    o.append("  const uint32_t loff = (uint32_t)(uintptr_t)j.lds + (uint32_t)lane * 16u;")
+    o.append("  const uint32_t loff = (uint32_t)(uintptr_t)j.lds + (uint32_t)lane * (uint32_t)Job::kVecBytes;")
     o.append("  const uint32_t outidx = j.out_read >= 0 ? (uint32_t)j.out_read * (uint32_t)a.b.n_haps : 0u;")
     o.append("  const int32_t padslot = j.padb_slot;")
     extra_v = ", ".join(f"\"{hard(c, r, 1)}\"({n})" for r, n in ((c.LMASK, "lmask"), (c.DIRECT, "direct"), (c.NDIRECT, "ndirect"),
@@ -644,9 +658,13 @@ def main(path):
     o.append("typedef const double __attribute__((address_space(4))) ConstF64;")
     legacy_fast(o)
     stats = []
-    for c in (Cfg("f32r8", False, 8), Cfg("f64r10", True, 10), Cfg("f64r8", True, 8)):
+    for c, wide in ((Cfg("f32r8", False, 8), True), (Cfg("f64r10", True, 10), True), (Cfg("f64r8", True, 8), True),
+                    # the narrow kernels of small and mid-size calls (one pair or a few reads per wavefront)
+                    (Cfg("f32r4", False, 4), False), (Cfg("f32r2", False, 2), False),
+                    (Cfg("f64r6", True, 6), False), (Cfg("f64r4", True, 4), False), (Cfg("f64r2", True, 2), False)):
         driver(c, o)
-        driver(c, o, wide=True)
+        if wide:
+            driver(c, o, wide=True)
         fb = fast_block(c, [f"s{S_E0 + u}" for u in range(U)])
         gs = general_step(c, "s72", 100)
         nv = lambda ins: sum(1 for i in ins if i.startswith("v_"))
