@@ -94,3 +94,26 @@ def test_a_lone_caller_is_not_combined(oracle):
         assert np.array_equal(bits(c.compute(b)), bits(want))
         assert c.stats()["ms_total_device"] > 0
     assert native.small_call_counts(0)[0] == 5
+
+
+@pytest.mark.gpu
+def test_speculated_fp64_beside_fp32_for_a_lone_tiny_call(oracle, monkeypatch):
+    """GKLHIP_SPECULATE_FP64=1: a tiny call that is alone on the device runs two wavefronts per pair (fp32 and fp64 at the
+    same time, pairhmm_pair_spec_kernel) and lets the policy pick; same bits, same flags, on batches with failing pairs,
+    without any, with N / odd bytes and with reads of every rows-per-lane class."""
+    from gkl_amd import native
+    from gkl_amd.synth import make_batch, random_batch
+    monkeypatch.setenv("GKLHIP_SPECULATE_FP64", "1")
+    rng = np.random.RandomState(12)
+    batches = [make_batch("hc", 100, 10, seed=3), make_batch("region", 80, 12, seed=4),
+               random_batch(rng, 40, 7, read_len=(1, 380), hap_len=(1, 500), alphabet=b"ACGTNacgtRY"),
+               random_batch(rng, 30, 20, read_len=(130, 383), hap_len=(400, 600), related=False)]
+    with native.PairHmmContext() as c:
+        for b in batches:
+            for _ in range(2):
+                out = c.compute(b)
+                r32, r64, u = c.raw(b.n_pairs)
+                oo, o32, o64, ou = oracle.batch(b, want_raw=True, n_threads=8)
+                assert np.array_equal(u, ou)
+                assert np.array_equal(r64[u == 1].view(np.uint64), o64[ou == 1].view(np.uint64))
+                assert out.tobytes() == oo.tobytes()
