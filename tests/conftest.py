@@ -52,3 +52,10 @@ _FILE_ORDER = [
 def pytest_collection_modifyitems(config, items):
     rank = {name: i for i, name in enumerate(_FILE_ORDER)}
     items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), len(_FILE_ORDER) - 1.5))  # stable within a file
+    # A device-side wait that never ends (the long-read kernel's wavefronts wait for each other's step counters, the
+    # combiner's callers for each other's launches) must fail ONE test, not hold the GPU box until its time limit:
+    # every GPU test gets a wall-clock limit when pytest-timeout is installed (it is in this image).
+    if config.pluginmanager.hasplugin("timeout"):
+        for it in items:
+            if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
+                it.add_marker(pytest.mark.timeout(900, method="thread"))
