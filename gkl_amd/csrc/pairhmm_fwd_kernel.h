@@ -132,7 +132,7 @@ __device__ __forceinline__ void emit_result(const FwdArgs<T>& a, int64_t idx, T 
   if (a.packed_out) {
     if (sizeof(T) == 4) {
       const float f = (float)v;
-      // the policy's test (IntelPairHmm.cc:159; NaN compares false and stays fp32); policy_plan_kernel applies the same one
+      // the policy's test (IntelPairHmm.cc:159; NaN compares false and stays fp32); plan_policy_kernel applies the same one
       a.packed_out[idx] = f < 1e-28f ? 0ull : (kPackedF32Tag | (uint64_t)__float_as_uint(f));
     } else if (!a.packed_only_flagged || a.packed_only_flagged[idx]) {
       a.packed_out[idx] = packed_word((double)v);
