@@ -106,3 +106,22 @@ def test_deferred_event_ring_reports_each_pipelined_call(native, oracle):
     with native.PairHmmContext(record_events=1) as c:
         with pytest.raises(IllegalArgumentException):
             c.step_times(0)
+
+
+def test_lds_reads_beyond_the_allocation_return_zero(tmp_path):
+    """The fp32 general step of the asm programs takes a separator lane's prior rows from beyond the workgroup's LDS
+    allocation and relies on the hardware returning 0 there (ISA manuals since GCN3).  tools/ubench_lds_oob.hip asks the
+    chip: four address classes, 262 144 reads each, with neighbouring workgroups' allocations right behind ours."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "lds_oob")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-o", exe, os.path.join(root, "tools", "ubench_lds_oob.hip")],
+                   check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+    lines = [ln for ln in out.splitlines() if ln.startswith("address class")]
+    assert len(lines) == 4 and all(" 0 non-zero" in ln for ln in lines), out
