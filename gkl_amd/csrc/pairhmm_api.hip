@@ -382,8 +382,8 @@ void launch_pair_policy(const FwdArgs<double>& d, const PairPolicyArgs& q, int r
 // tiny calls: fp32 + policy + fp64 of ONE pair per wavefront in one launch (pairhmm_pair_fused_kernel)
 // `alone`: nothing else is on the device -- the fp64 recomputation of every pair runs beside its fp32 recurrence
 // (pairhmm_pair_spec_kernel) and the call takes max(fp32, fp64) instead of fp32 + fp64
-void launch_pair_fused(const FwdArgs<float>& f, const FwdArgs<double>& d, const PairPolicyArgs& q, int fma, int64_t n_pairs, hipStream_t s,
-                       bool alone = false) {
+void launch_pair_fused(const FwdArgs<float>& f, const FwdArgs<double>& d, const PairPolicyArgs& q, int rows, int fma, int64_t n_pairs,
+                       hipStream_t s, bool alone = false) {
   // Opt-in (GKLHIP_SPECULATE_FP64=1; read per call): it pays when a good share of the pairs fails the policy (100 x 10 with
   // 16 % failing: 0.151 -> 0.130 ms per call) and costs when none does (0.100 -> 0.130: the fp64 wavefront of a pair takes
   // twice as long as its fp32 one) -- and real active regions are mostly of the second kind.
@@ -395,6 +395,11 @@ void launch_pair_fused(const FwdArgs<float>& f, const FwdArgs<double>& d, const 
     return;
   }
   const dim3 grid((unsigned)n_pairs), block(64);
+  if (rows <= 4) {   // every read of the call has at most 255 bases: the four-wavefronts-per-SIMD variant
+    if (fma) hipLaunchKernelGGL((pairhmm_pair_fused_kernel<4, true>), grid, block, 0, s, f, d, q);
+    else     hipLaunchKernelGGL((pairhmm_pair_fused_kernel<4, false>), grid, block, 0, s, f, d, q);
+    return;
+  }
   if (fma) hipLaunchKernelGGL((pairhmm_pair_fused_kernel<kRplF64, true>), grid, block, 0, s, f, d, q);
   else     hipLaunchKernelGGL((pairhmm_pair_fused_kernel<kRplF64, false>), grid, block, 0, s, f, d, q);
 }
@@ -760,7 +765,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       }
       if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
       if (fused_call) {
-        launch_pair_fused(a, d, q, fma, n_pairs, s, g_host_calls_in_flight.load(std::memory_order_relaxed) <= 1);
+        launch_pair_fused(a, d, q, rows, fma, n_pairs, s, g_host_calls_in_flight.load(std::memory_order_relaxed) <= 1);
       } else if (n_pairs > kTwoStepFrom) {
         if ((rc = c->fail_order.reserve((size_t)n_pairs * 4))) return rc;
         launch_pair_policy_two_step(d, q, rows, fma, n_pairs, c->fail_order.as<int32_t>(), s);
@@ -1010,6 +1015,8 @@ struct SmallCombiner {
   Slot slot[kFlightSlots];
   int flights = 0;
   int max_flights = 3;
+  int min_batch = 0;               // 0: by load (see run())
+  int64_t batch_wait_ns = 50000;
   int64_t n_calls = 0, n_combined = 0, n_launch_sets = 0;  // diagnostics (gklhip_small_call_counts)
   int64_t ns_queued = 0, ns_launch = 0, ns_sync = 0;
   std::atomic<int64_t> ns_stage{0}, ns_run{0}, ns_finalize{0};  // per call, outside the lock
@@ -1018,7 +1025,7 @@ struct SmallCombiner {
   int launch_single(const SmallCall& k, hipStream_t s, bool alone) {
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)k.prep_grid), dim3(kPrepBlock), 0, s, k.prep);
     if (k.fused) {
-      launch_pair_fused(k.f, k.d, k.q, k.fma, k.n_pairs, s, alone);
+      launch_pair_fused(k.f, k.d, k.q, k.rows, k.fma, k.n_pairs, s, alone);
     } else {
       launch_main_f32(k.f, k.rpl_main, k.fma, k.main_blocks, s);
       launch_pair_policy(k.d, k.q, k.rows, k.fma, k.n_pairs, s);
@@ -1038,8 +1045,13 @@ struct SmallCombiner {
     }
     hipLaunchKernelGGL(prep_multi_kernel, dim3((unsigned)mp.begin[n]), dim3(kPrepBlock), 0, sl.stream, mp);
     if (batch[0]->sl->call.fused) {  // (every call of a set is of one kind: the leader only takes calls like its own)
-      if (fma) hipLaunchKernelGGL((pair_fused_multi_kernel<true, kRplF64>), dim3((unsigned)mq.begin[n]), dim3(64), 0, sl.stream, mq);
-      else     hipLaunchKernelGGL((pair_fused_multi_kernel<false, kRplF64>), dim3((unsigned)mq.begin[n]), dim3(64), 0, sl.stream, mq);
+      bool narrow = true;   // reads of at most 255 bases in every call of the set: the four-wavefronts-per-SIMD variant
+      for (int i = 0; i < n; i++) narrow = narrow && batch[i]->sl->call.rows <= 4;
+      const dim3 grid((unsigned)mq.begin[n]), block(64);
+      if (narrow && fma)  hipLaunchKernelGGL((pair_fused_multi_kernel<true, 4>), grid, block, 0, sl.stream, mq);
+      else if (narrow)    hipLaunchKernelGGL((pair_fused_multi_kernel<false, 4>), grid, block, 0, sl.stream, mq);
+      else if (fma)       hipLaunchKernelGGL((pair_fused_multi_kernel<true, kRplF64>), grid, block, 0, sl.stream, mq);
+      else                hipLaunchKernelGGL((pair_fused_multi_kernel<false, kRplF64>), grid, block, 0, sl.stream, mq);
     } else if (fma) {
       hipLaunchKernelGGL((fwd_stream_multi_kernel<true, kRplF32>), dim3((unsigned)mf.begin[n]), dim3(64), 0, sl.stream, mf);
       hipLaunchKernelGGL((pair_policy_multi_kernel<true, kRplF64>), dim3((unsigned)mq.begin[n]), dim3(64), 0, sl.stream, mq);
@@ -1062,6 +1074,19 @@ struct SmallCombiner {
     queue.push_back(&t);
     while (t.state == 0 || t.state == 4) {
       if (t.state == 4 || flights >= max_flights) { cv.wait(l); continue; }
+      // Under load (other sets are in the air) a set is worth more the more calls it carries -- its kernels take as long
+      // as their slowest pair whatever their size -- so a would-be leader that finds fewer than `min_batch` calls waiting
+      // gives the others `batch_wait_ns` to arrive (GKL_HIP_COMBINE_MIN / GKL_HIP_COMBINE_WAIT_US; 1 / 0 = lead at once).
+      // The number to wait for follows the load: a quarter of the host calls inside the library right now, at most 4
+      // (16 callers: 4, 8: 2, up to 7: none -- with few callers the wait only adds latency; measured with 50 us: 16 callers
+      // 1.42 -> 2.14 TCUPS, while a fixed minimum of 4 cost 4 callers 0.90 -> 0.71).
+      {
+        const int want = min_batch > 0 ? min_batch : std::min(4, g_host_calls_in_flight.load(std::memory_order_relaxed) / 4);
+        if (flights > 0 && (int)queue.size() < want && now_ns() - t_in < batch_wait_ns) {
+          cv.wait_for(l, std::chrono::microseconds(5));
+          continue;
+        }
+      }
       // lead: this call first, then the waiting calls of the same arithmetic mode
       const int64_t t_lead = now_ns();
       ns_queued += t_lead - t_in;
@@ -1150,6 +1175,8 @@ SmallCombiner* small_combiner(int device) {
     }
     if (have_dev) (void)hipSetDevice(prev);
     if (const char* v = getenv("GKL_HIP_COMBINE_FLIGHTS")) all[(size_t)device]->max_flights = std::max(1, std::min(kFlightSlots, atoi(v)));
+    if (const char* v = getenv("GKL_HIP_COMBINE_MIN")) all[(size_t)device]->min_batch = std::max(0, std::min(kMultiMax, atoi(v)));
+    if (const char* v = getenv("GKL_HIP_COMBINE_WAIT_US")) all[(size_t)device]->batch_wait_ns = (int64_t)std::max(0, atoi(v)) * 1000;
   }
   return all[(size_t)device];
 }

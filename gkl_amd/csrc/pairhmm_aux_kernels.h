@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pa
 }
 
 template <bool FMA, int kRplF64>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pair_fused_multi_kernel(MultiArgs m) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRplF64 <= 4 ? 4 : 3))) void pair_fused_multi_kernel(MultiArgs m) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[PairFusedLds<kRplF64, FMA>::bytes];
   const int r = multi_find(m, (int)blockIdx.x);
   const SmallCall* c = m.call[r];

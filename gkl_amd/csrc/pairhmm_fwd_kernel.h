@@ -826,10 +826,13 @@ __device__ __forceinline__ void pair_fused_block(const FwdArgs<float>& f, const 
   const int lane = threadIdx.x;
   const int r = (int)(p / f.b.n_haps), k = q.hap_sidx[(int)(p - (int64_t)r * f.b.n_haps)];
   const int R = (int)(f.b.read_off[r + 1] - f.b.read_off[r]);
+  // (MAXR64 <= 4: the variant for calls whose reads have at most 255 bases -- no 8-row fp32 and no 6-row fp64 code in the
+  //  kernel, 128 VGPRs, four wavefronts per SIMD instead of three: these wavefronts wait on their own dependent chains,
+  //  so a SIMD's throughput under many concurrent callers is the number of wavefronts it holds)
   float v;
-  if (R <= 2 * kLanes - 1)      v = pair_fp32_alone<2, FMA>(f, p, r, R, k, lds);
-  else if (R <= 4 * kLanes - 1) v = pair_fp32_alone<4, FMA>(f, p, r, R, k, lds);
-  else                          v = pair_fp32_alone<8, FMA>(f, p, r, R, k, lds);
+  if (R <= 2 * kLanes - 1)                     v = pair_fp32_alone<2, FMA>(f, p, r, R, k, lds);
+  else if (MAXR64 <= 4 || R <= 4 * kLanes - 1) v = pair_fp32_alone<4, FMA>(f, p, r, R, k, lds);
+  else                                         v = pair_fp32_alone<8, FMA>(f, p, r, R, k, lds);
   const bool fails = v < 1e-28f;  // NaN compares false and stays fp32, like the reference (IntelPairHmm.cc:159)
   if (lane == 0) {
     q.used64[p] = fails ? 1 : 0;
@@ -846,12 +849,12 @@ __device__ __forceinline__ void pair_fused_block(const FwdArgs<float>& f, const 
 }
 template <int MAXR64, bool FMA>
 struct PairFusedLds {
-  static constexpr int a = WaveJob<float, 8, FMA>::kLdsBytes, b = WaveJob<double, 2, FMA>::kLdsBytes, c = WaveJob<double, 4, FMA>::kLdsBytes,
-                       d = WaveJob<double, MAXR64, FMA>::kLdsBytes;
+  static constexpr int a = WaveJob<float, (MAXR64 <= 4 ? 4 : 8), FMA>::kLdsBytes, b = WaveJob<double, 2, FMA>::kLdsBytes,
+                       c = WaveJob<double, 4, FMA>::kLdsBytes, d = WaveJob<double, MAXR64, FMA>::kLdsBytes;
   static constexpr int ab = a > b ? a : b, cd = c > d ? c : d, bytes = ab > cd ? ab : cd;
 };
 template <int MAXR64, bool FMA>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void pairhmm_pair_fused_kernel(FwdArgs<float> f, FwdArgs<double> d,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MAXR64 <= 4 ? 4 : 3))) void pairhmm_pair_fused_kernel(FwdArgs<float> f, FwdArgs<double> d,
                                                                                                        PairPolicyArgs q) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[PairFusedLds<MAXR64, FMA>::bytes];
   pair_fused_block<MAXR64, FMA>(f, d, q, (int64_t)blockIdx.x, lds);

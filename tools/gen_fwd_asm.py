@@ -79,8 +79,9 @@ class Cfg:
             self.code_shift = {2: 9, 4: 10, 8: 11}[R]   # log2(kRowBytes)
             self.codes = 5
         else:
-            b, W2 = (8 if R == 6 else 16), 2 * R              # ten-row map: v16..v240; eight rows: v16..v204; six: v8..v160 (three
-                                                             # wavefronts per SIMD in the one-pair-per-wavefront kernels)
+            b, W2 = (8 if R <= 6 else 16), 2 * R              # ten-row map: v16..v240; eight rows: v16..v204; six: v8..v160 (three
+                                                             # wavefronts per SIMD in the one-pair-per-wavefront kernels), four:
+                                                             # v8..v124 (four per SIMD)
             self.M = lambda s: b + 2 * s
             self.X = lambda s: b + W2 + 2 * s
             self.YA = lambda s: b + 2 * W2 + 2 * s
