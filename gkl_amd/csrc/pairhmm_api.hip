@@ -404,9 +404,11 @@ void launch_pair_fused(const FwdArgs<float>& f, const FwdArgs<double>& d, const 
   else     hipLaunchKernelGGL((pairhmm_pair_fused_kernel<kRplF64, false>), grid, block, 0, s, f, d, q);
 }
 
-// The whole device-side pipeline on stream `s`: 5 launches in the policy mode (prep, fp32 forward, policy + planning
-// of the fp64 pass, fp64 forward over the job list, log10 of the recomputed pairs; + the log10 of the kept pairs on a
-// side stream in the device finalisation modes), no host synchronisation.  `db` holds host offsets and DEVICE byte
+// The whole device-side pipeline on stream `s`: 7 launches in the policy mode (prep, fp32 forward, the three launches of
+// policy + planning of the fp64 pass, fp64 forward over the job list, log10 / packed words of the recomputed pairs; + the
+// log10 of the kept pairs on a side stream in the device finalisation modes), 3-4 for calls of up to 65 536 pairs (prep,
+// fp32 forward, per-pair policy in one or two launches), 2 for up to 2048 (prep, the fused per-pair kernel); no host
+// synchronisation.  `db` holds host offsets and DEVICE byte
 // arrays -- or, with `inline_host`, HOST byte arrays that travel inside the plan block (small host-buffer calls: one
 // copy for plan and inputs).
 // `defer` (host-buffer calls on an idle context only): a call that takes the small-call path -- pulled plan block,
