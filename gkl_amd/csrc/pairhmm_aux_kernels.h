@@ -261,9 +261,9 @@ struct PlanArgs {
 // block: the one that arrives last, which then sees everything the other blocks wrote before arriving.
 __device__ __forceinline__ bool last_block_done(int32_t* arrivals) {
   __shared__ int32_t s_is_last;
-  __threadfence();  // release this thread's writes (agent scope: writes back the XCD's L2)
-  __syncthreads();
+  __syncthreads();  // every store of the block has reached this XCD's L2 (workgroup-scope release: vmcnt(0) before the barrier)
   if (threadIdx.x == 0) {
+    __threadfence();  // release at agent scope: ONE write-back of the L2 per block (1024 of them cost the policy launch ~20 us)
     const int32_t before = atomicAdd(arrivals, 1);
     s_is_last = before == (int32_t)gridDim.x - 1 ? 1 : 0;
     __threadfence();  // acquire the other blocks' writes (invalidates this CU's vector cache and the non-local L2 lines)
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kPlanBlock) void plan_policy_kernel(PlanArgs a) {
       if (mask) {
         // r-major pairs: the failing lanes of a wavefront usually belong to one read (n_haps >= 64) or a few
         const int leader = __builtin_ctzll(mask);
-        const int32_t read = fails ? (int32_t)(i / a.n_haps) : -1;
+        const int32_t read = fails ? (int32_t)((uint32_t)i / (uint32_t)a.n_haps) : -1;  // (pairs < 2^31: a 32-bit division, not the 64-bit one of `i / n_haps`)
         const int32_t lead_read = __shfl(read, leader, 64);
         const uint64_t same = __ballot(fails && read == lead_read);
         if (lane == leader) atomicAdd(a.fa.read_fail + lead_read, __builtin_popcountll(same));
