@@ -173,3 +173,37 @@ def test_generated_asm_header_is_what_its_generator_writes(tmp_path):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_fwd_asm.py"), str(out)], check=True, capture_output=True)
     assert out.read_bytes() == open(os.path.join(ROOT, "gkl_amd", "csrc", "pairhmm_fwd_asm.h"), "rb").read(), \
         "regenerate: python tools/gen_fwd_asm.py"
+
+
+def test_generated_fp32_programs_keep_the_bank_rule_and_their_registers():
+    """Static checks of the generated asm (no GPU): (1) the VGPR file of gfx950 has two banks, even and odd registers, and
+    a three-source fp32 op whose sources all sit in one bank issues at half rate (docs/NOTES.md, round 3) -- no v_fmac_f32 /
+    v_fma_f32 of the fp32 programs may be monochrome; (2) every register a program names lies inside its configuration's
+    map, i.e. below the VGPR budget its kernels are launched with (128 for fp32, 256 for fp64 at 8 / 10 rows, 168 / 128 for
+    the narrow fp64 ones)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_fwd_asm", os.path.join(ROOT, "tools", "gen_fwd_asm.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    budgets = {("f32", 8): 128, ("f32", 4): 128, ("f32", 2): 128, ("f64", 10): 256, ("f64", 8): 256, ("f64", 6): 168, ("f64", 4): 128,
+               ("f64", 2): 128}
+    for (kind, R), budget in budgets.items():
+        c = g.Cfg(f"{kind}r{R}", kind == "f64", R)
+        for wide in ((False, True) if R >= 8 else (False,)):
+            prog = g.program(c, wide)
+            regs = set()
+            for ins in prog:
+                for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", ins):
+                    if m.group(3) is not None:
+                        regs.add(int(m.group(3)))
+                    else:
+                        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                if kind == "f32" and (ins.startswith("v_fmac_f32 ") or ins.startswith("v_fma_f32 ")):
+                    ops = [int(x) for x in re.findall(r"\bv(\d+)\b", ins)]
+                    srcs = ops if ins.startswith("v_fmac_f32 ") else ops[1:]   # fmac reads its destination as the third source
+                    assert len({r % 2 for r in srcs}) == 2, f"monochrome three-source op in {c.name}: {ins}"
+            assert max(regs) < budget, (c.name, wide, max(regs), budget)
+            assert max(regs) <= c.last, (c.name, max(regs), c.last)
+            # labels are unique within the one asm statement
+            labels = [ins[:-1] for ins in prog if re.fullmatch(r"\d+:", ins)]
+            assert len(labels) == len(set(labels)), (c.name, "duplicate label")
