@@ -942,6 +942,26 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
   int rc = GKLHIP_OK;
   auto bail = [&](int status) { dev_done(c); return status; };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  {
+    // once per process and device: is this build's denormal mode the one the kernels (and the reference) assume?
+    static std::mutex mu;
+    static std::vector<int> checked;   // 0 unknown, 1 good, -1 bad
+    std::lock_guard<std::mutex> l(mu);
+    if ((int)checked.size() <= dev) checked.resize((size_t)dev + 1, 0);
+    if (checked[(size_t)dev] == 0) {
+      uint32_t* d_out = nullptr;
+      uint32_t h_out[2] = {1u, 1u};
+      if (hipMalloc(reinterpret_cast<void**>(&d_out), 8) != hipSuccess) return bail(fail(GKLHIP_ERR_OOM, "hipMalloc failed"));
+      float f_den; double d_den;
+      { const uint32_t fb = 1u; memcpy(&f_den, &fb, 4); const uint64_t db = 0x0000000100000001ull; memcpy(&d_den, &db, 8); }
+      hipLaunchKernelGGL(flush_selftest_kernel, dim3(1), dim3(1), 0, c->stream, d_out, f_den, d_den);
+      const bool ok = hipMemcpyAsync(h_out, d_out, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+      (void)hipFree(d_out);
+      checked[(size_t)dev] = ok && h_out[0] == 0u && h_out[1] == 0u ? 1 : -1;
+    }
+    if (checked[(size_t)dev] < 0)
+      return bail(fail(GKLHIP_ERR_HIP, "this library was built without the denormal-flush flags its kernels depend on (gkl_amd/csrc/Makefile: HIPFLAGS)"));
+  }
   if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
   for (int k = 0; k < 2; k++)
     if (hipEventCreateWithFlags(&c->stage_free_slot[k], hipEventDisableTiming) != hipSuccess ||

@@ -642,6 +642,20 @@ __global__ __launch_bounds__(kPlanBlock) void plan_jobs_kernel(PlanArgs a) {
 }
 #undef GKLHIP_PLAN_STAMP
 
+// ---- build self-test: the kernels of this library must run with fp32 AND fp64 denormals flushed (Makefile: -fgpu-flush-
+// denormals-to-zero, -fdenormal-fp-math=preserve-sign; MXCSR.FTZ in the reference).  The generated fp64 programs zero a
+// value by masking its high half and rely on the flush for the rest, so a library built without the flags must not start.
+// out[0] = the bits of (smallest fp32 denormal * 1), out[1] = the high word of (an fp64 denormal * 1): both 0 when flushed.
+__global__ void flush_selftest_kernel(uint32_t* out, float f, double d) {
+  float fm;
+  double dm;
+  // (real multiplies: the compiler folds x * 1 away)
+  asm volatile("v_mul_f32 %0, 1.0, %1" : "=v"(fm) : "v"(f));
+  asm volatile("v_mul_f64 %0, 1.0, %1" : "=v"(dm) : "v"(d));
+  out[0] = __float_as_uint(fm);
+  out[1] = (uint32_t)((uint64_t)__double_as_longlong(dm) >> 32) | (uint32_t)(uint64_t)__double_as_longlong(dm);
+}
+
 // ---- diagnostics: the VALU issue ceiling of the forward recurrence's instruction mix ----------------------------
 // Eight "cells" of 4 multiplies + 4 fused multiply-adds per loop iteration, operands in registers chosen so that no
 // three-source op has all sources in one VGPR bank (even / odd), four wavefronts per SIMD on every CU: what the chip
