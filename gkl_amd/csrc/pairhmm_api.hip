@@ -640,6 +640,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   b.read_off = reinterpret_cast<const int64_t*>(dp + L.read_off);
   b.n_reads = n_reads; b.n_haps = n_haps;
 
+  // XCD-aware grid of the streaming kernels (fwd_stream_block): a chunk's jobs all land on one XCD
+  static const bool xcd_env = [] { const char* v = getenv("GKLHIP_XCD_AWARE"); return !v || atoi(v) != 0; }();
+  const int chunk_stride = (xcd_env && plan.n_chunks >= 64) ? ((plan.n_chunks + 7) & ~7) : plan.n_chunks;
   auto fill_common = [&](auto& a) {
     a.b = b;
     a.stream = stream_grouped;
@@ -651,6 +654,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     a.n_groups = (int)plan.groups.size();
     a.chunk_lanes = c->lanes_main.as<LaneSlot>();
     a.n_chunks = plan.n_chunks;
+    a.chunk_stride = chunk_stride;
     a.jobs = c->jobs.as<FwdJob>();
     a.job_count = c->counters.as<int32_t>() + 2;
     a.job_next = c->counters.as<int32_t>() + 3;
@@ -667,7 +671,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   fa.log10_init32_as_f64 = std::log10(std::ldexp(1.0, 120));
   fa.log10_init_d = host_tables_f64().log10_initial;
 
-  const int n_main_blocks = plan.n_chunks * (int)plan.groups.size();
+  const int n_main_blocks = chunk_stride * (int)plan.groups.size();
   // persistent wavefronts of the striped long-read kernel: one per job up to two per SIMD (each owns two carry rows of
   // the longest stream group: ~110 KB)
   const int n_long_waves = (int)std::min<size_t>(2048, std::max<size_t>(512, std::max(long_jobs.size(), (size_t)n_long64 * plan.groups.size())));

@@ -99,6 +99,7 @@ struct FwdArgs {
   int32_t n_groups;
   const LaneSlot* chunk_lanes;  // [n_chunks * 64]
   int32_t n_chunks;
+  int32_t chunk_stride;  // blocks per haplotype group in the streaming kernels' grid (>= n_chunks, see fwd_stream_block)
   T* raw;  // [n_reads * n_haps], r-major, scaled likelihood sums
   // Host-buffer calls (reference-exact log10 on the host): the packed result word of a pair (packed_word below; fp32
   // pass: the tagged fp32 sum, or 0 = "pending" when the policy will send the pair to the fp64 pass) goes straight to
@@ -675,8 +676,13 @@ template <typename T, int RPL, bool FMA>
 __device__ __forceinline__ void fwd_stream_block(const FwdArgs<T>& a, int block, unsigned char* lds) {
   using Job = WaveJob<T, RPL, FMA>;
   const int lane = threadIdx.x;
-  const int g = block / a.n_chunks;  // group-major: the groups come in order of decreasing length
-  const int chunk = block - g * a.n_chunks;
+  // group-major: the groups come in order of decreasing length.  `chunk_stride` = n_chunks rounded up to a multiple of 8
+  // in big launches: workgroups go to the chip's 8 XCDs round-robin by index, so a chunk then meets all its haplotype
+  // groups on ONE XCD and its read rows (re-read by every job of the chunk) stay in that XCD's L2 instead of being
+  // fetched through all eight (the <= 7 blocks per group beyond n_chunks leave at once).
+  const int g = block / a.chunk_stride;
+  const int chunk = block - g * a.chunk_stride;
+  if (chunk >= a.n_chunks) return;
   const HapGroup grp = a.groups[g];
   Job job;
   job.lds = lds;

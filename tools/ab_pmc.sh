@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 CMDS="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras $EXTRA"
 for V in $VALS; do
   i=0
-  for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+  for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
              "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
     i=$((i+1))
     env $VAR=$V rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/v${V}_p$i -o pmc -- $CMDS > $OUT/v${V}_p$i.json 2> $OUT/v${V}_p$i.err
