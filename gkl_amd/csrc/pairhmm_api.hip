@@ -825,10 +825,13 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       const int pack_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kPlanBlocks, (max_windows + kPlanBlock / 64 - 1) / (kPlanBlock / 64)));
       const int jobs_grid = std::max(1, std::min(c->n_cus, blocks_env > 0 ? blocks_env : (int)std::min<int64_t>(kPlanBlocks, std::max<int64_t>(16, n_pairs / 8192))));
       hipLaunchKernelGGL(plan_policy_kernel, dim3((unsigned)policy_grid), dim3(kPlanBlock), 0, s, pa);
+      // The policy's flags and the kept pairs' words are final here: the log10 of the kept pairs (side stream below; the
+      // host's early pass in host-buffer calls) starts now and overlaps the two small planning launches -- behind them it
+      // would queue up against the fp64 pass, whose persistent wavefronts leave it no registers until they drain.
+      HIP_TRY(hipEventRecord(c->policy_done, s));
       hipLaunchKernelGGL(plan_pack_kernel, dim3((unsigned)pack_grid), dim3(kPlanBlock), 0, s, pa);
       hipLaunchKernelGGL(plan_jobs_kernel, dim3((unsigned)jobs_grid), dim3(kPlanBlock), 0, s, pa);
     }
-    HIP_TRY(hipEventRecord(c->policy_done, s));
     const bool side_finalize = finalize_mode == GKLHIP_FINALIZE_DEVICE_F64 || finalize_mode == GKLHIP_FINALIZE_DEVICE_REF32;
     if (side_finalize) {
       HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->policy_done, 0));
