@@ -522,9 +522,9 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const int carry_len = entry_stride;
   const int n_blocks = std::max(1, std::min(std::max(n_jobs, (int)n_tail), 256 * 8));
   if ((rc = c->entries.reserve(nh * (size_t)entry_stride * 4))) return rc;
-  if (n_tab_haps && (rc = c->entries_tab.reserve(nh * (size_t)entry_stride * 4))) return rc;
+  if (n_tab_haps && (rc = c->entries_tab.reserve(2 * nh * (size_t)entry_stride * 4))) return rc;   // + the next-special-column table
   if ((rc = c->sums.reserve(n * 8))) return rc;
-  if ((rc = c->misc.reserve(64))) return rc;
+  if ((rc = c->misc.reserve(256))) return rc;
   if ((rc = c->carry.reserve((size_t)n_blocks * 2 * (6 * (size_t)carry_len + 64) * 8))) return rc;
   const size_t o_jl = 0, o_jp = up((size_t)n_general * kLanes * sizeof(PlanLane)), o_jn = o_jp + up((size_t)n_general * 4),
                o_js = o_jn + up((size_t)n_general * 4), o_cl = o_js + up((size_t)n_general),
@@ -572,7 +572,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const int32_t n_striped_listed = cross ? n_general : (int32_t)n_striped;   // (lives, like the vectors, until the stream is drained below)
   std::vector<int32_t> full_first((size_t)n_striped_listed);
   for (int32_t k = 0; k < n_striped_listed; k++) full_first[(size_t)k] = k;
-  PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 64, s));
+  PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 256, s));
   PD_HIP_TRY(put(o_fj, full_first.data(), full_first.size() * 4));
   if (staged_jobs && staged_hi > 0) PD_HIP_TRY(hipMemcpyAsync(dj, hj, staged_hi, hipMemcpyHostToDevice, s));
   PD_HIP_TRY(hipMemcpyAsync(c->misc.as<int32_t>() + 5, &n_striped_listed, 4, hipMemcpyHostToDevice, s));
@@ -612,9 +612,13 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   a.hap_ncls = n_tab_haps ? dj + o_nc : nullptr;
   a.class_codes = reinterpret_cast<const uint32_t*>(dj + o_cc);
   a.entries_tab = c->entries_tab.as<uint32_t>();
+  a.next_special = n_tab_haps ? reinterpret_cast<int32_t*>(c->entries_tab.as<uint32_t>() + nh * (size_t)entry_stride) : nullptr;
   a.job_flags = dj + o_jf;
   a.full_jobs = reinterpret_cast<const int32_t*>(dj + o_fj);
   a.full_count = c->misc.as<int32_t>() + 5;
+#ifdef GKL_PD_PROF
+  a.prof = reinterpret_cast<unsigned long long*>(c->misc.as<char>() + 128);
+#endif
 
   hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)nh), dim3(kLanes), 0, s, a);   // one wavefront per haplotype item
   if (!cross && !chunk_used.empty()) {
@@ -684,6 +688,15 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const double ms_launched = ms_since(t_begin);
   PD_HIP_TRY(hipStreamSynchronize(s));
   PD_HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+#ifdef GKL_PD_PROF
+  {  // development build: where the table kernel's wavefronts spent their cycles (s_memtime)
+    unsigned long long pr[16];
+    PD_HIP_TRY(hipMemcpy(pr, c->misc.as<char>() + 128, sizeof pr, hipMemcpyDeviceToHost));
+    const double tot = (double)(pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[5]);
+    fprintf(stderr, "[pd prof] setup+table %.3f  asm runs %.3f (%llu steps)  plain x2 loop %.3f (%llu)  plain x1 loop %.3f (%llu)  general %.3f (%llu)  other %.3f  | jobs %llu, total %.3e ticks\n",
+            pr[0] / tot, pr[1] / tot, pr[8], pr[2] / tot, pr[9], pr[3] / tot, pr[10], pr[4] / tot, pr[11], pr[5] / tot, pr[12], tot);
+  }
+#endif
   if (timing)
     fprintf(stderr, "[gklhip] pdhmm call: uploads enqueued %.2f ms, jobs built %.2f, routed %.2f, launched %.2f, synchronised %.2f (kernels %.2f ms), %zu pairs\n",
             ms_uploads, ms_jobs, ms_routing, ms_launched, ms_since(t_begin), (double)c->last_ms, n);

@@ -116,6 +116,7 @@ struct PdArgs {
   const uint8_t* hap_ncls;
   const uint32_t* class_codes;  // [n_hap_items * 8]
   uint32_t* entries_tab;
+  int32_t* next_special;        // table haplotypes, per column j: the first special column >= j (INT32_MAX: none), same stride
   // listed jobs routed on the device: job_flags[j] != 0 (set by pdhmm_expand_kernel: some haplotype of the job has a base
   // outside ACGTN) or a striped job -> the full kernel's, everything else the hot kernel's; both launches walk the whole
   // list.  NULL: the launch takes every listed job (the tail launch).
@@ -125,6 +126,9 @@ struct PdArgs {
   // them costs a millisecond of contended atomics
   const int32_t* full_jobs;
   const int32_t* full_count;
+#ifdef GKL_PD_PROF
+  unsigned long long* prof;     // development build: cycle and step counters of the table kernel
+#endif
 };
 
 __device__ __forceinline__ int pd_read_of(const PdArgs& a, int p) { return a.cross_haps ? p / a.cross_haps : p; }
@@ -191,6 +195,25 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
     const int last = __shfl(incl, kLanes - 1, kLanes);
     if (last > carry) carry = last;
   }
+  // Table haplotypes: per column the next special column at or behind it (a suffix minimum, tiles back to front) -- the
+  // table kernel reads the length of a run of plain steps off it with one scalar load instead of balloting every step.
+  if (et) {
+    int32_t* ns = a.next_special + (int64_t)p * a.entry_stride;
+    int32_t behind = 0x7fffffff;
+    for (int base = H > 0 ? ((H - 1) / kLanes) * kLanes : -1; base >= 0; base -= kLanes) {
+      const int j = base + lane;
+      int32_t v = (j < H && (int32_t)et[j] < 0) ? j : 0x7fffffff;
+#pragma unroll
+      for (int dd = 1; dd < kLanes; dd <<= 1) {
+        const int32_t o = __shfl_down(v, dd, kLanes);
+        if (lane + dd < kLanes && o < v) v = o;
+      }
+      if (behind < v) v = behind;
+      if (j < H) ns[j] = v;
+      behind = __shfl(v, 0, kLanes);
+    }
+    for (int j = H + lane; j < a.entry_stride; j += kLanes) ns[j] = 0x7fffffff;
+  }
   // Scalar-engine rows >= 2: the columns up to and including the first flagged one are entered in the state the
   // previous row ENDED in (after the last column: DEL_END there -> AFTER_DEL, DEL_START as the last flag -> INSIDE_DEL,
   // else NORMAL); AFTER_DEL lasts one column, INSIDE_DEL until a flag, behind the first flag the rows agree.
@@ -249,6 +272,13 @@ __global__ __launch_bounds__(256) void pdhmm_collect_kernel(const uint8_t* job_f
   if (j < n_general && job_flags[j] && !job_striped[j]) full_jobs[atomicAdd(full_count, 1)] = j;
 }
 
+#ifndef GKL_PD_ASM
+#define GKL_PD_ASM 1
+#endif
+}  // namespace gklhip
+#include "pdhmm_plain_asm.h"   // generated (tools/gen_pdhmm_asm.py): pd_plain_run_asm
+namespace gklhip {
+
 // _mm256_max_pd / std::max on the values this recurrence produces (finite, non-negative, no -0): one v_max_f64.  Written
 // as asm because the compiler turns `x > y ? x : y` into a compare and two selects (three instructions, and the general
 // step has 32 of these merges), and fmax() into a canonicalising pair under the kernel's IEEE mode.
@@ -292,6 +322,9 @@ struct PdJob {
   int row1_slot;      // kSerial: the slot holding the read's FIRST row (the only row that starts in NORMAL), else -1
   bool has_non_acgt;  // kSerial: some real row's base is not A/C/G/T (any case)
   uint32_t tab_lane;  // kTab: LDS byte address of this lane's slot in class 0, plane 0
+#ifdef GKL_PD_PROF
+  unsigned long long* prof_out = nullptr;
+#endif
 
   // kTab: the lane's [class][row] priors into LDS (after setup(); `codes`: the haplotype's class match bits).
   // `lds_base`: the LDS byte address of the job's table.
@@ -619,6 +652,9 @@ struct PdJob {
 
   // a column is special when it is entered in state INSIDE_DEL / AFTER_DEL or carries DEL_END
   static __device__ __forceinline__ bool any_special(uint32_t e) {
+#ifdef GKL_PD_TIMING_NOSPECIAL
+    return false;
+#endif
     if (kTab) return __ballot((int32_t)e < 0) != 0;
     return __ballot((int)(e & kPdSpecial)) != 0;   // idle entries never carry the bit
   }
@@ -626,7 +662,11 @@ struct PdJob {
   // A packed job (no stripes): alternate between runs of plain steps and runs of general steps, each in its own
   // loop so that neither pays register shuffling for the other at every iteration.
   // `bytewise`: some lane's haplotype has a base outside ACGTN (uniform over the wavefront): every step compares bytes.
-  __device__ __forceinline__ void run_packed(const uint32_t* __restrict__ ep, int n_steps, bool bytewise) {
+  // `e0`, `block`, `top`, `H`, `ns` (table kernel only): the wavefront's entry pointer at column 0, the lane's row block,
+  // the highest row block of the chunk, the haplotype's length and its next-special-column table -- what the asm run of
+  // plain steps (pdhmm_plain_asm.h) needs.
+  __device__ __forceinline__ void run_packed(const uint32_t* __restrict__ ep, int n_steps, bool bytewise, const uint32_t* e0 = nullptr,
+                                             int block = 0, int top = 0, int H = 0, const int32_t* __restrict__ ns = nullptr) {
     fetch_above();
     if (!kHot && (kSerial || bytewise)) {
       uint32_t cur = ep[0];
@@ -644,12 +684,43 @@ struct PdJob {
     uint32_t cur = ep[0], n1 = ep[1], n2 = ep[2], n3 = ep[3];
     bool s0 = any_special(cur), s1 = any_special(n1), s2 = any_special(n2);
     int t = 0;
+#ifdef GKL_PD_PROF
+    unsigned long long pt = __builtin_readcyclecounter(), pc[5] = {0, 0, 0, 0, 0}, pn[4] = {0, 0, 0, 0};
+    int pt0 = 0;
+#define PD_PROF_MARK(k) { const unsigned long long now = __builtin_readcyclecounter(); pc[k] += now - pt; pt = now; if (k < 4) pn[k] += (unsigned long long)(t - pt0); pt0 = t; }
+#else
+#define PD_PROF_MARK(k)
+#endif
     while (t < n_steps) {
+      PD_PROF_MARK(4)
+      if constexpr (kTab && FMA && GKL_PD_ASM != 0) {
+        // Steps top .. H-1: every lane is inside its haplotype.  No special column in [t - top, t + 2] <=> the next
+        // special column at or behind t - top lies beyond t + 2; the run of plain steps ends two steps before it reaches
+        // the first lane (the lead-in of the general steps).
+        if (t >= top && t + 4 <= H && !(s0 || s1 || s2)) {
+#ifdef GKL_PD_TIMING_NOSPECIAL
+          const int32_t c = 0x7fffffff;
+#else
+          const int32_t c = ns[t - top];
+#endif
+          const int t_end = c - 2 < H ? c - 2 : H;
+          const int n4 = (t_end - t) >> 2;
+          if (n4 > 0) {
+            pd_plain_run_asm(*this, e0 - top + t, (uint32_t)(top - block) * 4u, n4);
+            t += 4 * n4;
+            cur = ep[t]; n1 = ep[t + 1]; n2 = ep[t + 2]; n3 = ep[t + 3];
+            s0 = any_special(cur); s1 = any_special(n1); s2 = any_special(n2);
+          }
+        }
+      }
+      PD_PROF_MARK(0)
+      // (with the asm run: the C++ plain loops stop where every lane has started, so that the asm run takes over from there)
+      const int lim = (kTab && FMA && GKL_PD_ASM != 0 && t < top && top + 4 <= H) ? top : n_steps;
       if (kTab && GKL_PD_TAB_UNROLL) {
         // plain steps two at a time, the d / r roles alternating (see step_plain); no way out between the two, or the
         // compiler restores the roles with copies on the main path
         bool s3 = any_special(n3);
-        while (t + 2 <= n_steps && !(s0 || s1 || s2 || s3)) {
+        while (t + 2 <= lim && !(s0 || s1 || s2 || s3)) {
           const uint32_t n4 = ep[t + 4], n5 = ep[t + 5];
           step_plain<false, true>(cur);
           step_plain<true, true>(n1);
@@ -658,7 +729,8 @@ struct PdJob {
           s0 = s2; s1 = s3; s2 = any_special(n2); s3 = any_special(n3);
         }
       }
-      while (t < n_steps && !(s0 || s1 || s2)) {
+      PD_PROF_MARK(1)
+      while (t < lim && !(s0 || s1 || s2)) {
         const uint32_t n4 = ep[t + 4];
         const bool s3 = any_special(n3);
         step_plain(cur);
@@ -666,6 +738,7 @@ struct PdJob {
         s0 = s1; s1 = s2; s2 = s3;
         t++;
       }
+      PD_PROF_MARK(2)
       while (t < n_steps && (s0 || s1 || s2)) {
         const uint32_t n4 = ep[t + 4];
         const bool s3 = any_special(n3);
@@ -674,7 +747,15 @@ struct PdJob {
         s0 = s1; s1 = s2; s2 = s3;
         t++;
       }
+      PD_PROF_MARK(3)
     }
+#ifdef GKL_PD_PROF
+    if (kTab && prof_out && (threadIdx.x == 0)) {
+      for (int k = 0; k < 4; k++) { atomicAdd(prof_out + 1 + k, pc[k]); atomicAdd(prof_out + 8 + k, pn[k]); }
+      atomicAdd(prof_out + 5, pc[4]);
+      atomicAdd(prof_out + 12, 1ull);
+    }
+#endif
   }
 
   // One stripe: `n_steps` steps over the loaded rows; ep[t] is this lane's column entry at step t
@@ -830,10 +911,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
     const int p = ri * a.cross_haps + hi;
     const int H = (int)a.hap_len[hi];
     const int n_blocks = ((int)a.read_len[ri] + Job::RPL) / Job::RPL;
+#ifdef GKL_PD_PROF
+    const unsigned long long pt_setup = __builtin_readcyclecounter();
+    job.prof_out = a.prof;
+#endif
     job.setup(a, p, sl.block, n_blocks, active, init_condition / (double)H);
     job.build_table(lds_base, lane, a.class_codes + (int64_t)hi * 8, (int)a.hap_ncls[hi]);
+#ifdef GKL_PD_PROF
+    if (lane == 0) atomicAdd(a.prof, __builtin_readcyclecounter() - pt_setup);
+#endif
     const uint32_t* e0 = a.entries_tab + (int64_t)hi * a.entry_stride;
-    job.run_packed(e0 + kLanes - sl.block, H + a.chunk_steps[chunk], false);
+    const int top = __builtin_amdgcn_readfirstlane(a.chunk_steps[chunk]);
+    job.run_packed(e0 + kLanes - sl.block, H + top, false, e0 + kLanes, sl.block, top, __builtin_amdgcn_readfirstlane(H),
+                   a.next_special + (int64_t)hi * a.entry_stride);
     if (job.holds_last) a.sums[p] = job.sum;
   }
 }

@@ -173,6 +173,11 @@ def test_generated_asm_header_is_what_its_generator_writes(tmp_path):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_fwd_asm.py"), str(out)], check=True, capture_output=True)
     assert out.read_bytes() == open(os.path.join(ROOT, "gkl_amd", "csrc", "pairhmm_fwd_asm.h"), "rb").read(), \
         "regenerate: python tools/gen_fwd_asm.py"
+    # ... and the PDHMM table kernel's plain-step run
+    out = tmp_path / "pdhmm_plain_asm.h"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_pdhmm_asm.py"), str(out)], check=True, capture_output=True)
+    assert out.read_bytes() == open(os.path.join(ROOT, "gkl_amd", "csrc", "pdhmm_plain_asm.h"), "rb").read(), \
+        "regenerate: python tools/gen_pdhmm_asm.py"
 
 
 def test_generated_fp32_programs_keep_the_bank_rule_and_their_registers():
