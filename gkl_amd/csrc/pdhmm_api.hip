@@ -505,6 +505,23 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     for (size_t h = 0; h < nh; h++) n_clean_haps += hap_odd[h] == 0;
     std::stable_partition(hap_order.begin(), hap_order.begin() + (ptrdiff_t)n_clean_haps, [&](int32_t h) { return hap_ncls[(size_t)h] != 0; });
     for (size_t h = 0; h < nh; h++) n_tab_haps += hap_ncls[h] != 0;
+    // The haplotypes of one region share their variant sites, hence their column classes: when the union of the table
+    // haplotypes' classes still fits the table, every one of them gets the union as its list -- a wavefront that takes
+    // several haplotypes with the same chunk of reads (tab_group_start below) then builds the table once.
+    {
+      uint32_t uni[kPdTabClasses + 1];
+      int n_uni = 0;
+      for (size_t h = 0; h < nh && n_uni <= kPdTabClasses; h++)
+        for (int k = 0; k < (int)hap_ncls[h] && n_uni <= kPdTabClasses; k++) {
+          const uint32_t code = class_codes[h * 8 + (size_t)k];
+          int at = 0;
+          while (at < n_uni && uni[at] != code) at++;
+          if (at == n_uni) { if (n_uni < kPdTabClasses) uni[n_uni] = code; n_uni++; }
+        }
+      if (n_uni <= kPdTabClasses)
+        for (size_t h = 0; h < nh; h++)
+          if (hap_ncls[h]) { for (int k = 0; k < n_uni; k++) class_codes[h * 8 + (size_t)k] = uni[k]; hap_ncls[h] = (uint8_t)n_uni; }
+    }
     c->last_routing[0] = (int32_t)n_tab_haps; c->last_routing[1] = (int32_t)(n_clean_haps - n_tab_haps); c->last_routing[2] = (int32_t)(nh - n_clean_haps);
   } else {
     c->last_routing[0] = c->last_routing[1] = c->last_routing[2] = 0;
@@ -515,6 +532,19 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   if (n_cross_jobs64 + (int64_t)job_pair.size() > 0x7fffffffLL) return pd_fail(GKLHIP_ERR_INVALID_ARG, "too many jobs");
   const int n_cross_jobs = (int)n_cross_jobs64;
   const int n_cross_tab = cross ? (int)((int64_t)n_chunks_cross * (int64_t)n_tab_haps) : 0;
+  // Table launch: a unit of work is (a group of consecutive table haplotypes, a chunk of reads) -- the wavefront sets the
+  // chunk's rows up once per group (a twelfth of a job's time otherwise).  Groups of up to four while there are at least
+  // eight units per wavefront, the shortest quarter of the haplotypes as singles (they run last and even the load out).
+  std::vector<int32_t> tab_group_start;
+  if (n_cross_tab > 0) {
+    const int64_t per_wave = (int64_t)n_cross_tab / (256 * 8);
+    const int group = (int)std::max<int64_t>(1, std::min<int64_t>(4, per_wave / 8));
+    const size_t grouped = group > 1 ? (n_tab_haps * 3 / 4) / (size_t)group * (size_t)group : 0;
+    for (size_t k = 0; k < grouped; k += (size_t)group) tab_group_start.push_back((int32_t)k);
+    for (size_t k = grouped; k < n_tab_haps; k++) tab_group_start.push_back((int32_t)k);
+    tab_group_start.push_back((int32_t)n_tab_haps);
+  }
+  const int n_tab_units = tab_group_start.empty() ? 0 : (int)((int64_t)n_chunks_cross * (int64_t)(tab_group_start.size() - 1));
   const int n_cross_hot = cross ? (int)((int64_t)n_chunks_cross * (int64_t)(n_clean_haps - n_tab_haps)) : 0;
   const int n_general = (int)job_pair.size();
   const int n_jobs = n_cross_jobs + n_general;
@@ -533,7 +563,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
                o_tp = o_tl + up(tail_lanes.size() * sizeof(PlanLane)), o_tn = o_tp + up(n_tail * 4), o_ts = o_tn + up(n_tail * 4),
                o_nc = o_ts + up(n_tail), o_cc = o_nc + up(hap_ncls.size()), o_jf = o_cc + up(class_codes.size() * 4),
                o_pc = o_jf + up((size_t)n_general), o_pl = o_pc + up(place_chunk.size() * 4), o_cu = o_pl + up(place_lane.size()),
-               o_fj = o_cu + up(chunk_used.size()), jobs_total = o_fj + up((size_t)n_general * 4);
+               o_fj = o_cu + up(chunk_used.size()), o_tg = o_fj + up((size_t)n_general * 4), jobs_total = o_tg + up(tab_group_start.size() * 4);
   if (up_th.th.joinable()) up_th.th.join();
   PD_HIP_TRY(up_th.err);
   if ((rc = c->jobs.reserve(jobs_total + 256))) return rc;
@@ -563,6 +593,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   PD_HIP_TRY(put(o_pc, place_chunk.data(), place_chunk.size() * 4));
   PD_HIP_TRY(put(o_pl, place_lane.data(), place_lane.size()));
   PD_HIP_TRY(put(o_cu, chunk_used.data(), chunk_used.size()));
+  PD_HIP_TRY(put(o_tg, tab_group_start.data(), tab_group_start.size() * 4));
   if (n_general > 0) {
     if (staged_jobs) { memset(hj + o_jf, 0, (size_t)n_general); staged_hi = std::max(staged_hi, o_jf + (size_t)n_general); }
     else PD_HIP_TRY(hipMemsetAsync(dj + o_jf, 0, (size_t)n_general, s));
@@ -616,6 +647,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   a.job_flags = dj + o_jf;
   a.full_jobs = reinterpret_cast<const int32_t*>(dj + o_fj);
   a.full_count = c->misc.as<int32_t>() + 5;
+  a.tab_group_start = reinterpret_cast<const int32_t*>(dj + o_tg);
 #ifdef GKL_PD_PROF
   a.prof = reinterpret_cast<unsigned long long*>(c->misc.as<char>() + 128);
 #endif
@@ -640,10 +672,10 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     // table launch: cross jobs over the haplotypes with few column classes
     if (n_cross_tab > 0) {
       PdArgs at = a;
-      at.n_cross_jobs = at.n_jobs = n_cross_tab;
+      at.n_cross_jobs = at.n_jobs = n_tab_units;   // (units: haplotype group x chunk)
       at.next = c->misc.as<int32_t>() + 4;
-      if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_tab_kernel<true>, dim3(std::min(n_cross_tab, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
-      else             hipLaunchKernelGGL(pdhmm_fwd_tab_kernel<false>, dim3(std::min(n_cross_tab, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
+      if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_tab_kernel<true>, dim3(std::min(n_tab_units, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
+      else             hipLaunchKernelGGL(pdhmm_fwd_tab_kernel<false>, dim3(std::min(n_tab_units, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
     }
     // hot launch: cross jobs over the other clean haplotypes + the listed jobs the device routes to it
     PdArgs ah = a;

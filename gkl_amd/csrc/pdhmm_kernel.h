@@ -117,6 +117,7 @@ struct PdArgs {
   const uint32_t* class_codes;  // [n_hap_items * 8]
   uint32_t* entries_tab;
   int32_t* next_special;        // table haplotypes, per column j: the first special column >= j (INT32_MAX: none), same stride
+  const int32_t* tab_group_start;  // table launch: group g = haplotypes hap_order[tab_group_start[g] .. tab_group_start[g + 1])
   // listed jobs routed on the device: job_flags[j] != 0 (set by pdhmm_expand_kernel: some haplotype of the job has a base
   // outside ACGTN) or a striped job -> the full kernel's, everything else the hot kernel's; both launches walk the whole
   // list.  NULL: the launch takes every listed job (the tail launch).
@@ -322,6 +323,7 @@ struct PdJob {
   int row1_slot;      // kSerial: the slot holding the read's FIRST row (the only row that starts in NORMAL), else -1
   bool has_non_acgt;  // kSerial: some real row's base is not A/C/G/T (any case)
   uint32_t tab_lane;  // kTab: LDS byte address of this lane's slot in class 0, plane 0
+  int pad_slot;       // the slot of the read's row 0 (the constant row above its first base), -1: not in this lane
 #ifdef GKL_PD_PROF
   unsigned long long* prof_out = nullptr;
 #endif
@@ -365,6 +367,7 @@ struct PdJob {
     holds_last = active && block == n_blocks - 1;
     status_flag = a.status;
     row1_slot = (active && first <= 0 && -first < RPL) ? -first : -1;
+    pad_slot = (active && first < 0 && -1 - first < RPL) ? -1 - first : -1;
     has_non_acgt = false;
     lmask = (active && block != 0) ? ~0u : 0u;
     asm("" : "+v"(lmask));  // opaque bit mask: recv_above stays v_and_b32_dpp (as a bool: DPP move + two selects per double)
@@ -400,6 +403,20 @@ struct PdJob {
         tii[s] = 1.0;  // row 0: deletion matrix constant INITIAL_CONDITION / haplen (the insertion matrix of a pad row only ever sees zeros, so the shared register is safe), everything else 0
         dm[s] = init;
       }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) d[k] = r[k] = 0.0;
+    sum = 0.0;
+    ent = kPdIdle;
+  }
+
+  // The same rows against the next haplotype: the matrices start over, the transitions and priors stay (table kernel:
+  // a wavefront takes a group of haplotypes with one chunk of reads).
+  __device__ __forceinline__ void restart(double init) {
+#pragma unroll
+    for (int s = 0; s < RPL; s++) {
+      mm[s] = im[s] = bmm[s] = bim[s] = bdm[s] = 0.0;
+      dm[s] = s == pad_slot ? init : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) d[k] = r[k] = 0.0;
@@ -899,32 +916,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
   Job job;
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
   for (;;) {
-    int j = 0;
-    if (lane == 0) j = atomicAdd(a.next, 1);
-    j = __builtin_amdgcn_readfirstlane(j);
-    if (j >= a.n_cross_jobs) break;
-    const int k = j / a.n_chunks_cross, chunk = j - k * a.n_chunks_cross;
-    const int hi = a.hap_order[k];
+    int u = 0;
+    if (lane == 0) u = atomicAdd(a.next, 1);
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (u >= a.n_cross_jobs) break;   // (units: haplotype group x chunk)
+    const int g = u / a.n_chunks_cross, chunk = u - g * a.n_chunks_cross;
+    const int k0 = a.tab_group_start[g], k1 = a.tab_group_start[g + 1];
     const LaneSlot sl = a.cross_lanes[(int64_t)chunk * kLanes + lane];
     const bool active = sl.read >= 0;
     const int ri = active ? sl.read : a.chunk_rep[chunk];
-    const int p = ri * a.cross_haps + hi;
-    const int H = (int)a.hap_len[hi];
     const int n_blocks = ((int)a.read_len[ri] + Job::RPL) / Job::RPL;
-#ifdef GKL_PD_PROF
-    const unsigned long long pt_setup = __builtin_readcyclecounter();
-    job.prof_out = a.prof;
-#endif
-    job.setup(a, p, sl.block, n_blocks, active, init_condition / (double)H);
-    job.build_table(lds_base, lane, a.class_codes + (int64_t)hi * 8, (int)a.hap_ncls[hi]);
-#ifdef GKL_PD_PROF
-    if (lane == 0) atomicAdd(a.prof, __builtin_readcyclecounter() - pt_setup);
-#endif
-    const uint32_t* e0 = a.entries_tab + (int64_t)hi * a.entry_stride;
     const int top = __builtin_amdgcn_readfirstlane(a.chunk_steps[chunk]);
-    job.run_packed(e0 + kLanes - sl.block, H + top, false, e0 + kLanes, sl.block, top, __builtin_amdgcn_readfirstlane(H),
-                   a.next_special + (int64_t)hi * a.entry_stride);
-    if (job.holds_last) a.sums[p] = job.sum;
+    int hi_built = -1;   // the haplotype whose classes the table in LDS was built for
+    for (int k = k0; k < k1; k++) {
+      const int hi = a.hap_order[k];
+      const int p = ri * a.cross_haps + hi;
+      const int H = (int)a.hap_len[hi];
+#ifdef GKL_PD_PROF
+      const unsigned long long pt_setup = __builtin_readcyclecounter();
+      job.prof_out = a.prof;
+#endif
+      // the table stays when this haplotype lists the classes of the one it was built for (the host gives the haplotypes
+      // of a call one common list whenever their union fits); otherwise the rows are set up again: keeping what
+      // build_table needs alive through a run would cost 30 registers
+      bool same = hi_built >= 0 && a.hap_ncls[hi] == a.hap_ncls[hi_built];
+      for (int c = 0; same && c < kPdTabClasses; c++) same = a.class_codes[(int64_t)hi * 8 + c] == a.class_codes[(int64_t)hi_built * 8 + c];
+      if (same) {
+        job.restart(init_condition / (double)H);
+      } else {
+        job.setup(a, p, sl.block, n_blocks, active, init_condition / (double)H);
+        job.build_table(lds_base, lane, a.class_codes + (int64_t)hi * 8, (int)a.hap_ncls[hi]);
+        hi_built = hi;
+      }
+#ifdef GKL_PD_PROF
+      if (lane == 0) atomicAdd(a.prof, __builtin_readcyclecounter() - pt_setup);
+#endif
+      const uint32_t* e0 = a.entries_tab + (int64_t)hi * a.entry_stride;
+      job.run_packed(e0 + kLanes - sl.block, H + top, false, e0 + kLanes, sl.block, top, __builtin_amdgcn_readfirstlane(H),
+                     a.next_special + (int64_t)hi * a.entry_stride);
+      if (job.holds_last) a.sums[p] = job.sum;
+    }
   }
 }
 
