@@ -288,6 +288,10 @@ int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
 }
 
 constexpr size_t kPdStageBytes = (size_t)4 << 20;
+// Cross layout: reads are packed into 64-lane chunks by best fit within windows of this many reads.  The chunks are reused
+// for every haplotype, so a fuller chunk pays off nh times: 2048 fills 99.2 % of the lanes on the reference's fixture
+// (192, the paired layout's window: 97.7 %).
+constexpr int kPdCrossWindow = 2048;
 int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   static const bool timing = getenv("GKLHIP_TIMING") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -368,7 +372,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
         job_pair.push_back((int32_t)(r * nh + h)); job_striped.push_back(1); job_steps.push_back(0);
       }
     }
-    const int made = pack_reads_windowed(shorts.data(), (int)shorts.size(), read_off.data(), kPdRpl, 192, &cross_lanes, nullptr);
+    const int made = pack_reads_windowed(shorts.data(), (int)shorts.size(), read_off.data(), kPdRpl, kPdCrossWindow, &cross_lanes, nullptr);
     chunk_steps.assign((size_t)made, 0);
     chunk_rep.assign((size_t)made, 0);
     for (int k = 0; k < made; k++) {
@@ -533,15 +537,18 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const int n_cross_jobs = (int)n_cross_jobs64;
   const int n_cross_tab = cross ? (int)((int64_t)n_chunks_cross * (int64_t)n_tab_haps) : 0;
   // Table launch: a unit of work is (a group of consecutive table haplotypes, a chunk of reads) -- the wavefront sets the
-  // chunk's rows up once per group (a twelfth of a job's time otherwise).  Groups of up to four while there are at least
-  // eight units per wavefront, the shortest quarter of the haplotypes as singles (they run last and even the load out).
+  // chunk's rows up once per group (a twelfth of a job's time otherwise).  Groups of up to six while there are at least
+  // six units per wavefront, shrinking to single haplotypes over the last part of the list (they run last and even the load out).
   std::vector<int32_t> tab_group_start;
   if (n_cross_tab > 0) {
     const int64_t per_wave = (int64_t)n_cross_tab / (256 * 8);
-    const int group = (int)std::max<int64_t>(1, std::min<int64_t>(4, per_wave / 8));
-    const size_t grouped = group > 1 ? (n_tab_haps * 3 / 4) / (size_t)group * (size_t)group : 0;
-    for (size_t k = 0; k < grouped; k += (size_t)group) tab_group_start.push_back((int32_t)k);
-    for (size_t k = grouped; k < n_tab_haps; k++) tab_group_start.push_back((int32_t)k);
+    const int group_max = (int)std::max<int64_t>(1, std::min<int64_t>(6, per_wave / 6));
+    for (size_t k = 0; k < n_tab_haps;) {   // sizes shrink towards the end of the list: the last units are single haplotypes
+      const size_t left = n_tab_haps - k;
+      const size_t g = std::max<size_t>(1, std::min<size_t>((size_t)group_max, left / 7));
+      tab_group_start.push_back((int32_t)k);
+      k += g;
+    }
     tab_group_start.push_back((int32_t)n_tab_haps);
   }
   const int n_tab_units = tab_group_start.empty() ? 0 : (int)((int64_t)n_chunks_cross * (int64_t)(tab_group_start.size() - 1));
@@ -604,6 +611,10 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   std::vector<int32_t> full_first((size_t)n_striped_listed);
   for (int32_t k = 0; k < n_striped_listed; k++) full_first[(size_t)k] = k;
   PD_HIP_TRY(hipMemsetAsync(c->misc.p, 0, 256, s));
+#ifdef GKL_PD_PROF
+  PD_HIP_TRY(hipMemsetAsync(c->misc.as<char>() + 128 + 13 * 8, 0xff, 8, s));
+  PD_HIP_TRY(hipMemsetAsync(c->misc.as<char>() + 128 + 15 * 8, 0xff, 8, s));
+#endif
   PD_HIP_TRY(put(o_fj, full_first.data(), full_first.size() * 4));
   if (staged_jobs && staged_hi > 0) PD_HIP_TRY(hipMemcpyAsync(dj, hj, staged_hi, hipMemcpyHostToDevice, s));
   PD_HIP_TRY(hipMemcpyAsync(c->misc.as<int32_t>() + 5, &n_striped_listed, 4, hipMemcpyHostToDevice, s));
@@ -725,8 +736,8 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     unsigned long long pr[16];
     PD_HIP_TRY(hipMemcpy(pr, c->misc.as<char>() + 128, sizeof pr, hipMemcpyDeviceToHost));
     const double tot = (double)(pr[0] + pr[1] + pr[2] + pr[3] + pr[4] + pr[5]);
-    fprintf(stderr, "[pd prof] setup+table %.3f  asm runs %.3f (%llu steps)  plain x2 loop %.3f (%llu)  plain x1 loop %.3f (%llu)  general %.3f (%llu)  other %.3f  | jobs %llu, total %.3e ticks\n",
-            pr[0] / tot, pr[1] / tot, pr[8], pr[2] / tot, pr[9], pr[3] / tot, pr[10], pr[4] / tot, pr[11], pr[5] / tot, pr[12], tot);
+    fprintf(stderr, "[pd prof] setup+table %.3f  asm runs %.3f (%llu steps)  plain x2 loop %.3f (%llu)  plain x1 loop %.3f (%llu)  general %.3f (%llu)  other %.3f  | jobs %llu, total %.3e ticks; first wavefront done at %.3f of the launch, last at 1\n",
+            pr[0] / tot, pr[1] / tot, pr[8], pr[2] / tot, pr[9], pr[3] / tot, pr[10], pr[4] / tot, pr[11], pr[5] / tot, pr[12], tot, (double)(pr[13] - pr[15]) / (double)(pr[14] - pr[15]));
   }
 #endif
   if (timing)

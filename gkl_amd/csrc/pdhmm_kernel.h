@@ -323,6 +323,7 @@ struct PdJob {
   int row1_slot;      // kSerial: the slot holding the read's FIRST row (the only row that starts in NORMAL), else -1
   bool has_non_acgt;  // kSerial: some real row's base is not A/C/G/T (any case)
   uint32_t tab_lane;  // kTab: LDS byte address of this lane's slot in class 0, plane 0
+  uint32_t asm_next[4];  // kTab: the entries of the four steps behind an asm run (pd_plain_run_asm)
   int pad_slot;       // the slot of the read's row 0 (the constant row above its first base), -1: not in this lane
 #ifdef GKL_PD_PROF
   unsigned long long* prof_out = nullptr;
@@ -718,14 +719,20 @@ struct PdJob {
 #ifdef GKL_PD_TIMING_NOSPECIAL
           const int32_t c = 0x7fffffff;
 #else
-          const int32_t c = ns[t - top];
+          int32_t c;   // one scalar load (the address is uniform; as a vector load it costs a global-memory round trip)
+          {
+            const uint64_t at = (uint64_t)(uintptr_t)(ns + (t - top));
+            const uint64_t at_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(at >> 32)) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)at);
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "s"(at_s) : "memory");
+          }
 #endif
           const int t_end = c - 2 < H ? c - 2 : H;
           const int n4 = (t_end - t) >> 2;
           if (n4 > 0) {
             pd_plain_run_asm(*this, e0 - top + t, (uint32_t)(top - block) * 4u, n4);
             t += 4 * n4;
-            cur = ep[t]; n1 = ep[t + 1]; n2 = ep[t + 2]; n3 = ep[t + 3];
+            cur = asm_next[0]; n1 = asm_next[1]; n2 = asm_next[2]; n3 = asm_next[3];   // (= ep[t .. t + 3]: the run's own look-ahead)
             s0 = any_special(cur); s1 = any_special(n1); s2 = any_special(n2);
           }
         }
@@ -915,6 +922,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
   using Job = PdJob<FMA, false, true, true>;
   Job job;
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+#ifdef GKL_PD_PROF
+  if (lane == 0) atomicMin(a.prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());   // (100 MHz, the same on every XCD)
+#endif
   for (;;) {
     int u = 0;
     if (lane == 0) u = atomicAdd(a.next, 1);
@@ -957,6 +967,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
       if (job.holds_last) a.sums[p] = job.sum;
     }
   }
+#ifdef GKL_PD_PROF
+  if (lane == 0) {
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    atomicMin(a.prof + 13, now);
+    atomicMax(a.prof + 14, now);
+  }
+#endif
 }
 
 }  // namespace gklhip

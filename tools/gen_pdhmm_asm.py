@@ -153,7 +153,8 @@ def main():
     o.append("namespace gklhip {")
     o.append("// `n4` x 4 plain steps of PdJob<true, false, true, true> (see the generator for the structure).  `base`: the")
     o.append("// wavefront's entry pointer for this step (uniform), `voff`: the lane's byte offset from it; every lane's entries")
-    o.append("// of these steps are real columns without a special bit (the caller's job).  Ends with nothing in flight.")
+    o.append("// of these steps are real columns without a special bit (the caller's job).  Ends with nothing in flight;")
+    o.append("// j.asm_next[0..3]: the lane's entries of the four steps behind the run (the loop's own look-ahead).")
     o.append("template <class Job>")
     o.append("__device__ __forceinline__ void pd_plain_run_asm(Job& j, const uint32_t* base_ptr, uint32_t voff, int n4) {")
     inout = []
@@ -184,11 +185,12 @@ def main():
     for ins in strip(program()):
         o.append(f"      \"{ins}\\n\\t\"")
     outs = ", ".join(f"\"+{{v[{reg}:{reg + 1}]}}\"({name})" for _, reg, name in inout)
-    o.append(f"      : {outs}, \"+&{{s94}}\"(cnt), \"+&{{s[92:93]}}\"(base)")
+    o.append(f"      : {outs}, \"+&{{s94}}\"(cnt), \"+&{{s[92:93]}}\"(base), \"=&{{v{EA}}}\"(j.asm_next[0]), \"=&{{v{EA + 1}}}\"(j.asm_next[1]), "
+             f"\"=&{{v{EB}}}\"(j.asm_next[2]), \"=&{{v{EB + 1}}}\"(j.asm_next[3])")
     ins = ", ".join(f"\"{{v[{reg}:{reg + 1}]}}\"({name})" for _, reg, name in consts)
     o.append(f"      : {ins}, \"{{v{LMASK}}}\"(lmask), \"{{v{TABL}}}\"(tabl), \"{{v{VOFF}}}\"(voff), \"{{s95}}\"(msk)")
     clob = [f"v{r}" for r in range(DB(0), DB(R - 1) + 2)] + [f"v{r}" for r in range(U(0), PR(R - 1) + 2)] + \
-           [f"v{TMP}", f"v{TMP + 1}", f"v{PADDR}"] + [f"v{r}" for r in range(EA, LAST + 1)] + ["scc", "memory"]
+           [f"v{TMP}", f"v{TMP + 1}", f"v{PADDR}"] + ["scc", "memory"]
     o.append("      : " + ", ".join(f"\"{c}\"" for c in clob) + ");")
     for expr, reg, name in inout:
         o.append(f"  {expr} = {name};")
