@@ -48,10 +48,14 @@ constexpr uint32_t kPdIdle = 1u << 30, kPdOdd = 1u << 31, kPdMatchBits = 0xfffff
 // FETCHES its six priors (three ds_read_b128) instead of evaluating the predicate per cell (and + compare + two selects
 // per row, a third of a plain step's issue time -- the PairHMM kernel's LDS prior planes).  Format: [14:0] the class's
 // byte offset in the lane-interleaved table (class * kPdTabClassBytes), [17:16] state on entry, bit 18 DEL_END,
-// bit 31 special (the sign: one signed compare in front of the ballot), an idle entry is exactly kPdIdle (one compare
-// against an inline constant instead of and + compare).
+// bit 31 special (the sign: one signed compare in front of the ballot), an idle entry is exactly kPdTabIdle (one compare
+// instead of and + compare).  An idle entry's class offset lies BEYOND the wavefront's table: a DS read beyond the
+// workgroup's LDS allocation returns 0 (ISA manuals since GCN3; tools/ubench_lds_oob.hip checks it on this chip), so a
+// lane on an idle entry that takes the step anyway computes with prior 0 -- which leaves a lane that has not started
+// in its initial state and adds +0 to the sum of one that is done (the whole-job asm program has no idle test).
 constexpr int kPdTabClasses = 6;
 constexpr uint32_t kPdTabDelEnd = 1u << 18, kPdTabOffsetMask = 0x7fffu, kPdTabSpecial = 1u << 31;
+constexpr uint32_t kPdTabIdleOffset = 0x6000u, kPdTabIdle = kPdIdle | kPdTabIdleOffset;
 __device__ __forceinline__ uint32_t pd_onehot_acgt(uint32_t b) {
   return b == (uint32_t)'A' ? 1u : b == (uint32_t)'C' ? 2u : b == (uint32_t)'G' ? 4u : b == (uint32_t)'T' ? 8u : 0u;
 }
@@ -71,6 +75,8 @@ constexpr int kPdRpl = GKL_PD_RPL;
 constexpr int kPdTabPlanes = (kPdRpl + 1) / 2;              // 16-byte planes of one class: two rows' priors each
 constexpr int kPdTabClassBytes = kPdTabPlanes * kLanes * 16;  // [plane][lane][2 doubles]
 static_assert(kPdTabClasses * kPdTabClassBytes <= (int)kPdTabOffsetMask + 1, "class offsets fit the entry");
+static_assert((int)kPdTabIdleOffset >= kPdTabClasses * kPdTabClassBytes + 1024 && kPdTabIdleOffset % 1024u == 0u &&
+              kPdTabIdleOffset + (uint32_t)kPdTabClassBytes <= kPdTabOffsetMask + 1u, "the idle class lies beyond the table");
 
 struct PdArgs {
   const int8_t* hap_bases;     // [batch * max_hap]
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
   uint32_t codes[kPdTabClasses];
 #pragma unroll
   for (int c = 0; c < kPdTabClasses; c++) codes[c] = ncls ? a.class_codes[(int64_t)p * 8 + c] : 0u;
-  if (et) { et[lane] = kPdIdle; et += kLanes; }
+  if (et) { et[lane] = kPdTabIdle; et += kLanes; }
   int carry = -1;  // key of the last flagged column of the tiles before this one
   int first_flagged = H;  // first column with DEL_START / DEL_END (H: none)
   bool has_odd = false;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
   }
   for (int j = H + lane; j < a.entry_stride - kLanes; j += kLanes) {
     e[j] = kPdIdle;
-    if (et) et[j] = kPdIdle;
+    if (et) et[j] = kPdTabIdle;
   }
   // a haplotype with an odd column says so in its first (idle) word: its jobs run the byte-comparing steps throughout
   if (__ballot(has_odd) != 0 && lane == 0) e[-kLanes] = kPdIdle | kPdOdd;
@@ -273,11 +279,13 @@ __global__ __launch_bounds__(256) void pdhmm_collect_kernel(const uint8_t* job_f
   if (j < n_general && job_flags[j] && !job_striped[j]) full_jobs[atomicAdd(full_count, 1)] = j;
 }
 
+// 2: the whole haplotype job as one asm program (pd_job_asm); 1: asm runs of plain steps inside the C++ loops
+// (pd_plain_run_asm, the arrangement before); 0: all C++ -- the cross-check builds of tests/test_pdhmm.py.
 #ifndef GKL_PD_ASM
-#define GKL_PD_ASM 1
+#define GKL_PD_ASM 2
 #endif
 }  // namespace gklhip
-#include "pdhmm_plain_asm.h"   // generated (tools/gen_pdhmm_asm.py): pd_plain_run_asm
+#include "pdhmm_plain_asm.h"   // generated (tools/gen_pdhmm_asm.py): pd_plain_run_asm, pd_job_asm
 namespace gklhip {
 
 // _mm256_max_pd / std::max on the values this recurrence produces (finite, non-negative, no -0): one v_max_f64.  Written
@@ -536,8 +544,8 @@ struct PdJob {
     double (&dg)[6] = kFlip ? r : d;   // diagonal inputs
     double (&tp)[6] = kFlip ? d : r;   // inputs from the row above at this column
     double pr[RPL];
-    if (kTab) fetch_priors(ent, pr);  // (idle entries read class 0: harmless)
-    if (kTab ? ent != kPdIdle : (ent & kPdIdle) == 0u) {
+    if (kTab) fetch_priors(ent, pr);  // (idle entries read zeros from beyond the table)
+    if (kTab ? ent != kPdTabIdle : (ent & kPdIdle) == 0u) {
 #pragma unroll
       for (int s = RPL - 1; s >= 0; s--) {
         const double mmD = s ? mm[s - 1] : dg[0], imD = s ? im[s - 1] : dg[1], dmD = s ? dm[s - 1] : dg[2];
@@ -606,7 +614,7 @@ struct PdJob {
   // (that form: 32 v_max_f64 + 64 v_cndmask + 44 v_mov per step).
   __device__ __forceinline__ void step_general(uint32_t entry) {
     ent = entry;
-    const bool off = kTab ? ent == kPdIdle : (ent & kPdIdle) != 0;
+    const bool off = kTab ? ent == kPdTabIdle : (ent & kPdIdle) != 0;
     const uint32_t state = (ent >> 16) & 3u;
     const bool del_end = (ent & (kTab ? kPdTabDelEnd : (uint32_t)kPdDelEnd << 8)) != 0;
     double pr[RPL];
@@ -711,7 +719,7 @@ struct PdJob {
 #endif
     while (t < n_steps) {
       PD_PROF_MARK(4)
-      if constexpr (kTab && FMA && GKL_PD_ASM != 0) {
+      if constexpr (kTab && FMA && GKL_PD_ASM == 1) {
         // Steps top .. H-1: every lane is inside its haplotype.  No special column in [t - top, t + 2] <=> the next
         // special column at or behind t - top lies beyond t + 2; the run of plain steps ends two steps before it reaches
         // the first lane (the lead-in of the general steps).
@@ -739,7 +747,7 @@ struct PdJob {
       }
       PD_PROF_MARK(0)
       // (with the asm run: the C++ plain loops stop where every lane has started, so that the asm run takes over from there)
-      const int lim = (kTab && FMA && GKL_PD_ASM != 0 && t < top && top + 4 <= H) ? top : n_steps;
+      const int lim = (kTab && FMA && GKL_PD_ASM == 1 && t < top && top + 4 <= H) ? top : n_steps;
       if (kTab && GKL_PD_TAB_UNROLL) {
         // plain steps two at a time, the d / r roles alternating (see step_plain); no way out between the two, or the
         // compiler restores the roles with copies on the main path
@@ -962,8 +970,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
       if (lane == 0) atomicAdd(a.prof, __builtin_readcyclecounter() - pt_setup);
 #endif
       const uint32_t* e0 = a.entries_tab + (int64_t)hi * a.entry_stride;
-      job.run_packed(e0 + kLanes - sl.block, H + top, false, e0 + kLanes, sl.block, top, __builtin_amdgcn_readfirstlane(H),
-                     a.next_special + (int64_t)hi * a.entry_stride);
+      if constexpr (FMA && GKL_PD_ASM == 2)
+        pd_job_asm(job, e0 + kLanes - top, (uint32_t)(top - sl.block) * 4u, H + top, top, a.next_special + (int64_t)hi * a.entry_stride);
+      else
+        job.run_packed(e0 + kLanes - sl.block, H + top, false, e0 + kLanes, sl.block, top, __builtin_amdgcn_readfirstlane(H),
+                       a.next_special + (int64_t)hi * a.entry_stride);
       if (job.holds_last) a.sums[p] = job.sum;
     }
   }

@@ -426,11 +426,12 @@ def pdhmm_available_memory_mb(max_memory_mb: int) -> int:
 class PdhmmContext:
     """One gklhip_pdhmm context (= IntelPDHMM.initNative)."""
 
-    def __init__(self, device: int = -1, fma_mode: int = 1, reference_tail: Optional[bool] = None):
+    def __init__(self, device: int = -1, fma_mode: int = 1, reference_tail: Optional[bool] = None, lib_path: Optional[str] = None):
         """fma_mode 1: bit-identical to GKL's AVX-512 PDHMM object, 0: to its AVX2 object.  reference_tail: the last
         `batch mod SIMD width` pairs of every reference batch take the scalar engine's arithmetic, as in GKL -- None:
-        the library's setting (default: on; GKL_HIP_PDHMM_TAIL=vector turns it off), True / False: set it."""
-        self.lib = load_pdhmm_library()
+        the library's setting (default: on; GKL_HIP_PDHMM_TAIL=vector turns it off), True / False: set it.
+        lib_path: another build of the library (the all-C++ cross-check build of the tests)."""
+        self.lib = load_pdhmm_library(lib_path)
         h = C.c_void_p()
         st = self.lib.gklhip_pdhmm_init(device, C.byref(h))
         if st != OK:

@@ -187,6 +187,7 @@ def pd_ctx(request):
     # the position-independent mode (vector arithmetic for every pair; the default is GKL's position-dependent one)
     with native.PdhmmContext(fma_mode=request.param, reference_tail=False) as c:
         c.sem = SEMANTICS_OF_FMA_MODE[request.param]
+        c.fma_mode = request.param
         yield c
 
 
@@ -431,6 +432,53 @@ def test_pdhmm_gpu_table_kernel_routing_and_parity(pd_ctx, pd_oracle):
     got = pd_ctx.compute_cross(src, hp)
     assert pd_ctx.last_routing() == (len(h2), 0, 0)
     assert got.tobytes() == pd_oracle.compute(b2, semantics=pd_ctx.sem)[1].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_pdhmm_gpu_table_kernel_flags_anywhere(pd_ctx, pd_oracle, seed):
+    # The table kernel's whole-job program switches between plain and general steps by the haplotype's next-special-
+    # column table and runs idle lanes on an all-zero prior class: deletion flags on the first and last columns (no
+    # lead-in possible), both flags on one column, dense and unbalanced flags, haplotypes shorter than the wavefront is
+    # deep, one-base reads, many haplotypes per group -- all with at most six column classes, so that every
+    # haplotype takes the table kernel.
+    rng = np.random.RandomState(1000 + seed)
+    one = np.zeros(1, np.int8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.int8)
+    haps_l = []
+    for k in range(40):
+        H = int(rng.choice([1, 2, 3, 5, 17, 40, 64, 65, 130, 257])) if k < 20 else int(rng.randint(1, 300))
+        b = acgt[rng.randint(0, 4, H)].copy()
+        pd = np.zeros(H, np.int8)
+        rate = [0.0, 0.02, 0.1, 0.4][k % 4]
+        for j in range(H):
+            if rng.rand() < rate:
+                pd[j] |= int(rng.choice([2, 4, 6]))
+        if k % 3 == 0:
+            pd[0] |= int(rng.choice([2, 4, 6]))
+        if k % 5 == 0:
+            pd[H - 1] |= int(rng.choice([2, 4, 6]))
+        if k % 7 == 0 and H > 1:
+            pd[1] |= 4
+        if k % 2 == 0 and H > 6:                                  # one SNP kind (a fifth class), twice
+            for j in rng.choice(np.arange(H), 2, replace=False):
+                b[j] = acgt[1]
+                pd[j] |= 1 | (5 << 3)
+        haps_l.append((b, pd))
+    haps = PdhmmBatch.from_pairs([(b, pd, one, one, one, one, one) for b, pd in haps_l])
+    reads = random_pd_batch(rng, 120, read_len=(1, 130), hap_len=(1, 2))
+    got = pd_ctx.compute_cross(reads, haps)
+    tab, pred, odd = pd_ctx.last_routing()
+    assert tab == len(haps_l), (tab, pred, odd)
+    _, vec = pd_oracle.compute(expand_cross(reads, haps), semantics=pd_ctx.sem)
+    assert got.tobytes() == vec.tobytes()
+    # the all-C++ cross-check build of the same kernel (libgklhip_pdhmm_cxx.so: step loops, ballots, idle tests)
+    import os
+    from gkl_amd import native
+    cxx = os.path.join(os.path.dirname(native.PDHMM_LIB_PATH), "libgklhip_pdhmm_cxx.so")
+    assert os.path.exists(cxx), "make -C gkl_amd/csrc builds it"
+    with native.PdhmmContext(fma_mode=pd_ctx.fma_mode, reference_tail=False, lib_path=cxx) as c:
+        assert c.compute_cross(reads, haps).tobytes() == vec.tobytes()
 
 
 @pytest.mark.gpu
