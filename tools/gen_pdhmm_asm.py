@@ -327,7 +327,7 @@ def emit_job(o):
         o.append(f"  double {name} = {expr};")
     o.append("  double sum;")
     o.append("  asm volatile(")
-    for ins in job_program():
+    for ins in strip(job_program()):
         o.append(f"      \"{ins}\\n\\t\"")
     outs = ", ".join(f"\"+{{v[{reg}:{reg + 1}]}}\"({name})" for _, reg, name in dms)
     o.append(f"      : {outs}, \"=&{{v[{SUM}:{SUM + 1}]}}\"(sum), \"+&{{s[92:93]}}\"(base)")
