@@ -174,6 +174,27 @@ int gklhip_pdhmm_init(int device, gklhip_pdhmm_ctx** out_ctx) {
     const char* tb = getenv("GKL_HIP_PDHMM_TABLE");
     c->use_table = (tb && tb[0] == '0') ? 0 : 1;
   }
+  if (c->use_table) {
+    // once per process and device: does a DS read beyond the workgroup's LDS allocation return 0 here?  The table
+    // kernel's idle entries depend on it (pdhmm_kernel.h: kPdTabIdle); if not, every haplotype takes the other kernels.
+    static std::mutex mu;
+    static std::vector<int> checked;   // 0 unknown, 1 good, -1 bad
+    std::lock_guard<std::mutex> l(mu);
+    if ((int)checked.size() <= device) checked.resize((size_t)device + 1, 0);
+    if (checked[(size_t)device] == 0) {
+      uint32_t* d_out = nullptr;
+      uint32_t h_out = 1u;
+      if (hipMalloc(reinterpret_cast<void**>(&d_out), 4) != hipSuccess) return bail(pd_fail(GKLHIP_ERR_OOM, "hipMalloc failed"));
+      bool ok = hipMemsetAsync(d_out, 0, 4, c->stream) == hipSuccess;
+      hipLaunchKernelGGL(pdhmm_idle_class_selftest_kernel, dim3(64), dim3(64), 0, c->stream, d_out);
+      ok = ok && hipMemcpyAsync(&h_out, d_out, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+      (void)hipFree(d_out);
+      checked[(size_t)device] = ok && h_out == 0u ? 1 : -1;
+      if (checked[(size_t)device] < 0)
+        fprintf(stderr, "[gklhip] pdhmm: LDS reads beyond the allocation do not return 0 on device %d (%08x): the table kernel is off\n", device, h_out);
+    }
+    if (checked[(size_t)device] < 0) c->use_table = 0;
+  }
   *out_ctx = c;
   return GKLHIP_OK;
 }

@@ -987,4 +987,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
 #endif
 }
 
+// Self-test of the assumption behind kPdTabIdle (run once per process and device by gklhip_pdhmm_init): a workgroup with the
+// table kernel's LDS allocation, every byte of it non-zero, reads what a lane on an idle entry reads -- the three planes
+// of the class at kPdTabIdleOffset -- and reports the OR of all bits.  Anything but 0 and the context routes no haplotype
+// to the table kernel.
+__global__ __launch_bounds__(64) void pdhmm_idle_class_selftest_kernel(uint32_t* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kPdTabClasses * kPdTabClassBytes];
+  for (int i = threadIdx.x; i < kPdTabClasses * kPdTabClassBytes / 4; i += kLanes) reinterpret_cast<uint32_t*>(lds)[i] = 0xA5A5A5A5u;
+  __syncthreads();
+  const uint32_t addr = (uint32_t)(uintptr_t)lds + (uint32_t)threadIdx.x * 16u + kPdTabIdleOffset;
+  uint32_t acc = 0;
+  for (int pl = 0; pl < kPdTabPlanes; pl++) {
+    uint32_t v0, v1, v2, v3;
+    asm volatile("ds_read_b128 v[40:43], %4\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, v40\n\tv_mov_b32 %1, v41\n\tv_mov_b32 %2, v42\n\tv_mov_b32 %3, v43"
+                 : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "v"(addr + (uint32_t)(pl * kLanes * 16)) : "v40", "v41", "v42", "v43", "memory");
+    acc |= v0 | v1 | v2 | v3;
+  }
+  if (acc) atomicOr(out, acc);
+  if (lds[threadIdx.x] == 0) atomicOr(out, 0x80000000u);   // (keeps the stores above alive)
+}
+
 }  // namespace gklhip
