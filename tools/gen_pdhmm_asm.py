@@ -259,7 +259,7 @@ def job_program():
     load_b = [f"global_load_dwordx2 v[{EB}:{EB + 1}], v{VOFF}, s[92:93] offset:8",
               "s_add_u32 s92, s92, 16", "s_addc_u32 s93, s93, 0"]
 
-    def pair(first_ent, lab0, ents, waits, posts):
+    def pair(lab0, ents, waits, posts):
         """two steps; `ents`: (cur, next) registers of the two steps"""
         q = []
         # s_c: the first special column at or behind the oldest column in flight (ns[max(t - top, 0)]).  It stays the
@@ -296,8 +296,8 @@ def job_program():
 
     o.append("1:")
     w = ["s_waitcnt vmcnt(0)"]
-    o += pair(None, 10, [(f"v{EA}", f"v{EA + 1}"), (f"v{EA + 1}", f"v{EB}")], [None, w], [None, load_a])
-    o += pair(None, 20, [(f"v{EB}", f"v{EB + 1}"), (f"v{EB + 1}", f"v{EA}")], [None, w], [None, load_b])
+    o += pair(10, [(f"v{EA}", f"v{EA + 1}"), (f"v{EA + 1}", f"v{EB}")], [None, w], [None, load_a])
+    o += pair(20, [(f"v{EB}", f"v{EB + 1}"), (f"v{EB + 1}", f"v{EA}")], [None, w], [None, load_b])
     o.append(f"s_cmp_lt_i32 s{S_T}, s{S_N}")
     o.append("s_cbranch_scc1 1b")
     o.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
