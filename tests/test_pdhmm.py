@@ -482,6 +482,58 @@ def test_pdhmm_gpu_table_kernel_flags_anywhere(pd_ctx, pd_oracle, seed):
 
 
 @pytest.mark.gpu
+def test_pdhmm_gpu_table_kernel_haplotype_groups(pd_ctx, pd_oracle):
+    # With enough work per wavefront the table launch hands out GROUPS of up to six haplotypes per chunk of reads (rows
+    # set up once, matrices restarted per haplotype, the LDS table kept while the class list stays the same) and packs
+    # the reads in windows of 2048 -- none of which a small call reaches.  The reference's fixture with its reads
+    # replicated 24 times (6624 reads x 48 haplotypes) must give every replica the bits of the single call, which is
+    # checked against the oracle; then the same with haplotypes whose class lists differ (five classes each, seven in
+    # their union: no common list, so the table is rebuilt inside a group).
+    one = np.zeros(1, np.int8)
+    r2, h2, b2, _ = holders_fixture_batch()
+    hp = PdhmmBatch.from_pairs([(x[0], x[1], one, one, one, one, one) for x in h2])
+    src1 = PdhmmBatch.from_pairs([(one, one, *r) for r in r2])
+    base = pd_ctx.compute_cross(src1, hp)
+    assert base.tobytes() == pd_oracle.compute(b2, semantics=pd_ctx.sem)[1].tobytes()
+    reps = 24
+    srcn = PdhmmBatch.from_pairs([(one, one, *r) for r in r2] * reps)
+    got = pd_ctx.compute_cross(srcn, hp).reshape(reps, -1)
+    assert pd_ctx.last_routing() == (len(h2), 0, 0)
+    for k in range(reps):
+        assert got[k].tobytes() == base.tobytes(), k
+    # class lists that differ from haplotype to haplotype
+    rng = np.random.RandomState(99)
+    acgt = np.frombuffer(b"ACGT", dtype=np.int8)
+    haps_l = []
+    for k in range(30):
+        H = int(rng.randint(150, 340))
+        b = acgt[rng.randint(0, 4, H)].copy()
+        pd = np.zeros(H, np.int8)
+        base_k, alleles = [(1, 5), (3, 3), (2, 9)][k % 3]
+        for j in rng.choice(np.arange(5, H - 5), 3, replace=False):
+            b[j] = acgt[base_k]
+            pd[j] = 1 | alleles << 3
+        j = int(rng.randint(10, H - 30))
+        pd[j] |= 2
+        pd[j + int(rng.randint(1, 9))] |= 4
+        haps_l.append((b, pd))
+    hq = PdhmmBatch.from_pairs([(b, pd, one, one, one, one, one) for b, pd in haps_l])
+    reads1 = random_pd_batch(rng, 220, read_len=(20, 120), hap_len=(1, 2))
+    n1 = reads1.batch
+    rr = lambda a, r: a.reshape(n1, reads1.max_read_len)[r, :int(reads1.read_lengths[r])]  # noqa: E731
+    rows = [(one, one, rr(reads1.read_bases, r), rr(reads1.read_qual, r), rr(reads1.read_ins_qual, r), rr(reads1.read_del_qual, r),
+             rr(reads1.gcp, r)) for r in range(n1)]
+    base = pd_ctx.compute_cross(PdhmmBatch.from_pairs(rows), hq)
+    assert pd_ctx.last_routing()[0] == len(haps_l)
+    _, vec = pd_oracle.compute(expand_cross(PdhmmBatch.from_pairs(rows), hq), semantics=pd_ctx.sem)
+    assert base.tobytes() == vec.tobytes()
+    got = pd_ctx.compute_cross(PdhmmBatch.from_pairs(rows * 40), hq).reshape(40, -1)
+    assert pd_ctx.last_routing()[0] == len(haps_l)
+    for k in range(40):
+        assert got[k].tobytes() == base.tobytes(), k
+
+
+@pytest.mark.gpu
 def test_pdhmm_gpu_argument_errors(pd_ctx):
     from gkl_amd import native
     b = random_pd_batch(np.random.RandomState(5), 8)
