@@ -534,6 +534,22 @@ def test_pdhmm_gpu_table_kernel_haplotype_groups(pd_ctx, pd_oracle):
 
 
 @pytest.mark.gpu
+def test_pdhmm_gpu_paired_large_batch_by_replication(pd_ctx, pd_oracle):
+    # The paired entry point at a size no other test reaches: inputs past the pinned staging block (direct copies from a
+    # helper thread), the packing expanded and routed on the device, job arrays past their staging block, threaded
+    # log10.  The holders fixture as 13 248 explicit pairs, then nine copies of it in one call (119 232 pairs): every
+    # copy must carry the bits of the single call, which is checked against the oracle.
+    _, _, b1, _ = holders_fixture_batch()
+    base = pd_ctx.compute(b1)
+    assert base.tobytes() == pd_oracle.compute(b1, semantics=pd_ctx.sem)[1].tobytes()
+    reps = 9
+    big = b1.subset(np.tile(np.arange(b1.batch), reps))
+    got = pd_ctx.compute(big).reshape(reps, -1)
+    for k in range(reps):
+        assert got[k].tobytes() == base.tobytes(), k
+
+
+@pytest.mark.gpu
 def test_pdhmm_gpu_argument_errors(pd_ctx):
     from gkl_amd import native
     b = random_pd_batch(np.random.RandomState(5), 8)
