@@ -154,6 +154,30 @@ def test_sw_gpu_batch_bit_exact(sw_ctx, sw_oracle, strategy):
 
 
 @pytest.mark.gpu
+def test_sw_gpu_batch_larger_than_the_grid(sw_ctx, sw_oracle):
+    # 4096 persistent wavefronts pull pairs longest-first and reuse one scratch slab each: only a batch of more pairs
+    # than that sends a wavefront round its loop a second time (back-track words, maxima and operations of the
+    # previous pair still in its slab).  300 distinct pairs, 24 shuffled copies of each = 7200 pairs in one call;
+    # every copy must be the oracle's answer for its original.
+    rng = np.random.RandomState(4242)
+    pairs = random_pairs(rng, 300, lengths=(1, 3, 17, 64, 100, 150, 300, 520))
+    p, strategy = PARAM_SETS[0], STRATEGIES[0]
+    stride = 2 * max(max(len(r), len(a)) for r, a in pairs)
+    exp = [sw_oracle.align(r, a, p, strategy, cigar_len=stride) for r, a in pairs]
+    order = rng.permutation(np.repeat(np.arange(len(pairs)), 24))
+    cig, cnt, off = sw_ctx.align_batch([pairs[k][0] for k in order], [pairs[k][1] for k in order], p, strategy)
+    for i, k in enumerate(order):
+        st, ecig, ecnt, eoff = exp[k]
+        assert st == 0 and (cig[i], int(cnt[i]), int(off[i])) == (ecig, ecnt, eoff), (i, k)
+    for strategy in STRATEGIES[1:]:
+        exp = [sw_oracle.align(r, a, p, strategy, cigar_len=stride) for r, a in pairs]
+        cig, cnt, off = sw_ctx.align_batch([pairs[k][0] for k in order], [pairs[k][1] for k in order], p, strategy)
+        for i, k in enumerate(order):
+            st, ecig, ecnt, eoff = exp[k]
+            assert st == 0 and (cig[i], int(cnt[i]), int(off[i])) == (ecig, ecnt, eoff), (strategy, i, k)
+
+
+@pytest.mark.gpu
 def test_sw_gpu_single_pair_long_and_striped(sw_ctx, sw_oracle):
     # more than 256 rows -> several stripes with the boundary row carried through HBM; odd / even widths
     rng = np.random.RandomState(7)
