@@ -94,8 +94,17 @@ def step(dprev, dthis, diag, top, next_ent, pre=None, post=None):
     # the prior registers are free again: the next step's priors are fetched now, a whole insertion chain ahead of their use
     if pre:
         o += pre
-    o.append(f"v_and_or_b32 v{PADDR}, {next_ent}, s95, v{TABL}")
-    o += prior_reads()
+    if 'predicate' in KNOB:   # timing experiment: the match predicate per cell instead of the table (what an asm predicate kernel would issue)
+        o.append(f"v_and_b32 v{VST}, 0x40000000, {next_ent}")
+        o.append(f"v_cmp_eq_u32_e32 vcc, 0, v{VST}")
+        for s in range(R):
+            o.append(f"v_and_b32 v{VST}, {next_ent}, v{TMM(s)}")
+            o.append(f"v_cmp_lt_u32_e32 vcc, s95, v{VST}")
+            o.append(f"v_cndmask_b32 v{PR(s)}, v{TIM(s)}, v{TII(s)}, vcc")
+            o.append(f"v_cndmask_b32 v{PR(s) + 1}, v{TIM(s) + 1}, v{TII(s) + 1}, vcc")
+    else:
+        o.append(f"v_and_or_b32 v{PADDR}, {next_ent}, s95, v{TABL}")
+        o += prior_reads()
     for s in range(R):
         o.append(mul(U(s), MM(s - 1) if s else top(0), TMI(s)))
     b = b_ops(dthis, dprev)
@@ -211,8 +220,17 @@ def job_step(dprev, dthis, diag, top, next_ent, cur_ent, general, lab, pre=None,
         o.append(mul(MM(s), PR(s), U(s)))
     if pre:
         o += pre
-    o.append(f"v_and_or_b32 v{PADDR}, {next_ent}, s95, v{TABL}")
-    o += prior_reads()
+    if 'predicate' in KNOB:   # timing experiment: the match predicate per cell instead of the table (what an asm predicate kernel would issue)
+        o.append(f"v_and_b32 v{VST}, 0x40000000, {next_ent}")
+        o.append(f"v_cmp_eq_u32_e32 vcc, 0, v{VST}")
+        for s in range(R):
+            o.append(f"v_and_b32 v{VST}, {next_ent}, v{TMM(s)}")
+            o.append(f"v_cmp_lt_u32_e32 vcc, s95, v{VST}")
+            o.append(f"v_cndmask_b32 v{PR(s)}, v{TIM(s)}, v{TII(s)}, vcc")
+            o.append(f"v_cndmask_b32 v{PR(s) + 1}, v{TIM(s) + 1}, v{TII(s) + 1}, vcc")
+    else:
+        o.append(f"v_and_or_b32 v{PADDR}, {next_ent}, s95, v{TABL}")
+        o += prior_reads()
     for s in range(R):
         o.append(mul(U(s), MM(s - 1) if s else top(0), TMI(s)))
     b = b_ops(dthis, dprev)
