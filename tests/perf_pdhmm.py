@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--json", default=None, help="write a bench-style JSON summary of the fixture case here")
     ap.add_argument("--fixture-x", type=int, default=4, help="how many times the fixture's 276 reads are replicated")
+    ap.add_argument("--fma-mode", type=int, default=1, help="1: the arithmetic of GKL's AVX-512 object (default), 0: of its AVX2 object")
     a = ap.parse_args()
     import json
     from gkl_amd import native
@@ -36,12 +37,12 @@ def main():
     reads, haps, _ = load_pdhmm_holders_file()
     pairs = [(h[0], h[1], r[0], r[1], r[2], r[3], r[4]) for r in reads for h in haps]
     cases[f"fixture pdhmm_new x{a.fixture_x}"] = PdhmmBatch.from_pairs(pairs * a.fixture_x)
-    ctx = native.PdhmmContext()
+    ctx = native.PdhmmContext(fma_mode=a.fma_mode)
     # the same fixture through the cross entry point (what computeLikelihoodsNative calls): reads x4, all 48 haplotypes
     one = b"\0"
     cross_reads = PdhmmBatch.from_pairs([(one, one, r[0], r[1], r[2], r[3], r[4]) for r in reads] * a.fixture_x)
     cross_haps = PdhmmBatch.from_pairs([(h[0], h[1], one, one, one, one, one) for h in haps])
-    ctx0 = native.PdhmmContext()
+    ctx0 = native.PdhmmContext(fma_mode=a.fma_mode)
     ctx0.compute_cross(cross_reads, cross_haps)
     best_k, best_w = 1e9, 1e9
     for _ in range(a.reps):
