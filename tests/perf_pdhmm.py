@@ -67,9 +67,10 @@ def main():
                             "achieved": round(12 * cc / best_k / 1e9, 2), "peak": 78.6, "unit": "TFLOP/s",
                             "frac": round(12 * cc / best_k / 1e9 / 78.6, 4), "traffic": None,
                             "note": "fp64 vector recurrence (no contraction for MFMA), priced at the dense fp64 MFMA peak = "
-                                    "fp64 vector peak; 2 wavefronts per SIMD; table kernel (match priors from an LDS class table): a plain "
-                                    "step of 6 rows is 50 fp64 operations in 70 vector instructions; 12 flop per cell caps the "
-                                    "fraction at 0.75 (DESIGN.md section 7)"}}
+                                    "fp64 vector peak; 2 wavefronts per SIMD; table kernel (match priors from an LDS class table), every haplotype "
+                                    "one generated asm program: a plain step of 6 rows is 50 fp64 operations in 57 vector instructions; 12 flop "
+                                    "per cell caps the fraction at 0.75; the kernel sustains ~1.9 of the 2.4 GHz the peak is quoted at "
+                                    "(DESIGN.md section 7, docs/NOTES.md 38)"}}
     for name, b in cases.items():
         ctx.compute(b)
         best_k, best_w = 1e9, 1e9
