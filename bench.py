@@ -5,6 +5,7 @@ HaplotypeCaller-shaped 10k-read x 128-haplotype batch, 1..N GPUs of one node.
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      # no launcher: bench.py starts the line above itself (free port)
 
 A "step" is one full pass of the hot path over one batch with the inputs already resident
 in HBM: plan -> fp32 forward kernel over all pairs -> precision policy + planning of the fp64
@@ -239,6 +240,24 @@ def in_library_probe(n_dev, reads, haps, workload, steps, warmup):
     print(json.dumps(res), flush=True)
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves -- the same
+    `torch.distributed.run --nnodes=1 --nproc-per-node N` command the module docstring shows, rendezvous on 127.0.0.1 and a
+    port the kernel says is free -- hand the arguments through unchanged and leave with the launcher's exit status (rank 0
+    prints the one JSON line on the inherited stdout; a rank that dies or a short-handed group stays a non-zero exit)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on these hosts
+    env.setdefault("OMP_NUM_THREADS", "4")              # (what the launcher would otherwise set to 1, with a warning)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {n_gpus} without a launcher; starting {n_gpus} ranks: {' '.join(cmd[1:9])} bench.py ...", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +284,8 @@ def main():
         a.reads, a.haps = 8000, 125
     if a.in_library_probe:
         return in_library_probe(a.in_library_probe, a.reads, a.haps, a.workload, a.steps, a.warmup)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(a.gpus)
 
     import torch
     import torch.distributed as dist
@@ -283,6 +304,8 @@ def main():
     same_device = os.environ.get("GKL_BENCH_SAME_DEVICE") == "1"
     backend = os.environ.get("GKL_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     dev_index = 0 if same_device else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"--gpus {a.gpus}: rank {rank} wants cuda:{dev_index} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     comm_dev = dev if backend == "nccl" else torch.device("cpu")

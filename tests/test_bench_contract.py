@@ -84,6 +84,44 @@ def test_bench_line_two_ranks_on_one_gpu():
     assert c["in_library_gather"]["backend"] == "peer" and c["in_library_gather"]["devices"] == 2
 
 
+def test_bench_without_a_launcher_starts_the_launcher_cpu():
+    """No GPU here: `python bench.py --gpus 2` must still get as far as starting its two ranks under torch.distributed.run
+    (each then refuses to run without an MI355X) and hand their failure back as a non-zero exit with no JSON line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU twin of this test runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "50", "--haps", "4", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "starting 2 ranks" in p.stderr and "torch.distributed.run" in p.stderr
+    assert p.stderr.count("needs an MI355X") >= 1, p.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as the driver types it (no torch.distributed.run around it, WORLD_SIZE unset): bench.py
+    starts the two ranks itself on a free port and rank 0 prints the one line, both ranks in the exchange step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GKL_BENCH_SAME_DEVICE="1", GKL_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "600", "--haps", "24", "--steps", "4",
+                        "--warmup", "2", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["steps"] == 4 and d["warmup"] == 2
+    c = d["comm"]
+    assert c["ranks_seen"] == 2 and c["world_size"] == 2 and len(c["gather_bytes_per_rank"]) == 2
+    # a node with fewer GPUs than ranks is a non-zero exit with no line, not a smaller number (no SAME_DEVICE here)
+    env.pop("GKL_BENCH_SAME_DEVICE")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "200", "--haps", "8", "--steps", "1",
+                        "--warmup", "0", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
 @pytest.mark.gpu
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     env = dict(os.environ, GKL_BENCH_SAME_DEVICE="1", GKL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
