@@ -119,11 +119,11 @@ struct gklhip_pdhmm_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
-  Buf tables, inputs, entries, entries_tab, sums, misc, carry, jobs;
+  Buf tables, inputs, entries, entries_tab, sums, misc, carry, jobs, tabx;
   PackScratch pack_scratch;
   PinBuf stage_in, stage_jobs, sums_pin;   // small calls: ONE copy per device buffer instead of one per array (9 + 17 of them)
   float last_ms = 0.f;
-  int32_t last_routing[3] = {0, 0, 0};  // haplotype items of the last cross call: table kernel / predicate kernel / byte-comparing kernel
+  int32_t last_routing[3] = {0, 0, 0};  // last cross call: haplotype items by kernel (table / predicate / byte-comparing); last paired call: packed jobs by kernel
   int use_table = 1;                    // GKL_HIP_PDHMM_TABLE=0: never route to the table kernel
   int fma_mode = 1;  // 1 = arithmetic of GKL's AVX-512 object (default), 0 = of its AVX2 object
   int tail_mode = 1; // 1 (default) = the last `batch mod SIMD width` pairs of every reference batch take the scalar engine's arithmetic, like GKL; 0 = vector arithmetic everywhere
@@ -211,7 +211,7 @@ int gklhip_pdhmm_done(gklhip_pdhmm_ctx* c) {
   if (!c) return GKLHIP_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->entries_tab, &c->sums, &c->misc, &c->carry, &c->jobs}) b->release();
+  for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->entries_tab, &c->sums, &c->misc, &c->carry, &c->jobs, &c->tabx}) b->release();
   for (PinBuf* b : {&c->stage_in, &c->stage_jobs, &c->sums_pin}) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -579,8 +579,18 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   const int entry_stride = (q.max_hap_len + 2 * kLanes + 4 + 63) / 64 * 64;   // 64 idle, the columns, 63 skew + 4 look-ahead
   const int carry_len = entry_stride;
   const int n_blocks = std::max(1, std::min(std::max(n_jobs, (int)n_tail), 256 * 8));
+  // Paired layout through the table kernel (pdhmm_fwd_tab_paired_kernel): classes, special columns and the routing of the
+  // jobs are found on the device.  Needs the program's 32-bit entry offsets to reach every item's stream and the step
+  // marks of a job to fit the special kernel's LDS.
+  const size_t n_packed = cross ? 0 : (size_t)n_general - n_striped;
+  const bool tab_paired = !cross && c->use_table && n_packed > 0 && nh * (size_t)entry_stride * 4 < ((size_t)1 << 32) && entry_stride <= 48 * 1024;
+  const bool tab_paired_asm = tab_paired && c->fma_mode == 1 && GKL_PD_ASM == 2;   // (the C++ step loops ballot on the lanes' own entries)
+  const int sb_stride = entry_stride / 64, ns_stride = entry_stride;
+  const size_t x_nc = 0, x_cc = up(nh), x_sb = x_cc + up(nh * 32), x_nt = x_sb + up(nh * (size_t)sb_stride * 8), x_hj = x_nt + up((size_t)n_general),
+               x_ns = x_hj + up((size_t)n_general * 4), x_total = x_ns + (tab_paired_asm ? up((size_t)n_general * (size_t)ns_stride * 4) : 0);
   if ((rc = c->entries.reserve(nh * (size_t)entry_stride * 4))) return rc;
   if (n_tab_haps && (rc = c->entries_tab.reserve(2 * nh * (size_t)entry_stride * 4))) return rc;   // + the next-special-column table
+  if (tab_paired && ((rc = c->entries_tab.reserve(nh * (size_t)entry_stride * 4)) || (rc = c->tabx.reserve(x_total)))) return rc;
   if ((rc = c->sums.reserve(n * 8))) return rc;
   if ((rc = c->misc.reserve(256))) return rc;
   if ((rc = c->carry.reserve((size_t)n_blocks * 2 * (6 * (size_t)carry_len + 64) * 8))) return rc;
@@ -680,6 +690,17 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   a.full_jobs = reinterpret_cast<const int32_t*>(dj + o_fj);
   a.full_count = c->misc.as<int32_t>() + 5;
   a.tab_group_start = reinterpret_cast<const int32_t*>(dj + o_tg);
+  unsigned char* dx = c->tabx.as<unsigned char>();
+  a.hap_ncls_out = nullptr; a.class_codes_out = nullptr; a.special_bits = nullptr; a.sb_stride = sb_stride;
+  a.job_notab = nullptr; a.job_ns = nullptr; a.ns_stride = ns_stride;
+  if (tab_paired) {
+    a.hap_ncls_out = dx + x_nc;
+    a.class_codes_out = reinterpret_cast<uint32_t*>(dx + x_cc);
+    a.special_bits = tab_paired_asm ? reinterpret_cast<uint64_t*>(dx + x_sb) : nullptr;
+    a.job_notab = dx + x_nt;
+    a.job_ns = reinterpret_cast<const int32_t*>(dx + x_ns);
+    PD_HIP_TRY(hipMemsetAsync(dx + x_nt, 0, (size_t)n_general, s));
+  }
 #ifdef GKL_PD_PROF
   a.prof = reinterpret_cast<unsigned long long*>(c->misc.as<char>() + 128);
 #endif
@@ -694,13 +715,44 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     x.entries = a.entries; x.entry_stride = entry_stride;
     x.lanes = reinterpret_cast<LaneSlot*>(dj + o_jl);
     x.job_flags = dj + o_jf;
+    x.hap_ncls = tab_paired ? dx + x_nc : nullptr;
+    x.job_notab = tab_paired ? dx + x_nt : nullptr;
     x.n_pairs = (int32_t)n; x.n_chunks = (int32_t)chunk_used.size(); x.n_striped = (int32_t)n_striped; x.rpl = kPdRpl;
     hipLaunchKernelGGL(pdhmm_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x);
     hipLaunchKernelGGL(pdhmm_collect_kernel, dim3((unsigned)((n_general + 255) / 256)), dim3(256), 0, s, dj + o_jf, dj + o_js, n_general,
-                       reinterpret_cast<int32_t*>(dj + o_fj), c->misc.as<int32_t>() + 5);
+                       reinterpret_cast<int32_t*>(dj + o_fj), c->misc.as<int32_t>() + 5, tab_paired ? dx + x_nt : nullptr,
+                       reinterpret_cast<int32_t*>(dx + x_hj), c->misc.as<int32_t>() + 6);
   }
   PD_HIP_TRY(hipEventRecord(c->ev0, s));
-  {
+  if (tab_paired) {
+    // table launch of the paired layout: the jobs' next-special-step tables first (part of the timed region: work only
+    // this route does), then every listed job that is clean and whose haplotypes all have at most kPdTabClasses classes
+    if (tab_paired_asm) {
+      PdJobNsArgs na;
+      na.lanes = a.lanes; na.job_steps = a.job_steps; na.job_striped = a.job_striped; na.job_flags = a.job_flags; na.job_notab = a.job_notab;
+      na.read_len = a.read_len; na.hap_len = a.hap_len; na.special_bits = a.special_bits; na.sb_stride = sb_stride;
+      na.job_ns = reinterpret_cast<int32_t*>(dx + x_ns); na.ns_stride = ns_stride; na.rpl = kPdRpl;
+      hipLaunchKernelGGL(pdhmm_job_special_kernel, dim3((unsigned)n_general), dim3(kLanes), (size_t)ns_stride, s, na);
+    }
+    PdArgs at = a;
+    at.n_cross_jobs = 0; at.n_jobs = n_general;
+    at.class_codes = a.class_codes_out;
+    at.next = c->misc.as<int32_t>() + 4;
+    if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_tab_paired_kernel<true>, dim3(std::min(n_general, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
+    else             hipLaunchKernelGGL(pdhmm_fwd_tab_paired_kernel<false>, dim3(std::min(n_general, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
+    // predicate launch: the (rare) clean packed jobs with an ineligible haplotype, from the list pdhmm_collect_kernel made
+    PdArgs ah = a;
+    ah.n_cross_jobs = 0; ah.n_jobs = 0;
+    ah.full_jobs = reinterpret_cast<const int32_t*>(dx + x_hj);
+    ah.full_count = c->misc.as<int32_t>() + 6;
+    if (c->fma_mode) hipLaunchKernelGGL((pdhmm_fwd_kernel<true, false, true>), dim3(std::min((int)n_packed, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
+    else             hipLaunchKernelGGL((pdhmm_fwd_kernel<false, false, true>), dim3(std::min((int)n_packed, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
+    PdArgs af = a;   // full launch: striped reads and haplotypes with odd bases
+    af.n_cross_jobs = 0; af.n_jobs = n_general;
+    af.next = c->misc.as<int32_t>() + 3;
+    if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(std::min(n_general, n_blocks)), dim3(64), 0, s, af, t.initial_condition);
+    else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(std::min(n_general, n_blocks)), dim3(64), 0, s, af, t.initial_condition);
+  } else {
     // table launch: cross jobs over the haplotypes with few column classes
     if (n_cross_tab > 0) {
       PdArgs at = a;
@@ -714,6 +766,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     ah.hap_order = a.hap_order + n_tab_haps;
     ah.n_cross_jobs = n_cross_hot;
     ah.n_jobs = n_cross_hot + (cross ? 0 : n_general);   // (cross layout: the listed jobs are striped reads, all the full kernel's)
+    ah.full_jobs = nullptr;   // walks every listed job and skips the flagged ones
     if (ah.n_jobs > 0) {
       if (c->fma_mode) hipLaunchKernelGGL((pdhmm_fwd_kernel<true, false, true>), dim3(std::min(ah.n_jobs, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
       else             hipLaunchKernelGGL((pdhmm_fwd_kernel<false, false, true>), dim3(std::min(ah.n_jobs, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
@@ -744,11 +797,11 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   }
   PD_HIP_TRY(hipEventRecord(c->ev1, s));
   PD_HIP_TRY(hipGetLastError());
-  if ((rc = c->sums_pin.reserve(n * 8 + 16))) return rc;
+  if ((rc = c->sums_pin.reserve(n * 8 + 64))) return rc;
   double* sums = c->sums_pin.as<double>();
   int32_t* status = reinterpret_cast<int32_t*>(sums + n);
   PD_HIP_TRY(hipMemcpyAsync(sums, c->sums.p, n * 8, hipMemcpyDeviceToHost, s));
-  PD_HIP_TRY(hipMemcpyAsync(status, c->misc.p, 8, hipMemcpyDeviceToHost, s));
+  PD_HIP_TRY(hipMemcpyAsync(status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
   const double ms_launched = ms_since(t_begin);
   PD_HIP_TRY(hipStreamSynchronize(s));
   PD_HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
@@ -764,6 +817,12 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   if (timing)
     fprintf(stderr, "[gklhip] pdhmm call: uploads enqueued %.2f ms, jobs built %.2f, routed %.2f, launched %.2f, synchronised %.2f (kernels %.2f ms), %zu pairs\n",
             ms_uploads, ms_jobs, ms_routing, ms_launched, ms_since(t_begin), (double)c->last_ms, n);
+  if (!cross) {   // paired layout: packed jobs by kernel (status[5] = the full launch's list, the striped jobs included; [6] = the predicate launch's)
+    const int32_t n_full_packed = status[5] - (int32_t)n_striped, n_hot = tab_paired ? status[6] : (int32_t)n_packed - n_full_packed;
+    c->last_routing[0] = tab_paired ? (int32_t)n_packed - n_hot - n_full_packed : 0;
+    c->last_routing[1] = n_hot;
+    c->last_routing[2] = n_full_packed;
+  }
   if (status[0] != 0)  // PDHMM_INPUT_DATA_ERROR (pdhmm-serial.cc:183-199): negative ins / del / gcp quality
     return pd_fail(GKLHIP_ERR_INVALID_ARG, "Error while calculating pdhmm. Input arrays aren't valid.");
   auto finalise = [&](size_t lo, size_t hi) {

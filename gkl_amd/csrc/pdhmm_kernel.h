@@ -133,6 +133,19 @@ struct PdArgs {
   // them costs a millisecond of contended atomics
   const int32_t* full_jobs;
   const int32_t* full_count;
+  // paired layout through the table kernel (every pair has its own haplotype item): nothing about the haplotypes is
+  // known on the host (scanning a haplotype per PAIR there is ~100 MB for 400k pairs), so pdhmm_entries_kernel discovers
+  // each item's column classes itself (hap_ncls_out != NULL: 0 = not eligible -- more than kPdTabClasses classes or a
+  // base outside ACGTN -- and the class match bits, like the host's lists of the cross layout) and leaves a bitmap of
+  // its special columns; pdhmm_expand_kernel marks the listed jobs that hold a pair with an ineligible haplotype
+  // (job_notab), pdhmm_job_special_kernel merges the bitmaps of a job's pairs into the job's next-special-STEP table.
+  uint8_t* hap_ncls_out;
+  uint32_t* class_codes_out;    // [n_hap_items * 8]
+  uint64_t* special_bits;       // [n_hap_items * sb_stride]: bit j % 64 of word j / 64 = column j is special
+  int32_t sb_stride;
+  const uint8_t* job_notab;     // [listed jobs]
+  const int32_t* job_ns;        // [listed jobs * ns_stride]: first step >= t at which some lane of the job sits on a special column
+  int32_t ns_stride;
 #ifdef GKL_PD_PROF
   unsigned long long* prof;     // development build: cycle and step counters of the table kernel
 #endif
@@ -158,11 +171,15 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
   uint32_t* e = a.entries + (int64_t)p * a.entry_stride;
   e[lane] = kPdIdle;
   e += kLanes;
-  const int ncls = a.hap_ncls ? (int)a.hap_ncls[p] : 0;
-  uint32_t* et = ncls ? a.entries_tab + (int64_t)p * a.entry_stride : nullptr;
+  // discover: the class list is not given (cross layout: the host's, one common list per call where it fits) but found
+  // here, in order of first occurrence (paired layout, see PdArgs::hap_ncls_out)
+  const bool discover = a.hap_ncls_out != nullptr;
+  int ncls = discover ? 0 : (a.hap_ncls ? (int)a.hap_ncls[p] : 0);
+  uint32_t* et = (ncls || discover) ? a.entries_tab + (int64_t)p * a.entry_stride : nullptr;
   uint32_t codes[kPdTabClasses];
 #pragma unroll
-  for (int c = 0; c < kPdTabClasses; c++) codes[c] = ncls ? a.class_codes[(int64_t)p * 8 + c] : 0u;
+  for (int c = 0; c < kPdTabClasses; c++) codes[c] = (ncls && !discover) ? a.class_codes[(int64_t)p * 8 + c] : 0u;
+  bool too_many = false;
   if (et) { et[lane] = kPdTabIdle; et += kLanes; }
   int carry = -1;  // key of the last flagged column of the tiles before this one
   int first_flagged = H;  // first column with DEL_START / DEL_END (H: none)
@@ -182,20 +199,39 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
     if (lane == 0) excl = -1;
     if (carry > excl) excl = carry;
     const uint32_t state = excl < 0 ? 0u : ((excl & 1) ? ((excl >> 1) == j - 1 ? 2u : 0u) : 1u);
-    if (valid) {
-      const uint32_t yb = (uint32_t)hb[j] & 0xffu, hot = pd_onehot_acgt(yb);
-      has_odd |= hot == 0u && yb != (uint32_t)'N';
-      const uint32_t allele = (flags & kPdSnp) ? ((flags >> 3) & 0xfu) : 0u;
-      const bool is_n = yb == (uint32_t)'N';
-      const uint32_t code = (hot << 20) | (allele << 24) | (1u << 28) | (is_n ? 1u << 29 : 0u);
-      const uint32_t special = (state != 0u || (flags & kPdDelEnd) != 0u) ? kPdSpecial : 0u;
-      e[j] = yb | (flags << 8) | (state << 16) | (state << 18) | code | ((hot == 0u && !is_n) ? kPdOdd : 0u) | special;
-      if (et) {
-        uint32_t cls = 0;
+    const uint32_t yb = valid ? ((uint32_t)hb[j] & 0xffu) : (uint32_t)'A', hot = pd_onehot_acgt(yb);
+    const bool is_n = yb == (uint32_t)'N';
+    const uint32_t allele = (flags & kPdSnp) ? ((flags >> 3) & 0xfu) : 0u;
+    const uint32_t code = (hot << 20) | (allele << 24) | (1u << 28) | (is_n ? 1u << 29 : 0u);
+    const uint32_t special = (valid && (state != 0u || (flags & kPdDelEnd) != 0u)) ? kPdSpecial : 0u;
+    uint32_t cls = 0;
+    if (discover) {
+      int mine = -1;
 #pragma unroll
-        for (int c = 1; c < kPdTabClasses; c++) cls = codes[c] == code ? (uint32_t)c : cls;  // (the host listed every code of the haplotype)
-        et[j] = cls * (uint32_t)kPdTabClassBytes | (special ? kPdTabSpecial : 0u) | (state << 16) | ((flags & kPdDelEnd) ? kPdTabDelEnd : 0u);
+      for (int c = 0; c < kPdTabClasses; c++) mine = (c < ncls && codes[c] == code) ? c : mine;
+      uint64_t pend = __ballot(valid && mine < 0);
+      while (pend != 0 && ncls < kPdTabClasses) {   // the first column without a class names the next one
+        const uint32_t cn = (uint32_t)__shfl((int)code, __builtin_ctzll(pend), kLanes);
+#pragma unroll
+        for (int c = 0; c < kPdTabClasses; c++) codes[c] = c == ncls ? cn : codes[c];
+        if (valid && mine < 0 && code == cn) mine = ncls;
+        ncls++;
+        pend = __ballot(valid && mine < 0);
       }
+      too_many |= pend != 0;
+      cls = mine < 0 ? 0u : (uint32_t)mine;
+    } else {
+#pragma unroll
+      for (int c = 1; c < kPdTabClasses; c++) cls = codes[c] == code ? (uint32_t)c : cls;  // (the host listed every code of the haplotype)
+    }
+    if (valid) {
+      has_odd |= hot == 0u && !is_n;
+      e[j] = yb | (flags << 8) | (state << 16) | (state << 18) | code | ((hot == 0u && !is_n) ? kPdOdd : 0u) | special;
+      if (et) et[j] = cls * (uint32_t)kPdTabClassBytes | (special ? kPdTabSpecial : 0u) | (state << 16) | ((flags & kPdDelEnd) ? kPdTabDelEnd : 0u);
+    }
+    if (a.special_bits) {
+      const uint64_t sp = __ballot(special != 0u);
+      if (lane == 0) a.special_bits[(int64_t)p * a.sb_stride + (base >> 6)] = sp;
     }
     const uint64_t fl = __ballot(flagged);
     if (fl && first_flagged == H) first_flagged = base + __builtin_ctzll(fl);
@@ -204,7 +240,7 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
   }
   // Table haplotypes: per column the next special column at or behind it (a suffix minimum, tiles back to front) -- the
   // table kernel reads the length of a run of plain steps off it with one scalar load instead of balloting every step.
-  if (et) {
+  if (et && a.next_special) {
     int32_t* ns = a.next_special + (int64_t)p * a.entry_stride;
     int32_t behind = 0x7fffffff;
     for (int base = H > 0 ? ((H - 1) / kLanes) * kLanes : -1; base >= 0; base -= kLanes) {
@@ -237,7 +273,13 @@ __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
     if (et) et[j] = kPdTabIdle;
   }
   // a haplotype with an odd column says so in its first (idle) word: its jobs run the byte-comparing steps throughout
-  if (__ballot(has_odd) != 0 && lane == 0) e[-kLanes] = kPdIdle | kPdOdd;
+  const bool any_odd = __ballot(has_odd) != 0;
+  if (any_odd && lane == 0) e[-kLanes] = kPdIdle | kPdOdd;
+  if (discover && lane == 0) {
+    a.hap_ncls_out[p] = (too_many || any_odd) ? (uint8_t)0 : (uint8_t)ncls;
+#pragma unroll
+    for (int c = 0; c < kPdTabClasses; c++) a.class_codes_out[(int64_t)p * 8 + c] = codes[c];   // (unused classes: match bits 0 = never a match)
+  }
 }
 
 // Paired layout: the host packs the pairs into chunks in compact form (pairhmm_plan.h pack_reads_place: chunk and
@@ -253,6 +295,8 @@ struct PdExpandArgs {
   int32_t entry_stride;
   LaneSlot* lanes;              // listed jobs' lane rows; chunk c is job n_striped + c
   uint8_t* job_flags;
+  const uint8_t* hap_ncls;      // table route of the paired layout (else NULL): per haplotype item, 0 = not eligible
+  uint8_t* job_notab;           // ... -> its job is not the table kernel's
   int32_t n_pairs, n_chunks, n_striped, rpl;
 };
 __global__ __launch_bounds__(256) void pdhmm_expand_kernel(PdExpandArgs a) {
@@ -264,6 +308,7 @@ __global__ __launch_bounds__(256) void pdhmm_expand_kernel(PdExpandArgs a) {
       LaneSlot* dst = a.lanes + (int64_t)(a.n_striped + ch) * kLanes + a.place_lane[i];
       for (int b = 0; b < nb; b++) dst[b] = LaneSlot{i, b};
       if (a.entries[(int64_t)i * a.entry_stride] & kPdOdd) a.job_flags[a.n_striped + ch] = 1;
+      if (a.hap_ncls && a.hap_ncls[i] == 0) a.job_notab[a.n_striped + ch] = 1;
     }
   }
   if (i < a.n_chunks) {
@@ -272,11 +317,70 @@ __global__ __launch_bounds__(256) void pdhmm_expand_kernel(PdExpandArgs a) {
   }
 }
 
-// the flagged packed jobs, appended to the full launch's list (one thread per listed job)
+// the flagged packed jobs, appended to the full launch's list (one thread per listed job); with the table route of the
+// paired layout, the clean packed jobs that are not the table kernel's likewise to the predicate launch's list
 __global__ __launch_bounds__(256) void pdhmm_collect_kernel(const uint8_t* job_flags, const uint8_t* job_striped, int n_general,
-                                                           int32_t* full_jobs, int32_t* full_count) {
+                                                           int32_t* full_jobs, int32_t* full_count, const uint8_t* job_notab,
+                                                           int32_t* hot_jobs, int32_t* hot_count) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < n_general && job_flags[j] && !job_striped[j]) full_jobs[atomicAdd(full_count, 1)] = j;
+  if (j >= n_general || job_striped[j]) return;
+  if (job_flags[j]) full_jobs[atomicAdd(full_count, 1)] = j;
+  else if (job_notab && job_notab[j]) hot_jobs[atomicAdd(hot_count, 1)] = j;
+}
+
+// Table route of the paired layout: the lanes of a job sit on different haplotypes, so "is some lane on a special column"
+// is a property of the job's STEP, not of a haplotype's column.  One wavefront per listed job: the special columns of
+// every pair in it (bitmaps of pdhmm_entries_kernel) are smeared over the steps at which the pair's lanes meet them
+// (column c reaches row block k at step c + k) and the suffix minimum of the marked steps becomes the table the whole-job
+// program (pd_job_asm with top = 0) switches between plain and general steps on.
+struct PdJobNsArgs {
+  const LaneSlot* lanes;
+  const int32_t* job_steps;
+  const uint8_t *job_striped, *job_flags, *job_notab;
+  const int64_t *read_len, *hap_len;   // per pair
+  const uint64_t* special_bits;
+  int32_t sb_stride;
+  int32_t* job_ns;
+  int32_t ns_stride, rpl;
+};
+__global__ __launch_bounds__(64) void pdhmm_job_special_kernel(PdJobNsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pd_step_marks[];   // ns_stride bytes
+  const int j = blockIdx.x, lane = threadIdx.x;
+  if (a.job_striped[j] || a.job_flags[j] || a.job_notab[j]) return;
+  const int n = a.job_steps[j] + 8;   // the program looks at most three steps past the job's last one
+  for (int t = lane * 4; t < n; t += kLanes * 4) *reinterpret_cast<uint32_t*>(pd_step_marks + t) = 0u;
+  __syncthreads();
+  const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
+  uint64_t heads = __ballot(sl.read >= 0 && sl.block == 0);
+  while (heads) {
+    const int p = __shfl(sl.read, __builtin_ctzll(heads), kLanes);
+    heads &= heads - 1;
+    const int nb = ((int)a.read_len[p] + a.rpl) / a.rpl;
+    const int H = (int)a.hap_len[p];
+    for (int w = lane; w * 64 < H; w += kLanes) {
+      uint64_t bits = a.special_bits[(int64_t)p * a.sb_stride + w];
+      while (bits) {
+        const int c = w * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        for (int k = 0; k < nb; k++) pd_step_marks[c + k] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  int32_t* ns = a.job_ns + (int64_t)j * a.ns_stride;
+  int32_t behind = 0x7fffffff;
+  for (int base = ((n - 1) / kLanes) * kLanes; base >= 0; base -= kLanes) {
+    const int t = base + lane;
+    int32_t v = (t < n && pd_step_marks[t]) ? t : 0x7fffffff;
+#pragma unroll
+    for (int dd = 1; dd < kLanes; dd <<= 1) {
+      const int32_t o = __shfl_down(v, dd, kLanes);
+      if (lane + dd < kLanes && o < v) v = o;
+    }
+    if (behind < v) v = behind;
+    if (t < n) ns[t] = v;
+    behind = __shfl(v, 0, kLanes);
+  }
 }
 
 // 2: the whole haplotype job as one asm program (pd_job_asm); 1: asm runs of plain steps inside the C++ loops
@@ -723,7 +827,7 @@ struct PdJob {
         // Steps top .. H-1: every lane is inside its haplotype.  No special column in [t - top, t + 2] <=> the next
         // special column at or behind t - top lies beyond t + 2; the run of plain steps ends two steps before it reaches
         // the first lane (the lead-in of the general steps).
-        if (t >= top && t + 4 <= H && !(s0 || s1 || s2)) {
+        if (ns != nullptr && t >= top && t + 4 <= H && !(s0 || s1 || s2)) {
 #ifdef GKL_PD_TIMING_NOSPECIAL
           const int32_t c = 0x7fffffff;
 #else
@@ -747,7 +851,7 @@ struct PdJob {
       }
       PD_PROF_MARK(0)
       // (with the asm run: the C++ plain loops stop where every lane has started, so that the asm run takes over from there)
-      const int lim = (kTab && FMA && GKL_PD_ASM == 1 && t < top && top + 4 <= H) ? top : n_steps;
+      const int lim = (kTab && FMA && GKL_PD_ASM == 1 && ns != nullptr && t < top && top + 4 <= H) ? top : n_steps;
       if (kTab && GKL_PD_TAB_UNROLL) {
         // plain steps two at a time, the d / r roles alternating (see step_plain); no way out between the two, or the
         // compiler restores the roles with copies on the main path
@@ -861,7 +965,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
     int j = 0;
     if (lane == 0) j = atomicAdd(a.next, 1);
     j = __builtin_amdgcn_readfirstlane(j);
-    const bool listed_by_index = !kHot && a.full_jobs != nullptr;  // the full launch: its listed jobs come from full_jobs
+    const bool listed_by_index = a.full_jobs != nullptr;  // the launch's listed jobs come from a list (the full launch; the predicate launch beside a paired table launch)
     if (j >= (listed_by_index ? a.n_cross_jobs + a.full_count[0] : a.n_jobs)) break;
     if (j < a.n_cross_jobs) {
       const int k = j / a.n_chunks_cross, chunk = j - k * a.n_chunks_cross;
@@ -985,6 +1089,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
     atomicMax(a.prof + 14, now);
   }
 #endif
+}
+
+// The table launch of the PAIRED layout (computePDHMMNative: every pair its own haplotype item): a unit of work is a
+// listed job -- up to 64 lanes of whole pairs, each lane streaming its OWN pair's table-format entries and fetching its
+// priors from the class table it built from its own haplotype's class list.  The same whole-job program as the cross
+// layout's: its entry address is a uniform base plus a per-lane byte offset, and with top = 0 its mode switch reads a table
+// indexed by STEP -- the job's next-special-step table (pdhmm_job_special_kernel).  Walks every listed job and leaves the
+// striped ones, those with a base outside ACGTN and those with an ineligible haplotype to the other two launches.
+template <bool FMA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pdhmm_fwd_tab_paired_kernel(PdArgs a, double init_condition) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kPdTabClasses * kPdTabClassBytes];
+  const int lane = threadIdx.x;
+  using Job = PdJob<FMA, false, true, true>;
+  Job job;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+  for (;;) {
+    int j = 0;
+    if (lane == 0) j = atomicAdd(a.next, 1);
+    j = __builtin_amdgcn_readfirstlane(j);
+    if (j >= a.n_jobs) break;
+    if (a.job_striped[j] != 0 || a.job_flags[j] != 0 || a.job_notab[j] != 0) continue;
+    const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
+    const bool active = sl.read >= 0;
+    const int p = active ? sl.read : a.job_pair[j];
+    const int n_blocks = ((int)a.read_len[p] + Job::RPL) / Job::RPL;
+    const int H = (int)a.hap_len[p];
+    job.setup(a, p, sl.block, n_blocks, active, init_condition / (double)H);
+    job.build_table(lds_base, lane, a.class_codes + (int64_t)p * 8, kPdTabClasses);
+    const int64_t first = (int64_t)p * a.entry_stride + kLanes - sl.block;   // block k of a pair sees column j at step j + k
+    if constexpr (FMA && GKL_PD_ASM == 2)
+      pd_job_asm(job, a.entries_tab, (uint32_t)(first * 4), a.job_steps[j], 0, a.job_ns + (int64_t)j * a.ns_stride);
+    else
+      job.run_packed(a.entries_tab + first, a.job_steps[j], false);
+    if (job.holds_last) a.sums[p] = job.sum;
+  }
 }
 
 // Self-test of the assumption behind kPdTabIdle (run once per process and device by gklhip_pdhmm_init): a workgroup with the

@@ -489,7 +489,8 @@ class PdhmmContext:
         return float(self.lib.gklhip_pdhmm_last_kernel_ms(self.handle))
 
     def last_routing(self):
-        """Haplotypes of the last cross call by kernel: (LDS prior table, predicate, byte-comparing)."""
+        """Last cross call: its haplotypes by kernel (LDS prior table, predicate, byte-comparing); last paired call: its
+        packed jobs (wavefront-loads of whole pairs) by kernel."""
         out = (C.c_int32 * 3)()
         st = self.lib.gklhip_pdhmm_last_routing(self.handle, out)
         if st != OK:

@@ -92,7 +92,9 @@ int64_t gklhip_pdhmm_reference_batch_pairs(int32_t max_memory_mb, int32_t max_re
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* ctx);
 /* Diagnostics: how the last cross call's haplotypes were routed: out[0] to the table kernel (at most six classes of
  * (base, SNP alleles, 'N') columns: the match priors come from an LDS table), out[1] to the predicate kernel, out[2] to
- * the byte-comparing kernel (a base outside ACGTN).  All zero after a paired call.  GKL_HIP_PDHMM_TABLE=0 disables the
+ * the byte-comparing kernel (a base outside ACGTN).  After a paired call (gklhip_pdhmm_compute; every pair its own haplotype
+ * item, classes and routing found on the device): the call's packed jobs -- wavefront-loads of whole pairs -- by kernel in
+ * the same order (a job is the table kernel's when all its haplotypes are eligible).  GKL_HIP_PDHMM_TABLE=0 disables the
  * table kernel.  Results are identical whichever kernel computes a pair. */
 int gklhip_pdhmm_last_routing(gklhip_pdhmm_ctx* ctx, int32_t out[3]);
 int gklhip_pdhmm_done(gklhip_pdhmm_ctx* ctx);

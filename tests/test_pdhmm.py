@@ -534,6 +534,114 @@ def test_pdhmm_gpu_table_kernel_haplotype_groups(pd_ctx, pd_oracle):
 
 
 @pytest.mark.gpu
+def test_pdhmm_gpu_paired_table_route_and_parity(pd_ctx, pd_oracle, monkeypatch):
+    # computePDHMMNative's layout (every pair its own haplotype item) through the table kernel: the column classes, the
+    # special columns and the routing of the packed jobs are found on the DEVICE.  Pairs over eligible haplotypes (at
+    # most six classes), ineligible ones (seven or more: predicate kernel) and ones with bases outside ACGTN
+    # (byte-comparing kernel), interleaved so that jobs of all three kinds arise -- and one job never mixes kernels
+    # silently: the bits are the oracle's whichever launch computed a pair.
+    rng = np.random.RandomState(4242)
+    acgt = np.frombuffer(b"ACGT", dtype=np.int8)
+
+    def hap(kind):
+        H = int(rng.randint(60, 260))
+        b = acgt[rng.randint(0, 4, H)].copy()
+        pd = np.zeros(H, np.int8)
+        n_snp = {"tab": int(rng.randint(0, 3)), "many": 4, "odd": 1}[kind]
+        for k in range(n_snp):
+            alleles = [3, 5, 9, 6][k]
+            for j in rng.choice(np.arange(2, H - 2), 2, replace=False):
+                b[j] = acgt[k % 4]
+                pd[j] = 1 | alleles << 3
+        if kind == "odd":
+            b[int(rng.randint(0, H))] = ord("r")
+        if rng.random_sample() < 0.8:
+            j = int(rng.randint(3, H - 12))
+            pd[j] |= 2
+            pd[j + int(rng.randint(1, 9))] |= 4
+        if rng.random_sample() < 0.2:
+            pd[0] |= int(rng.choice([2, 4]))
+        if rng.random_sample() < 0.2:
+            pd[H - 1] |= int(rng.choice([2, 4, 6]))
+        return b, pd
+
+    src = random_pd_batch(rng, 600, read_len=(1, 150), hap_len=(1, 2))
+    n1 = src.batch
+    rr = lambda a, r: a.reshape(n1, src.max_read_len)[r, :int(src.read_lengths[r])]  # noqa: E731
+    # blocks of 120 pairs of one kind: the packing window (192 pairs, sorted by haplotype length) then yields jobs that
+    # are purely of one kind as well as mixed ones
+    kinds = ["tab"] * 240 + ["many"] * 60 + ["tab"] * 120 + ["odd"] * 60 + ["tab"] * 120
+    pairs = []
+    for r, kind in enumerate(kinds):
+        hb, hp = hap(kind)
+        pairs.append((hb, hp, rr(src.read_bases, r), rr(src.read_qual, r), rr(src.read_ins_qual, r), rr(src.read_del_qual, r), rr(src.gcp, r)))
+    b = PdhmmBatch.from_pairs(pairs)
+    got = pd_ctx.compute(b)
+    tab, pred, full = pd_ctx.last_routing()
+    assert tab > 0 and pred > 0 and full > 0, (tab, pred, full)
+    st, vec = pd_oracle.compute(b, semantics=pd_ctx.sem)
+    assert st == 0 and got.tobytes() == vec.tobytes()
+    # only eligible haplotypes: every packed job is the table kernel's
+    only = b.subset(np.array([i for i, k in enumerate(kinds) if k == "tab"]))
+    got = pd_ctx.compute(only)
+    tab, pred, full = pd_ctx.last_routing()
+    assert tab > 0 and pred == 0 and full == 0, (tab, pred, full)
+    assert got.tobytes() == vec[[i for i, k in enumerate(kinds) if k == "tab"]].tobytes()
+    # the same pairs with the table route switched off (GKL_HIP_PDHMM_TABLE=0: predicate kernel) and through the all-C++
+    # cross-check build of the table kernel (ballots on the lanes' own entries instead of the job's next-special-step table)
+    import os
+    from gkl_amd import native
+    cxx = os.path.join(os.path.dirname(native.PDHMM_LIB_PATH), "libgklhip_pdhmm_cxx.so")
+    with native.PdhmmContext(fma_mode=pd_ctx.fma_mode, reference_tail=False, lib_path=cxx) as c:
+        assert c.compute(b).tobytes() == vec.tobytes()
+        assert c.last_routing()[0] > 0
+    monkeypatch.setenv("GKL_HIP_PDHMM_TABLE", "0")
+    with native.PdhmmContext(fma_mode=pd_ctx.fma_mode, reference_tail=False) as c:
+        assert c.compute(b).tobytes() == vec.tobytes()
+        assert c.last_routing()[0] == 0 and c.last_routing()[1] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_pdhmm_gpu_paired_table_route_flags_anywhere(pd_ctx, pd_oracle, seed):
+    # The whole-job program on jobs whose lanes sit on DIFFERENT haplotypes: it switches between plain and general
+    # steps on the job's next-special-step table, so special columns of one pair force general steps on its wavefront
+    # mates.  Deletion flags on first / last columns, both on one column, dense and unbalanced, haplotypes of 1..300
+    # columns next to each other, one-base reads; at most six classes everywhere (all table jobs).
+    rng = np.random.RandomState(2000 + seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.int8)
+    src = random_pd_batch(rng, 500, read_len=(1, 130), hap_len=(1, 2))
+    n1 = src.batch
+    rr = lambda a, r: a.reshape(n1, src.max_read_len)[r, :int(src.read_lengths[r])]  # noqa: E731
+    pairs = []
+    for k in range(n1):
+        H = int(rng.choice([1, 2, 3, 5, 17, 40, 64, 65, 130, 257])) if k % 3 == 0 else int(rng.randint(1, 300))
+        hb = acgt[rng.randint(0, 4, H)].copy()
+        pd = np.zeros(H, np.int8)
+        rate = [0.0, 0.02, 0.1, 0.4][k % 4]
+        for j in range(H):
+            if rng.rand() < rate:
+                pd[j] |= int(rng.choice([2, 4, 6]))
+        if k % 3 == 0:
+            pd[0] |= int(rng.choice([2, 4, 6]))
+        if k % 5 == 0:
+            pd[H - 1] |= int(rng.choice([2, 4, 6]))
+        if k % 7 == 0 and H > 1:
+            pd[1] |= 4
+        if k % 2 == 0 and H > 6:
+            for j in rng.choice(np.arange(H), 2, replace=False):
+                hb[j] = acgt[1]
+                pd[j] |= 1 | (5 << 3)
+        pairs.append((hb, pd, rr(src.read_bases, k), rr(src.read_qual, k), rr(src.read_ins_qual, k), rr(src.read_del_qual, k), rr(src.gcp, k)))
+    b = PdhmmBatch.from_pairs(pairs)
+    got = pd_ctx.compute(b)
+    tab, pred, full = pd_ctx.last_routing()
+    assert tab > 0 and pred == 0 and full == 0, (tab, pred, full)
+    st, vec = pd_oracle.compute(b, semantics=pd_ctx.sem)
+    assert st == 0 and got.tobytes() == vec.tobytes()
+
+
+@pytest.mark.gpu
 def test_pdhmm_gpu_paired_large_batch_by_replication(pd_ctx, pd_oracle):
     # The paired entry point at a size no other test reaches: inputs past the pinned staging block (direct copies from a
     # helper thread), the packing expanded and routed on the device, job arrays past their staging block, threaded
@@ -545,6 +653,8 @@ def test_pdhmm_gpu_paired_large_batch_by_replication(pd_ctx, pd_oracle):
     reps = 9
     big = b1.subset(np.tile(np.arange(b1.batch), reps))
     got = pd_ctx.compute(big).reshape(reps, -1)
+    tab, pred, full = pd_ctx.last_routing()
+    assert tab > 0 and pred == 0 and full == 0, (tab, pred, full)   # real PD haplotypes: every job is the table kernel's
     for k in range(reps):
         assert got[k].tobytes() == base.tobytes(), k
 
