@@ -24,6 +24,7 @@
 #include <string>
 #include <thread>
 #include <deque>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/gkl_hip_pairhmm.h"
@@ -111,6 +112,13 @@ struct DevCtx {
   gklhip_config cfg;
   int device = 0;
   int n_cus = 256;
+  int n_xcds = 8;   // hipDeviceAttributeNumberOfXccs: workgroups go to the XCDs round-robin by index
+  // development / cross-check switches, read from the environment ONCE per context (dev_init), never on a call path
+  // (getenv is not safe against a concurrent setenv in the host JVM): GKLHIP_ASM_GENERAL=0 (round-3 arrangement: C++
+  // general steps), GKLHIP_SPECULATE_FP64=1 (fp64 beside fp32 for a lone tiny call)
+  int asm_general = 1;
+  int speculate_fp64 = 0;
+  int lds_oob_zero = 1;   // dev_init's self-test: a DS read beyond the allocation returns 0 here (the fp32 programs' separator priors)
   hipStream_t stream = nullptr;
   // tables
   DevBuf tab32, tab64;
@@ -383,12 +391,11 @@ void launch_pair_policy(const FwdArgs<double>& d, const PairPolicyArgs& q, int r
 // `alone`: nothing else is on the device -- the fp64 recomputation of every pair runs beside its fp32 recurrence
 // (pairhmm_pair_spec_kernel) and the call takes max(fp32, fp64) instead of fp32 + fp64
 void launch_pair_fused(const FwdArgs<float>& f, const FwdArgs<double>& d, const PairPolicyArgs& q, int rows, int fma, int64_t n_pairs,
-                       hipStream_t s, bool alone = false) {
-  // Opt-in (GKLHIP_SPECULATE_FP64=1; read per call): it pays when a good share of the pairs fails the policy (100 x 10 with
+                       hipStream_t s, bool speculate = false) {
+  // Opt-in (GKLHIP_SPECULATE_FP64=1, read when the context is made, and only for a call that is alone on the device): it pays when a good share of the pairs fails the policy (100 x 10 with
   // 16 % failing: 0.151 -> 0.130 ms per call) and costs when none does (0.100 -> 0.130: the fp64 wavefront of a pair takes
   // twice as long as its fp32 one) -- and real active regions are mostly of the second kind.
-  const char* spec_env = getenv("GKLHIP_SPECULATE_FP64");
-  if (alone && spec_env && atoi(spec_env) != 0) {
+  if (speculate) {
     const dim3 grid((unsigned)n_pairs), block(128);
     if (fma) hipLaunchKernelGGL((pairhmm_pair_spec_kernel<kRplF64, true>), grid, block, 0, s, f, d, q);
     else     hipLaunchKernelGGL((pairhmm_pair_spec_kernel<kRplF64, false>), grid, block, 0, s, f, d, q);
@@ -642,7 +649,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
 
   // XCD-aware grid of the streaming kernels (fwd_stream_block): a chunk's jobs all land on one XCD
   static const bool xcd_env = [] { const char* v = getenv("GKLHIP_XCD_AWARE"); return !v || atoi(v) != 0; }();
-  const int chunk_stride = (xcd_env && plan.n_chunks >= 64) ? ((plan.n_chunks + 7) & ~7) : plan.n_chunks;
+  // (c->n_xcds: what the device reports -- 8 on an MI355X in SPX mode; a partitioned device shows fewer and gets no padding it cannot use)
+  const int xq = c->n_xcds;
+  const int chunk_stride = (xcd_env && xq > 1 && plan.n_chunks >= 64) ? (plan.n_chunks + xq - 1) / xq * xq : plan.n_chunks;
   auto fill_common = [&](auto& a) {
     a.b = b;
     a.stream = stream_grouped;
@@ -658,8 +667,9 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     a.jobs = c->jobs.as<FwdJob>();
     a.job_count = c->counters.as<int32_t>() + 2;
     a.job_next = c->counters.as<int32_t>() + 3;
-    const char* ag = getenv("GKLHIP_ASM_GENERAL");   // (read per call: the parity tests switch it)
-    a.asm_general = ag ? atoi(ag) : 1;
+    // the fp32 programs fetch a separator lane's priors from beyond the LDS allocation: only where that reads 0 (dev_init)
+    constexpr bool is_f32 = std::is_same<typename std::decay<decltype(a)>::type, FwdArgs<float>>::value;
+    a.asm_general = (c->asm_general && (!is_f32 || c->lds_oob_zero)) ? 1 : 0;
   };
 
   FinalizeArgs fa;
@@ -758,7 +768,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       const int rows = plan.max_read_len <= 2 * kLanes - 1 ? 2 : plan.max_read_len <= 4 * kLanes - 1 ? 4 : kRplF64;
       if (deferred_launch) {
         SmallCall& k = defer->call;
-        k.d = d; k.q = q; k.rows = rows; k.n_pairs = (int32_t)n_pairs; k.fma = fma;
+        k.d = d; k.q = q; k.rows = rows; k.n_pairs = (int32_t)n_pairs; k.fma = fma; k.speculate = c->speculate_fp64;
         memcpy(hs + L.desc, &k, sizeof k);  // nothing has been launched yet: the block is still ours to write
         defer->desc_pinned = reinterpret_cast<const SmallCall*>(hs_dev + L.desc);
         defer->desc_dev = reinterpret_cast<const SmallCall*>(dp + L.desc);
@@ -771,7 +781,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       }
       if (ev) HIP_TRY(hipEventRecord(c->ev[3], s));
       if (fused_call) {
-        launch_pair_fused(a, d, q, rows, fma, n_pairs, s, g_host_calls_in_flight.load(std::memory_order_relaxed) <= 1);
+        launch_pair_fused(a, d, q, rows, fma, n_pairs, s, c->speculate_fp64 && g_host_calls_in_flight.load(std::memory_order_relaxed) <= 1);
       } else if (n_pairs > kTwoStepFrom) {
         if ((rc = c->fail_order.reserve((size_t)n_pairs * 4))) return rc;
         launch_pair_policy_two_step(d, q, rows, fma, n_pairs, c->fail_order.as<int32_t>(), s);
@@ -945,6 +955,11 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
   c->cfg = cfg;
   c->device = dev;
   c->n_cus = std::max(1, prop.multiProcessorCount);
+  {
+    int xccs = 0;
+    if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess) { (void)hipGetLastError(); xccs = 8; }
+    c->n_xcds = std::max(1, std::min(xccs, 64));
+  }
   memset(&c->stats, 0, sizeof c->stats);
   int rc = GKLHIP_OK;
   auto bail = [&](int status) { dev_done(c); return status; };
@@ -955,19 +970,42 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
     static std::vector<int> checked;   // 0 unknown, 1 good, -1 bad
     std::lock_guard<std::mutex> l(mu);
     if ((int)checked.size() <= dev) checked.resize((size_t)dev + 1, 0);
-    if (checked[(size_t)dev] == 0) {
+    static std::vector<int> oob_checked;   // the same for "a DS read beyond the LDS allocation returns 0"
+    if ((int)oob_checked.size() <= dev) oob_checked.resize((size_t)dev + 1, 0);
+    if (checked[(size_t)dev] == 0 || oob_checked[(size_t)dev] == 0) {
       uint32_t* d_out = nullptr;
-      uint32_t h_out[2] = {1u, 1u};
-      if (hipMalloc(reinterpret_cast<void**>(&d_out), 8) != hipSuccess) return bail(fail(GKLHIP_ERR_OOM, "hipMalloc failed"));
+      uint32_t h_out[3] = {1u, 1u, 1u};
+      if (hipMalloc(reinterpret_cast<void**>(&d_out), 12) != hipSuccess) return bail(fail(GKLHIP_ERR_OOM, "hipMalloc failed"));
       float f_den; double d_den;
       { const uint32_t fb = 1u; memcpy(&f_den, &fb, 4); const uint64_t db = 0x0000000100000001ull; memcpy(&d_den, &db, 8); }
+      bool ok = hipMemsetAsync(d_out, 0, 12, c->stream) == hipSuccess;
       hipLaunchKernelGGL(flush_selftest_kernel, dim3(1), dim3(1), 0, c->stream, d_out, f_den, d_den);
-      const bool ok = hipMemcpyAsync(h_out, d_out, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+      hipLaunchKernelGGL(lds_oob_selftest_kernel, dim3(1024), dim3(256), 0, c->stream, d_out + 2);
+      ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(h_out, d_out, 12, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+           hipStreamSynchronize(c->stream) == hipSuccess;
       (void)hipFree(d_out);
-      checked[(size_t)dev] = ok && h_out[0] == 0u && h_out[1] == 0u ? 1 : -1;
+      // a HIP failure here says nothing about the build or the chip: the verdicts stay open and the error goes to the caller
+      if (!ok) { (void)hipGetLastError(); return bail(fail(GKLHIP_ERR_HIP, "the start-up self-tests could not run on device %d", dev)); }
+      checked[(size_t)dev] = h_out[0] == 0u && h_out[1] == 0u ? 1 : -1;
+      oob_checked[(size_t)dev] = h_out[2] == 0u ? 1 : -1;
+      if (oob_checked[(size_t)dev] < 0)
+        fprintf(stderr, "[gklhip] pairhmm: LDS reads beyond the allocation do not return 0 on device %d (%08x): the fp32 general steps stay in C++\n", dev, h_out[2]);
     }
     if (checked[(size_t)dev] < 0)
       return bail(fail(GKLHIP_ERR_HIP, "this library was built without the denormal-flush flags its kernels depend on (gkl_amd/csrc/Makefile: HIPFLAGS)"));
+    c->lds_oob_zero = oob_checked[(size_t)dev] > 0 ? 1 : 0;
+  }
+  {
+    const char* ag = getenv("GKLHIP_ASM_GENERAL");
+    c->asm_general = ag ? (atoi(ag) != 0) : 1;
+    const char* sp = getenv("GKLHIP_SPECULATE_FP64");
+    c->speculate_fp64 = sp ? (atoi(sp) != 0) : 0;
+    // tests only: GKLHIP_SELFTEST_FAIL=lds_oob makes this context behave as if the self-test above had failed
+    const char* sf = getenv("GKLHIP_SELFTEST_FAIL");
+    if (sf && strcmp(sf, "lds_oob") == 0) {
+      c->lds_oob_zero = 0;
+      fprintf(stderr, "[gklhip] pairhmm: GKLHIP_SELFTEST_FAIL=lds_oob: the fp32 general steps stay in C++ for this context\n");
+    }
   }
   if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
   for (int k = 0; k < 2; k++)
@@ -1054,7 +1092,7 @@ struct SmallCombiner {
   int launch_single(const SmallCall& k, hipStream_t s, bool alone) {
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)k.prep_grid), dim3(kPrepBlock), 0, s, k.prep);
     if (k.fused) {
-      launch_pair_fused(k.f, k.d, k.q, k.rows, k.fma, k.n_pairs, s, alone);
+      launch_pair_fused(k.f, k.d, k.q, k.rows, k.fma, k.n_pairs, s, alone && k.speculate);
     } else {
       launch_main_f32(k.f, k.rpl_main, k.fma, k.main_blocks, s);
       launch_pair_policy(k.d, k.q, k.rows, k.fma, k.n_pairs, s);
@@ -1295,13 +1333,24 @@ int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
 // Host buffers in, host doubles out on one device.  An error return must not leave copies from the caller's
 // arrays (or into them) in flight: drain the streams first.
 int dev_compute_host(DevCtx* c, const gklhip_batch* hb, double* out_host) {
-  const int rc = dev_compute_host_impl(c, hb, out_host);
-  if (rc != GKLHIP_OK) {
-    const std::string keep = g_err;
+  // ... and neither must a C++ exception on its way to the entry point's guarded() (bad_alloc from a plan vector, a
+  // finalisation worker's rethrow): the same drain, then the exception goes on
+  auto drain = [c]() noexcept {
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamSynchronize(c->upload_stream);
     (void)hipGetLastError();
+  };
+  int rc;
+  try {
+    rc = dev_compute_host_impl(c, hb, out_host);
+  } catch (...) {
+    drain();
+    throw;
+  }
+  if (rc != GKLHIP_OK) {
+    const std::string keep = g_err;
+    drain();
     g_err = keep;
   }
   return rc;

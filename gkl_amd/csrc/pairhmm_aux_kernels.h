@@ -106,6 +106,7 @@ struct SmallCall {
   PairPolicyArgs q;
   int32_t prep_grid, rpl_main, main_blocks, rows, n_pairs, fma;
   int32_t fused;  // the whole pair in one wavefront (pair_fused_block) instead of the packed fp32 pass + per-pair policy
+  int32_t speculate;  // host side only: the context asked for the fp64 pass beside the fp32 one when the call runs alone
 };
 constexpr int kMultiMax = 16;
 struct MultiArgs {
@@ -654,6 +655,34 @@ __global__ void flush_selftest_kernel(uint32_t* out, float f, double d) {
   asm volatile("v_mul_f64 %0, 1.0, %1" : "=v"(dm) : "v"(d));
   out[0] = __float_as_uint(fm);
   out[1] = (uint32_t)((uint64_t)__double_as_longlong(dm) >> 32) | (uint32_t)(uint64_t)__double_as_longlong(dm);
+}
+
+// The fp32 whole-job programs (tools/gen_fwd_asm.py: OOB_PLANE) give a lane on a separator-type entry the priors of a
+// "plane" that starts 512 row-blocks behind its own -- 256 KB or more, beyond the CU's whole LDS -- and rely on a DS read
+// beyond the workgroup's allocation returning 0 (ISA manuals since GCN3).  Asked of the device once per process (dev_init):
+// workgroups with the forward kernels' kind of allocation, every byte non-zero, neighbours resident on the same CU, read
+// what such a lane reads at the three plane sizes (8 / 4 / 2 rows per lane: ds_read_b128 at the base and one plane
+// further, ds_read_b64) and OR the bits into out[0].  Anything but 0 and the context keeps the fp32 general steps in C++
+// (the round-3 arrangement, FwdArgs::asm_general = 0), where a separator lane's priors are selected, not fetched.
+__global__ __launch_bounds__(256) void lds_oob_selftest_kernel(uint32_t* out) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 2560];   // four wavefronts' 10 KB tables
+  for (int i = threadIdx.x; i < 4 * 2560; i += 256) lds[i] = 0xA5A50000u | (uint32_t)i;
+  __syncthreads();
+  const uint32_t loff = (uint32_t)(uintptr_t)lds + (threadIdx.x >> 6) * 10240u + (threadIdx.x & 63u) * 16u;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int shift = 9; shift <= 11; shift++) {
+    const uint32_t addr = (512u << shift) + loff;   // v_lshl_add_u32 ADDR, min(entry, 512), code_shift, LOFF
+    uint32_t v0, v1, v2, v3, w0, w1, w2, w3, x0, x1;
+    asm volatile("ds_read_b128 v[40:43], %10\n\tds_read_b128 v[44:47], %10 offset:1024\n\tds_read_b64 v[48:49], %10\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "v_mov_b32 %0, v40\n\tv_mov_b32 %1, v41\n\tv_mov_b32 %2, v42\n\tv_mov_b32 %3, v43\n\t"
+                 "v_mov_b32 %4, v44\n\tv_mov_b32 %5, v45\n\tv_mov_b32 %6, v46\n\tv_mov_b32 %7, v47\n\tv_mov_b32 %8, v48\n\tv_mov_b32 %9, v49"
+                 : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3), "=v"(x0), "=v"(x1)
+                 : "v"(addr) : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "memory");
+    acc |= v0 | v1 | v2 | v3 | w0 | w1 | w2 | w3 | x0 | x1;
+  }
+  if (acc) atomicOr(out, acc);
+  if (lds[threadIdx.x] == 0) atomicOr(out, 0x80000000u);   // (keeps the stores above alive)
 }
 
 // ---- diagnostics: the VALU issue ceiling of the forward recurrence's instruction mix ----------------------------

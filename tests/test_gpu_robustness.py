@@ -125,3 +125,32 @@ def test_lds_reads_beyond_the_allocation_return_zero(tmp_path):
     out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
     lines = [ln for ln in out.splitlines() if ln.startswith("address class")]
     assert len(lines) == 4 and all(" 0 non-zero" in ln for ln in lines), out
+
+
+@pytest.mark.gpu
+def test_forced_lds_selftest_failure_keeps_the_fp32_general_steps_in_cxx(oracle, monkeypatch, capfd):
+    """gklhip_init asks the device once whether a DS read beyond the LDS allocation returns 0 (lds_oob_selftest_kernel) --
+    the fp32 whole-job programs fetch a separator lane's priors from there.  GKLHIP_SELFTEST_FAIL=lds_oob makes a context
+    behave as if the answer had been no: one line on stderr, the fp32 general steps stay in C++ (the round-3 arrangement,
+    what GKLHIP_ASM_GENERAL=0 selects), the fp64 programs -- which do not depend on it -- stay, and every bit is the oracle's:
+    bench shape (planned fp64 pass), long reads (wide kernel), a tiny call (fused kernel)."""
+    from gkl_amd import native
+    from gkl_amd.synth import make_batch, random_batch
+    rng = np.random.RandomState(515)
+    batches = [make_batch("hc", 1400, 50, seed=19), make_batch("hc", 100, 10, seed=3),
+               random_batch(rng, 70, 10, read_len=(60, 500), hap_len=(80, 700), alphabet=b"ACGTNacgtRY"),
+               random_batch(rng, 6, 5, read_len=(700, 1300), hap_len=(900, 1500), qual_range=(25, 45))]
+    with native.PairHmmContext() as c:   # (the real self-test runs with the first context of the process and must pass here)
+        base = [c.compute(b).copy() for b in batches]
+    capfd.readouterr()
+    monkeypatch.setenv("GKLHIP_SELFTEST_FAIL", "lds_oob")
+    with native.PairHmmContext() as c:
+        err = capfd.readouterr().err
+        assert "GKLHIP_SELFTEST_FAIL=lds_oob" in err and "stay in C++" in err
+        for b, ref in zip(batches, base):
+            out = c.compute(b)
+            r32, r64, u = c.raw(b.n_pairs)
+            oo, o32, o64, ou = oracle.batch(b, want_raw=True, n_threads=8)
+            assert np.array_equal(u, ou) and r32.tobytes() == o32.tobytes()
+            assert r64[u == 1].tobytes() == o64[ou == 1].tobytes()
+            assert out.tobytes() == oo.tobytes() == ref.tobytes()
