@@ -205,6 +205,74 @@ def jni_records(batch, c1, host_ms, host_ms_4=None):
     return rec, conc
 
 
+def small_proc_worker(idx, dev_index, workload, duration_s):
+    """Child-process mode of `process_records`: ONE caller with its own context (its own process: what a GATK
+    HaplotypeCaller JVM is to the GPU), 100 x 10 regions through gklhip_compute back to back.  Says "ready" when warm, starts
+    on a line from the parent, prints one JSON object."""
+    from gkl_amd import native
+    from gkl_amd.synth import DEFAULT_SEED, make_batch
+    b = make_batch(workload, 100, 10, seed=DEFAULT_SEED + 17 * idx)   # every process its own region
+    out = np.empty(b.n_pairs)
+    with native.PinnedBatch(b) as pb, native.PairHmmContext(device=dev_index) as c:
+        for _ in range(60):
+            c.compute(pb, out)
+        print("ready", flush=True)
+        sys.stdin.readline()
+        lat = []
+        t0 = time.perf_counter()
+        t_end = t0 + duration_s
+        while True:
+            t = time.perf_counter()
+            if t >= t_end:
+                break
+            c.compute(pb, out)
+            lat.append(time.perf_counter() - t)
+        elapsed = time.perf_counter() - t0
+    lat = np.sort(np.array(lat))
+    print(json.dumps({"calls": int(lat.size), "elapsed_s": elapsed, "cells_per_call": int(b.cells),
+                      "p50_ms": float(lat[lat.size // 2]) * 1e3, "p99_ms": float(lat[min(lat.size - 1, int(lat.size * 0.99))]) * 1e3,
+                      "checksum": float(out.sum())}), flush=True)
+
+
+def process_records(dev_index, workload, counts=(4, 16), duration_s=1.5):
+    """P PROCESSES x one caller on one GPU -- the deployment GATK produces (HaplotypeCaller is one compute thread per JVM,
+    scattered over many JVMs per node): each child owns a context and loops 100 x 10 host calls; all start together.
+    Aggregate rate, median and 99th-percentile call latency over all children's calls.  The per-process SmallCombiner cannot
+    combine across processes: what is measured here is the device's own scheduling of P independent HIP processes."""
+    rec = {}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for n_proc in counts:
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--small-proc-worker", str(i), "--small-proc-device", str(dev_index),
+                                   "--workload", workload, "--small-proc-seconds", str(duration_s)], stdin=subprocess.PIPE,
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for i in range(n_proc)]
+        try:
+            for p in procs:
+                line = p.stdout.readline()
+                if line.strip() != "ready":
+                    raise RuntimeError(f"a worker process did not come up: {line!r}")
+            for p in procs:
+                p.stdin.write("go\n")
+                p.stdin.flush()
+            res = []
+            for p in procs:
+                out, _ = p.communicate(timeout=120)
+                res.append(json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1]))
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        calls = sum(r["calls"] for r in res)
+        rec[f"processes_{n_proc}"] = {
+            "aggregate_gcups": round(sum(r["calls"] * r["cells_per_call"] / r["elapsed_s"] for r in res) / 1e9, 1),
+            "calls_per_s": round(sum(r["calls"] / r["elapsed_s"] for r in res), 1),
+            "p50_ms": round(float(np.median([r["p50_ms"] for r in res])), 4),
+            "p99_ms": round(float(np.max([r["p99_ms"] for r in res])), 4),
+            "calls": calls, "seconds": duration_s}
+    rec["note"] = ("P processes, each ONE caller with its own context looping 100 x 10 regions through gklhip_compute (host arrays in, "
+                   "host doubles out), all started together; p50 = median over processes of their median call, p99 = the worst process's")
+    return rec
+
+
 def in_library_probe(n_dev, reads, haps, workload, steps, warmup):
     """Child-process mode: ONE process drives n_dev devices through a multi-device context (GKL_HIP_DEVICES),
     i.e. what a JVM calling computeLikelihoodsNative gets.  Prints one JSON object."""
@@ -279,7 +347,12 @@ def main():
                                                            "roofline's kernel durations are those of kernels running alone)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one context, one stream per rank")
     ap.add_argument("--in-library-probe", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--small-proc-worker", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--small-proc-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--small-proc-seconds", type=float, default=1.5, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.small_proc_worker >= 0:
+        return small_proc_worker(a.small_proc_worker, a.small_proc_device, a.workload, a.small_proc_seconds)
     if a.config4:
         a.reads, a.haps = 8000, 125
     if a.in_library_probe:
@@ -590,6 +663,10 @@ def main():
                     res["small_batch"]["concurrent"] = conc
                 except Exception as e:
                     res["jni_path"] = {"error": repr(e)}
+                try:
+                    res["small_batch"]["processes"] = process_records(dev_index, a.workload)
+                except Exception as e:
+                    res["small_batch"]["processes"] = {"error": repr(e)}
                 # reads longer than one wavefront's rows (fp32 > 511 bases, fp64 > 639): workgroups of 2-4 wavefronts per read
                 try:
                     lb = make_batch(a.workload, 1000, 32, seed=DEFAULT_SEED, read_len=(600, 1000), hap_len=(900, 1100))

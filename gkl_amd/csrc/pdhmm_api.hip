@@ -6,6 +6,7 @@
 #include <sys/sysinfo.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -118,6 +119,11 @@ struct gklhip_pdhmm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // big paired calls are cut into slices of pairs whose kernels run while later slices still cross PCIe (pd_run_locked)
+  static constexpr int kMaxSlices = 8;
+  hipStream_t up_stream = nullptr;
+  hipEvent_t up_ev[kMaxSlices] = {}, sl_ev0[kMaxSlices] = {}, sl_ev1[kMaxSlices] = {};
+  int pipeline = 1;                     // GKL_HIP_PDHMM_PIPELINE=0: one slice whatever the size
   std::mutex mu;
   Buf tables, inputs, entries, entries_tab, sums, misc, carry, jobs, tabx;
   PackScratch pack_scratch;
@@ -162,6 +168,11 @@ int gklhip_pdhmm_init(int device, gklhip_pdhmm_ctx** out_ctx) {
   auto bail = [&](int st) { gklhip_pdhmm_done(c); return st; };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(pd_fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(pd_fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
+  if (hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) return bail(pd_fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  for (int k = 0; k < gklhip_pdhmm_ctx::kMaxSlices; k++)
+    if (hipEventCreateWithFlags(&c->up_ev[k], hipEventDisableTiming) != hipSuccess || hipEventCreate(&c->sl_ev0[k]) != hipSuccess ||
+        hipEventCreate(&c->sl_ev1[k]) != hipSuccess)
+      return bail(pd_fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
   const PdTables& t = pd_tables();
   int rc = c->tables.reserve((t.q2err.size() + t.mm.size()) * sizeof(double));
   if (rc) return bail(rc);
@@ -173,6 +184,8 @@ int gklhip_pdhmm_init(int device, gklhip_pdhmm_ctx** out_ctx) {
     c->tail_mode = (tm && (strcmp(tm, "vector") == 0 || strcmp(tm, "0") == 0)) ? 0 : 1;  // "reference" (default) | "vector"
     const char* tb = getenv("GKL_HIP_PDHMM_TABLE");
     c->use_table = (tb && tb[0] == '0') ? 0 : 1;
+    const char* pl = getenv("GKL_HIP_PDHMM_PIPELINE");
+    c->pipeline = (pl && pl[0] == '0') ? 0 : 1;
   }
   if (c->use_table) {
     // once per process and device: does a DS read beyond the workgroup's LDS allocation return 0 here?  The table
@@ -211,6 +224,11 @@ int gklhip_pdhmm_done(gklhip_pdhmm_ctx* c) {
   if (!c) return GKLHIP_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+  for (int k = 0; k < gklhip_pdhmm_ctx::kMaxSlices; k++)
+    for (hipEvent_t e : {c->up_ev[k], c->sl_ev0[k], c->sl_ev1[k]})
+      if (e) (void)hipEventDestroy(e);
+  if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
   for (Buf* b : {&c->tables, &c->inputs, &c->entries, &c->entries_tab, &c->sums, &c->misc, &c->carry, &c->jobs, &c->tabx}) b->release();
   for (PinBuf* b : {&c->stage_in, &c->stage_jobs, &c->sums_pin}) b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -302,6 +320,7 @@ int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   if (rc != GKLHIP_OK) {
     const std::string keep = g_pd_err;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     (void)hipGetLastError();
     g_pd_err = keep;
   }
@@ -332,21 +351,49 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   // The nine input copies (the paired layout of a big batch is hundreds of MB of padded [pair][maxLen] arrays: the
   // calls alone -- pinning the caller's pages -- take milliseconds): a helper thread issues them while this one builds
   // the jobs; both meet before anything else goes onto the stream.
+  // A big PAIRED call (computePDHMMNative: ~1.2 KB of padded input per pair -- the x32 fixture is 498 MB, 9.5 ms of PCIe
+  // against 5 ms of kernels) is cut into slices of consecutive pairs, biggest first: the helper thread sends slice after
+  // slice on the upload stream and records an event behind each; the kernels of a slice -- its pairs are packed among
+  // themselves -- wait for that event only, so they run while the later slices still cross the bus, and the last,
+  // smallest slice leaves little to do once the bus is done.  Everything else about the call is one problem: one set of
+  // device arrays, one job list (slice k = a range of listed jobs), the rare striped / odd-base / tail jobs at the end.
+  int n_slices = 1;
+  size_t slice_lo[gklhip_pdhmm_ctx::kMaxSlices + 1] = {0, n};
+  if (!q.cross_haps && c->pipeline && n >= 65536 && hap_bytes + 5 * read_bytes >= ((size_t)64 << 20)) {
+    static const double kShare[] = {0.28, 0.24, 0.19, 0.13, 0.09, 0.05, 0.02};
+    n_slices = (int)(sizeof kShare / sizeof kShare[0]);
+    double acc = 0.0;
+    for (int k = 0; k < n_slices; k++) { slice_lo[k] = (size_t)(acc * (double)n) / 64 * 64; acc += kShare[k]; }
+    slice_lo[n_slices] = n;
+  }
   struct Uploads {
     hipError_t err = hipSuccess;
     std::thread th;
+    std::atomic<int> recorded{0};   // slices whose upload event has been recorded (or given up on)
     ~Uploads() { if (th.joinable()) th.join(); }
   } up_th;
   auto do_uploads = [&, d]() {
+    (void)hipSetDevice(c->device);
+    hipStream_t us = n_slices > 1 ? c->up_stream : s;
     auto cp = [&](size_t off, const void* src, size_t bytes) {
       if (up_th.err != hipSuccess || bytes == 0) return;
-      up_th.err = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s);
+      up_th.err = hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, us);
     };
-    (void)hipSetDevice(c->device);
-    cp(o_hb, q.hap_bases, hap_bytes); cp(o_hp, q.hap_pdbases, hap_bytes);
-    cp(o_rb, q.read_bases, read_bytes); cp(o_rq, q.read_qual, read_bytes); cp(o_ri, q.read_ins_qual, read_bytes);
-    cp(o_rd, q.read_del_qual, read_bytes); cp(o_gc, q.gcp, read_bytes);
-    cp(o_hl, q.hap_lengths, nh * 8); cp(o_rl, q.read_lengths, nr * 8);
+    for (int k = 0; k < n_slices; k++) {
+      // (paired layout: item i of every array belongs to pair i; cross layout: one slice, all items)
+      const size_t h0 = n_slices > 1 ? slice_lo[k] : 0, h1 = n_slices > 1 ? slice_lo[k + 1] : nh;
+      const size_t r0 = n_slices > 1 ? slice_lo[k] : 0, r1 = n_slices > 1 ? slice_lo[k + 1] : nr;
+      const size_t mh = (size_t)q.max_hap_len, mr = (size_t)q.max_read_len;
+      cp(o_hl + h0 * 8, q.hap_lengths + h0, (h1 - h0) * 8); cp(o_rl + r0 * 8, q.read_lengths + r0, (r1 - r0) * 8);
+      cp(o_hb + h0 * mh, q.hap_bases + h0 * mh, (h1 - h0) * mh); cp(o_hp + h0 * mh, q.hap_pdbases + h0 * mh, (h1 - h0) * mh);
+      cp(o_rb + r0 * mr, q.read_bases + r0 * mr, (r1 - r0) * mr); cp(o_rq + r0 * mr, q.read_qual + r0 * mr, (r1 - r0) * mr);
+      cp(o_ri + r0 * mr, q.read_ins_qual + r0 * mr, (r1 - r0) * mr); cp(o_rd + r0 * mr, q.read_del_qual + r0 * mr, (r1 - r0) * mr);
+      cp(o_gc + r0 * mr, q.gcp + r0 * mr, (r1 - r0) * mr);
+      if (n_slices > 1) {
+        if (up_th.err == hipSuccess) up_th.err = hipEventRecord(c->up_ev[k], us);
+        up_th.recorded.store(k + 1, std::memory_order_release);
+      }
+    }
   };
   // A call of the fixture's size (276 reads x 48 haplotypes) spent half its time in two dozen small copies from
   // pageable memory (~10 us each): up to kPdStageBytes the arrays are gathered in a pinned block and travel in ONE copy.
@@ -359,7 +406,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     memcpy(h + o_rd, q.read_del_qual, read_bytes); memcpy(h + o_gc, q.gcp, read_bytes);
     memcpy(h + o_hl, q.hap_lengths, nh * 8); memcpy(h + o_rl, q.read_lengths, nr * 8);
     PD_HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, s));
-  } else if (hap_bytes + 5 * read_bytes >= ((size_t)8 << 20)) {
+  } else if (n_slices > 1 || hap_bytes + 5 * read_bytes >= ((size_t)8 << 20)) {
     up_th.th = std::thread(do_uploads);
   } else {
     do_uploads();
@@ -377,6 +424,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   std::vector<uint8_t> job_striped;
   std::vector<PlanLane> cross_lanes;           // cross layout: [chunk][64] = {read item, block}
   std::vector<int32_t> hap_order, chunk_steps, chunk_rep;
+  int32_t slice_chunk0[gklhip_pdhmm_ctx::kMaxSlices + 1] = {0, 0};   // paired layout: slice k = chunks [slice_chunk0[k], slice_chunk0[k + 1]) = listed jobs n_striped + those
   size_t n_tail = 0;                           // paired layout, tail mode: the last n_tail pairs
   std::vector<PlanLane> tail_lanes;
   std::vector<int32_t> tail_pair, tail_steps;
@@ -452,37 +500,43 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     // into 64-lane chunks; a read that needs more than 64 lanes becomes a striped job
     std::vector<int64_t> pair_off(n + 1, 0);  // pack_reads_windowed() addresses reads through offsets
     for (size_t i = 0; i < n; i++) pair_off[i + 1] = pair_off[i] + read_len_of(i);
-    std::vector<int32_t> shorts;
-    shorts.reserve(n);
-    {  // counting sort by haplotype length, longest first (the big jobs start first)
-      std::vector<int32_t> cnt((size_t)q.max_hap_len + 2, 0);
-      size_t n_short = 0;
-      for (size_t i = 0; i < n_vec; i++)
-        if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) { cnt[(size_t)hap_len_of(i)]++; n_short++; }
-      int32_t acc = 0;
-      for (int64_t h = q.max_hap_len; h >= 0; h--) { const int32_t k = cnt[(size_t)h]; cnt[(size_t)h] = acc; acc += k; }
-      shorts.resize(n_short);
-      for (size_t i = 0; i < n_vec; i++)
-        if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) shorts[(size_t)cnt[(size_t)hap_len_of(i)]++] = (int32_t)i;
-    }
     for (size_t i = 0; i < n_vec; i++) {
       if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) continue;
       job_pair.push_back((int32_t)i); job_striped.push_back(1); job_steps.push_back(0);  // (a striped job's lane row stays unused)
     }
-    // compact packing (5 bytes per pair); pdhmm_expand_kernel turns it into the lane rows on the device
+    // compact packing (5 bytes per pair); pdhmm_expand_kernel turns it into the lane rows on the device.  Slice by slice
+    // (one slice: the whole batch): the pairs of a slice share chunks among themselves only, chunk numbers run on.
     n_striped = job_pair.size();
     place_chunk.assign(n, -1);
     place_lane.assign(n, 0);
-    const int made = pack_reads_place(shorts.data(), (int)shorts.size(), pair_off.data(), kPdRpl, 192, place_chunk.data(),
-                                      place_lane.data(), &chunk_used, nullptr, &c->pack_scratch);
-    job_pair.resize(n_striped + (size_t)made, -1);
-    job_steps.resize(n_striped + (size_t)made, 0);
-    job_striped.resize(n_striped + (size_t)made, 0);
-    for (const int32_t i : shorts) {
-      const size_t j = n_striped + (size_t)place_chunk[(size_t)i];
-      if (job_pair[j] < 0) job_pair[j] = i;
-      job_steps[j] = std::max(job_steps[j], (int32_t)(hap_len_of((size_t)i) + blocks_for(read_len_of((size_t)i), kPdRpl) - 1));
+    std::vector<int32_t> shorts, cnt;
+    shorts.reserve(n);
+    for (int k = 0; k < n_slices; k++) {
+      const size_t lo = std::min(slice_lo[k], n_vec), hi = std::min(slice_lo[k + 1], n_vec);
+      slice_chunk0[k] = (int32_t)chunk_used.size();
+      // counting sort by haplotype length, longest first (the big jobs start first)
+      cnt.assign((size_t)q.max_hap_len + 2, 0);
+      size_t n_short = 0;
+      for (size_t i = lo; i < hi; i++)
+        if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) { cnt[(size_t)hap_len_of(i)]++; n_short++; }
+      int32_t acc = 0;
+      for (int64_t h = q.max_hap_len; h >= 0; h--) { const int32_t m = cnt[(size_t)h]; cnt[(size_t)h] = acc; acc += m; }
+      shorts.resize(n_short);
+      for (size_t i = lo; i < hi; i++)
+        if (blocks_for(read_len_of(i), kPdRpl) <= kLanes) shorts[(size_t)cnt[(size_t)hap_len_of(i)]++] = (int32_t)i;
+      const int made = pack_reads_place(shorts.data(), (int)shorts.size(), pair_off.data(), kPdRpl, 192, place_chunk.data(),
+                                        place_lane.data(), &chunk_used, nullptr, &c->pack_scratch);
+      const size_t j0 = n_striped + (size_t)slice_chunk0[k];
+      job_pair.resize(j0 + (size_t)made, -1);
+      job_steps.resize(j0 + (size_t)made, 0);
+      job_striped.resize(j0 + (size_t)made, 0);
+      for (const int32_t i : shorts) {
+        const size_t j = n_striped + (size_t)place_chunk[(size_t)i];
+        if (job_pair[j] < 0) job_pair[j] = i;
+        job_steps[j] = std::max(job_steps[j], (int32_t)(hap_len_of((size_t)i) + blocks_for(read_len_of((size_t)i), kPdRpl) - 1));
+      }
     }
+    slice_chunk0[n_slices] = (int32_t)chunk_used.size();
   }
   const double ms_jobs = ms_since(t_begin);
   // ---- routing: the hot launch (only the two in-place step loops, see pdhmm_fwd_kernel) takes every job without a
@@ -602,8 +656,10 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
                o_nc = o_ts + up(n_tail), o_cc = o_nc + up(hap_ncls.size()), o_jf = o_cc + up(class_codes.size() * 4),
                o_pc = o_jf + up((size_t)n_general), o_pl = o_pc + up(place_chunk.size() * 4), o_cu = o_pl + up(place_lane.size()),
                o_fj = o_cu + up(chunk_used.size()), o_tg = o_fj + up((size_t)n_general * 4), jobs_total = o_tg + up(tab_group_start.size() * 4);
-  if (up_th.th.joinable()) up_th.th.join();
-  PD_HIP_TRY(up_th.err);
+  if (n_slices == 1) {   // (sliced call: the kernels of slice k wait for slice k's upload event, see below)
+    if (up_th.th.joinable()) up_th.th.join();
+    PD_HIP_TRY(up_th.err);
+  }
   if ((rc = c->jobs.reserve(jobs_total + 256))) return rc;
   unsigned char* dj = c->jobs.as<unsigned char>();
   const bool staged_jobs = jobs_total <= kPdStageBytes;
@@ -705,8 +761,10 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   a.prof = reinterpret_cast<unsigned long long*>(c->misc.as<char>() + 128);
 #endif
 
-  hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)nh), dim3(kLanes), 0, s, a);   // one wavefront per haplotype item
-  if (!cross && !chunk_used.empty()) {
+  a.item_base = 0; a.job_base = 0;
+  const bool paired_packed = !cross && !chunk_used.empty();
+  if (paired_packed) {
+    // ---- paired layout: slice by slice (one slice unless the call is big, see above) ----
     PdExpandArgs x;
     x.place_chunk = reinterpret_cast<const int32_t*>(dj + o_pc);
     x.place_lane = dj + o_pl;
@@ -717,42 +775,73 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     x.job_flags = dj + o_jf;
     x.hap_ncls = tab_paired ? dx + x_nc : nullptr;
     x.job_notab = tab_paired ? dx + x_nt : nullptr;
-    x.n_pairs = (int32_t)n; x.n_chunks = (int32_t)chunk_used.size(); x.n_striped = (int32_t)n_striped; x.rpl = kPdRpl;
-    hipLaunchKernelGGL(pdhmm_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x);
-    hipLaunchKernelGGL(pdhmm_collect_kernel, dim3((unsigned)((n_general + 255) / 256)), dim3(256), 0, s, dj + o_jf, dj + o_js, n_general,
-                       reinterpret_cast<int32_t*>(dj + o_fj), c->misc.as<int32_t>() + 5, tab_paired ? dx + x_nt : nullptr,
-                       reinterpret_cast<int32_t*>(dx + x_hj), c->misc.as<int32_t>() + 6);
-  }
-  PD_HIP_TRY(hipEventRecord(c->ev0, s));
-  if (tab_paired) {
-    // table launch of the paired layout: the jobs' next-special-step tables first (part of the timed region: work only
-    // this route does), then every listed job that is clean and whose haplotypes all have at most kPdTabClasses classes
-    if (tab_paired_asm) {
-      PdJobNsArgs na;
-      na.lanes = a.lanes; na.job_steps = a.job_steps; na.job_striped = a.job_striped; na.job_flags = a.job_flags; na.job_notab = a.job_notab;
-      na.read_len = a.read_len; na.hap_len = a.hap_len; na.special_bits = a.special_bits; na.sb_stride = sb_stride;
-      na.job_ns = reinterpret_cast<int32_t*>(dx + x_ns); na.ns_stride = ns_stride; na.rpl = kPdRpl;
-      hipLaunchKernelGGL(pdhmm_job_special_kernel, dim3((unsigned)n_general), dim3(kLanes), (size_t)ns_stride, s, na);
+    x.n_striped = (int32_t)n_striped; x.rpl = kPdRpl;
+    for (int k = 0; k < n_slices; k++) {
+      const size_t lo = slice_lo[k], hi = slice_lo[k + 1];
+      const int c0 = slice_chunk0[k], c1 = slice_chunk0[k + 1];
+      const int j0 = (int)n_striped + c0, j1 = (int)n_striped + c1;
+      if (n_slices > 1) {
+        while (up_th.recorded.load(std::memory_order_acquire) <= k) std::this_thread::yield();
+        PD_HIP_TRY(up_th.err);
+        PD_HIP_TRY(hipStreamWaitEvent(s, c->up_ev[k], 0));
+      }
+      PdArgs ae = a;
+      ae.item_base = (int32_t)lo;
+      hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)(hi - lo)), dim3(kLanes), 0, s, ae);   // one wavefront per haplotype item
+      x.pair_base = (int32_t)lo; x.n_pairs = (int32_t)hi; x.chunk_base = c0; x.n_chunks = c1;
+      hipLaunchKernelGGL(pdhmm_expand_kernel, dim3((unsigned)((std::max<size_t>(hi - lo, (size_t)(c1 - c0)) + 255) / 256)), dim3(256), 0, s, x);
+      if (j1 > j0)
+        hipLaunchKernelGGL(pdhmm_collect_kernel, dim3((unsigned)((j1 - j0 + 255) / 256)), dim3(256), 0, s, dj + o_jf, dj + o_js, j1,
+                           reinterpret_cast<int32_t*>(dj + o_fj), c->misc.as<int32_t>() + 5, tab_paired ? dx + x_nt : nullptr,
+                           reinterpret_cast<int32_t*>(dx + x_hj), c->misc.as<int32_t>() + 6, j0);
+      PD_HIP_TRY(hipEventRecord(n_slices > 1 ? c->sl_ev0[k] : c->ev0, s));
+      if (j1 <= j0) { if (n_slices > 1) PD_HIP_TRY(hipEventRecord(c->sl_ev1[k], s)); continue; }
+      if (tab_paired) {
+        // table launch: the jobs' next-special-step tables first (part of the timed region: work only this route does),
+        // then every listed job of the slice that is clean and whose haplotypes all have at most kPdTabClasses classes
+        if (tab_paired_asm) {
+          PdJobNsArgs na;
+          na.lanes = a.lanes; na.job_steps = a.job_steps; na.job_striped = a.job_striped; na.job_flags = a.job_flags; na.job_notab = a.job_notab;
+          na.read_len = a.read_len; na.hap_len = a.hap_len; na.special_bits = a.special_bits; na.sb_stride = sb_stride;
+          na.job_ns = reinterpret_cast<int32_t*>(dx + x_ns); na.ns_stride = ns_stride; na.rpl = kPdRpl; na.job_base = j0;
+          hipLaunchKernelGGL(pdhmm_job_special_kernel, dim3((unsigned)(j1 - j0)), dim3(kLanes), (size_t)ns_stride, s, na);
+        }
+        PdArgs at = a;
+        at.n_cross_jobs = 0; at.job_base = j0; at.n_jobs = j1;
+        at.class_codes = a.class_codes_out;
+        at.next = c->misc.as<int32_t>() + 8 + k;
+        if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_tab_paired_kernel<true>, dim3(std::min(j1 - j0, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
+        else             hipLaunchKernelGGL(pdhmm_fwd_tab_paired_kernel<false>, dim3(std::min(j1 - j0, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
+      } else {
+        // predicate launch: walks the slice's listed jobs and skips the flagged ones
+        PdArgs ah = a;
+        ah.n_cross_jobs = 0; ah.job_base = j0; ah.n_jobs = j1;
+        ah.full_jobs = nullptr;
+        ah.next = c->misc.as<int32_t>() + 16 + k;
+        if (c->fma_mode) hipLaunchKernelGGL((pdhmm_fwd_kernel<true, false, true>), dim3(std::min(j1 - j0, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
+        else             hipLaunchKernelGGL((pdhmm_fwd_kernel<false, false, true>), dim3(std::min(j1 - j0, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
+      }
+      if (n_slices > 1) PD_HIP_TRY(hipEventRecord(c->sl_ev1[k], s));
     }
-    PdArgs at = a;
-    at.n_cross_jobs = 0; at.n_jobs = n_general;
-    at.class_codes = a.class_codes_out;
-    at.next = c->misc.as<int32_t>() + 4;
-    if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_tab_paired_kernel<true>, dim3(std::min(n_general, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
-    else             hipLaunchKernelGGL(pdhmm_fwd_tab_paired_kernel<false>, dim3(std::min(n_general, n_blocks)), dim3(64), 0, s, at, t.initial_condition);
-    // predicate launch: the (rare) clean packed jobs with an ineligible haplotype, from the list pdhmm_collect_kernel made
-    PdArgs ah = a;
-    ah.n_cross_jobs = 0; ah.n_jobs = 0;
-    ah.full_jobs = reinterpret_cast<const int32_t*>(dx + x_hj);
-    ah.full_count = c->misc.as<int32_t>() + 6;
-    if (c->fma_mode) hipLaunchKernelGGL((pdhmm_fwd_kernel<true, false, true>), dim3(std::min((int)n_packed, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
-    else             hipLaunchKernelGGL((pdhmm_fwd_kernel<false, false, true>), dim3(std::min((int)n_packed, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
-    PdArgs af = a;   // full launch: striped reads and haplotypes with odd bases
+    if (n_slices > 1) PD_HIP_TRY(hipEventRecord(c->ev0, s));
+    if (tab_paired) {
+      // predicate launch: the (rare) clean packed jobs with an ineligible haplotype, from the list pdhmm_collect_kernel made
+      PdArgs ah = a;
+      ah.n_cross_jobs = 0; ah.n_jobs = 0;
+      ah.full_jobs = reinterpret_cast<const int32_t*>(dx + x_hj);
+      ah.full_count = c->misc.as<int32_t>() + 6;
+      if (c->fma_mode) hipLaunchKernelGGL((pdhmm_fwd_kernel<true, false, true>), dim3(std::min((int)n_packed, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
+      else             hipLaunchKernelGGL((pdhmm_fwd_kernel<false, false, true>), dim3(std::min((int)n_packed, n_blocks)), dim3(64), 0, s, ah, t.initial_condition);
+    }
+    PdArgs af = a;   // full launch: striped reads and haplotypes with odd bases (the list: striped jobs from the host, flagged ones from pdhmm_collect_kernel)
     af.n_cross_jobs = 0; af.n_jobs = n_general;
     af.next = c->misc.as<int32_t>() + 3;
     if (c->fma_mode) hipLaunchKernelGGL(pdhmm_fwd_kernel<true>, dim3(std::min(n_general, n_blocks)), dim3(64), 0, s, af, t.initial_condition);
     else             hipLaunchKernelGGL(pdhmm_fwd_kernel<false>, dim3(std::min(n_general, n_blocks)), dim3(64), 0, s, af, t.initial_condition);
   } else {
+    // ---- cross layout (and a paired call that holds striped reads only) ----
+    hipLaunchKernelGGL(pdhmm_entries_kernel, dim3((unsigned)nh), dim3(kLanes), 0, s, a);   // one wavefront per haplotype item
+    PD_HIP_TRY(hipEventRecord(c->ev0, s));
     // table launch: cross jobs over the haplotypes with few column classes
     if (n_cross_tab > 0) {
       PdArgs at = a;
@@ -804,7 +893,15 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   PD_HIP_TRY(hipMemcpyAsync(status, c->misc.p, 32, hipMemcpyDeviceToHost, s));
   const double ms_launched = ms_since(t_begin);
   PD_HIP_TRY(hipStreamSynchronize(s));
+  if (up_th.th.joinable()) up_th.th.join();   // (a sliced call: the stream has waited for every upload event by now)
+  PD_HIP_TRY(up_th.err);
   PD_HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  if (paired_packed && n_slices > 1)   // kernel time of a sliced call: its slices' launches plus the closing ones (the waits for the bus lie between them)
+    for (int k = 0; k < n_slices; k++) {
+      float ms = 0.f;
+      PD_HIP_TRY(hipEventElapsedTime(&ms, c->sl_ev0[k], c->sl_ev1[k]));
+      c->last_ms += ms;
+    }
 #ifdef GKL_PD_PROF
   {  // development build: where the table kernel's wavefronts spent their cycles (s_memtime)
     unsigned long long pr[16];

@@ -146,6 +146,9 @@ struct PdArgs {
   const uint8_t* job_notab;     // [listed jobs]
   const int32_t* job_ns;        // [listed jobs * ns_stride]: first step >= t at which some lane of the job sits on a special column
   int32_t ns_stride;
+  // a launch over one slice of a big paired call (pdhmm_api.hip): pdhmm_entries_kernel's first haplotype item; the first
+  // listed job of a launch that walks the list (n_jobs is then where it ends)
+  int32_t item_base, job_base;
 #ifdef GKL_PD_PROF
   unsigned long long* prof;     // development build: cycle and step counters of the table kernel
 #endif
@@ -162,7 +165,7 @@ __device__ __forceinline__ int pd_hap_of(const PdArgs& a, int p) { return a.cros
 // column, else NORMAL; DEL_START only -> INSIDE_DEL.  "Nearest flagged column before j" is an exclusive prefix
 // maximum of (2 * k + is_end) over the columns.
 __global__ __launch_bounds__(64) void pdhmm_entries_kernel(PdArgs a) {
-  const int p = blockIdx.x;
+  const int p = (int)blockIdx.x + a.item_base;
   const int lane = threadIdx.x;
   if (p >= a.n_hap_items) return;
   const int H = (int)a.hap_len[p];
@@ -297,10 +300,11 @@ struct PdExpandArgs {
   uint8_t* job_flags;
   const uint8_t* hap_ncls;      // table route of the paired layout (else NULL): per haplotype item, 0 = not eligible
   uint8_t* job_notab;           // ... -> its job is not the table kernel's
-  int32_t n_pairs, n_chunks, n_striped, rpl;
+  int32_t n_pairs, n_chunks, n_striped, rpl;   // pairs [pair_base, n_pairs), chunks [chunk_base, n_chunks): one slice of the call
+  int32_t pair_base, chunk_base;
 };
 __global__ __launch_bounds__(256) void pdhmm_expand_kernel(PdExpandArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x) + a.pair_base;
   if (i < a.n_pairs) {
     const int ch = a.place_chunk[i];
     if (ch >= 0) {
@@ -311,9 +315,10 @@ __global__ __launch_bounds__(256) void pdhmm_expand_kernel(PdExpandArgs a) {
       if (a.hap_ncls && a.hap_ncls[i] == 0) a.job_notab[a.n_striped + ch] = 1;
     }
   }
-  if (i < a.n_chunks) {
-    LaneSlot* dst = a.lanes + (int64_t)(a.n_striped + i) * kLanes;
-    for (int l = a.chunk_used[i]; l < kLanes; l++) dst[l] = LaneSlot{-1, 0};
+  const int ch = (int)(blockIdx.x * 256 + threadIdx.x) + a.chunk_base;
+  if (ch < a.n_chunks) {
+    LaneSlot* dst = a.lanes + (int64_t)(a.n_striped + ch) * kLanes;
+    for (int l = a.chunk_used[ch]; l < kLanes; l++) dst[l] = LaneSlot{-1, 0};
   }
 }
 
@@ -321,8 +326,8 @@ __global__ __launch_bounds__(256) void pdhmm_expand_kernel(PdExpandArgs a) {
 // paired layout, the clean packed jobs that are not the table kernel's likewise to the predicate launch's list
 __global__ __launch_bounds__(256) void pdhmm_collect_kernel(const uint8_t* job_flags, const uint8_t* job_striped, int n_general,
                                                            int32_t* full_jobs, int32_t* full_count, const uint8_t* job_notab,
-                                                           int32_t* hot_jobs, int32_t* hot_count) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
+                                                           int32_t* hot_jobs, int32_t* hot_count, int job_base) {
+  const int j = (int)(blockIdx.x * 256 + threadIdx.x) + job_base;   // listed jobs [job_base, n_general): one slice of the call
   if (j >= n_general || job_striped[j]) return;
   if (job_flags[j]) full_jobs[atomicAdd(full_count, 1)] = j;
   else if (job_notab && job_notab[j]) hot_jobs[atomicAdd(hot_count, 1)] = j;
@@ -341,11 +346,11 @@ struct PdJobNsArgs {
   const uint64_t* special_bits;
   int32_t sb_stride;
   int32_t* job_ns;
-  int32_t ns_stride, rpl;
+  int32_t ns_stride, rpl, job_base;
 };
 __global__ __launch_bounds__(64) void pdhmm_job_special_kernel(PdJobNsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pd_step_marks[];   // ns_stride bytes
-  const int j = blockIdx.x, lane = threadIdx.x;
+  const int j = (int)blockIdx.x + a.job_base, lane = threadIdx.x;
   if (a.job_striped[j] || a.job_flags[j] || a.job_notab[j]) return;
   const int n = a.job_steps[j] + 8;   // the program looks at most three steps past the job's last one
   for (int t = lane * 4; t < n; t += kLanes * 4) *reinterpret_cast<uint32_t*>(pd_step_marks + t) = 0u;
@@ -966,6 +971,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
     if (lane == 0) j = atomicAdd(a.next, 1);
     j = __builtin_amdgcn_readfirstlane(j);
     const bool listed_by_index = a.full_jobs != nullptr;  // the launch's listed jobs come from a list (the full launch; the predicate launch beside a paired table launch)
+    if (!listed_by_index) j += a.job_base;
     if (j >= (listed_by_index ? a.n_cross_jobs + a.full_count[0] : a.n_jobs)) break;
     if (j < a.n_cross_jobs) {
       const int k = j / a.n_chunks_cross, chunk = j - k * a.n_chunks_cross;
@@ -1104,12 +1110,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
   using Job = PdJob<FMA, false, true, true>;
   Job job;
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+#ifdef GKL_PD_PROF
+  if (lane == 0) atomicMin(a.prof + 15, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  unsigned long long pt_mark = __builtin_readcyclecounter();
+#define PD_PAIRED_MARK(k) { const unsigned long long now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.prof + (k), now - pt_mark); pt_mark = now; }
+#else
+#define PD_PAIRED_MARK(k)
+#endif
   for (;;) {
     int j = 0;
     if (lane == 0) j = atomicAdd(a.next, 1);
-    j = __builtin_amdgcn_readfirstlane(j);
+    j = __builtin_amdgcn_readfirstlane(j) + a.job_base;
     if (j >= a.n_jobs) break;
     if (a.job_striped[j] != 0 || a.job_flags[j] != 0 || a.job_notab[j] != 0) continue;
+    PD_PAIRED_MARK(5)
     const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
     const bool active = sl.read >= 0;
     const int p = active ? sl.read : a.job_pair[j];
@@ -1117,13 +1131,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pd
     const int H = (int)a.hap_len[p];
     job.setup(a, p, sl.block, n_blocks, active, init_condition / (double)H);
     job.build_table(lds_base, lane, a.class_codes + (int64_t)p * 8, kPdTabClasses);
+    PD_PAIRED_MARK(0)
+#ifdef GKL_PD_TIMING_SHARED_STREAMS   // timing experiment (tools/build_pd_variant.sh): 48 streams for all pairs -- what the kernel takes when its entries come from L2
+    const int64_t first = (int64_t)(p % 48) * a.entry_stride + kLanes - sl.block;
+#else
     const int64_t first = (int64_t)p * a.entry_stride + kLanes - sl.block;   // block k of a pair sees column j at step j + k
+#endif
     if constexpr (FMA && GKL_PD_ASM == 2)
       pd_job_asm(job, a.entries_tab, (uint32_t)(first * 4), a.job_steps[j], 0, a.job_ns + (int64_t)j * a.ns_stride);
     else
       job.run_packed(a.entries_tab + first, a.job_steps[j], false);
     if (job.holds_last) a.sums[p] = job.sum;
+    PD_PAIRED_MARK(1)
+#ifdef GKL_PD_PROF
+    if (lane == 0) { atomicAdd(a.prof + 12, 1ull); atomicAdd(a.prof + 8, (unsigned long long)a.job_steps[j]); }
+#endif
   }
+#ifdef GKL_PD_PROF
+  if (lane == 0) {
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    atomicMin(a.prof + 13, now);
+    atomicMax(a.prof + 14, now);
+  }
+#endif
 }
 
 // Self-test of the assumption behind kPdTabIdle (run once per process and device by gklhip_pdhmm_init): a workgroup with the

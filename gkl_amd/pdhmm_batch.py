@@ -36,6 +36,14 @@ class PdhmmBatch:
                           r(self.read_bases), r(self.read_qual), r(self.read_ins_qual), r(self.read_del_qual),
                           r(self.gcp), self.hap_lengths[idx], self.read_lengths[idx])
 
+    def pairs(self, idx=None):
+        """The pairs (trimmed to their lengths) in from_pairs' form."""
+        idx = range(self.batch) if idx is None else idx
+        hb, hp = (a.reshape(self.batch, self.max_hap_len) for a in (self.hap_bases, self.hap_pdbases))
+        rs = [a.reshape(self.batch, self.max_read_len) for a in (self.read_bases, self.read_qual, self.read_ins_qual,
+                                                                  self.read_del_qual, self.gcp)]
+        return [(hb[i, :self.hap_lengths[i]], hp[i, :self.hap_lengths[i]], *[a[i, :self.read_lengths[i]] for a in rs]) for i in idx]
+
     @staticmethod
     def from_pairs(pairs) -> "PdhmmBatch":
         """pairs: iterable of (hap_bases, hap_pdbases, read_bases, read_qual, ins, del, gcp) byte strings/arrays."""

@@ -55,6 +55,11 @@ def test_bench_line_single_gpu():
     assert d["comm"]["ranks_seen"] == 1 and d["comm"]["backend"] == "none" and d["comm"]["gather_bytes_per_rank"] == []
     conc = d["small_batch"]["concurrent"]
     assert all(conc[f"callers_{n}"]["aggregate_gcups"] > 0 for n in (1, 4, 16))
+    # the deployment GATK produces: P processes x one caller on the one GPU
+    pr = d["small_batch"]["processes"]
+    assert "error" not in pr, pr
+    for n in (4, 16):
+        assert pr[f"processes_{n}"]["aggregate_gcups"] > 0 and 0 < pr[f"processes_{n}"]["p50_ms"] <= pr[f"processes_{n}"]["p99_ms"]
     er = d["small_batch"]["eighth_device_resident"]
     assert "error" not in er and er["two_streams_one_context_ms_per_step"] > 0
 

@@ -660,6 +660,50 @@ def test_pdhmm_gpu_paired_large_batch_by_replication(pd_ctx, pd_oracle):
 
 
 @pytest.mark.gpu
+def test_pdhmm_gpu_paired_sliced_call_equals_the_unsliced_one(pd_ctx, pd_oracle, monkeypatch):
+    # A big paired call (>= 65 536 pairs and >= 64 MB of padded input) is cut into slices of consecutive pairs whose
+    # kernels run while the later slices still cross PCIe: per-slice packing, entry / expand / collect / special / table
+    # launches over ranges of items and listed jobs, the striped, odd-base, ineligible and tail jobs at the end.  The
+    # holders fixture six times over with 3 000 random pairs of every other kind spread through it (reads of up to 420
+    # bases: striped jobs; haplotypes with bases outside ACGTN; with seven or more column classes) and a pair count that
+    # leaves a tail: same bits as the same call unsliced (GKL_HIP_PDHMM_PIPELINE=0), and the oracle's on the random pairs.
+    from gkl_amd import native
+    _, _, b1, _ = holders_fixture_batch()
+    rng = np.random.RandomState(6060)
+    extra = random_pd_batch(rng, 3003, read_len=(1, 420), hap_len=(20, 330), odd_haps=0.2)
+    base = b1.pairs() * 6
+    at = np.sort(rng.choice(len(base), extra.batch, replace=False))
+    pairs, e = [], extra.pairs()
+    nxt = 0
+    for i, pr in enumerate(base):
+        if nxt < len(at) and at[nxt] == i:
+            pairs.append(e[nxt])
+            nxt += 1
+        pairs.append(pr)
+    big = PdhmmBatch.from_pairs(pairs)
+    assert big.batch >= 65536 and big.batch % 8 != 0 and big.batch * (2 * big.max_hap_len + 5 * big.max_read_len) >= 64 << 20
+    got = pd_ctx.compute(big)
+    tab, pred, full = pd_ctx.last_routing()
+    assert tab > 0 and pred > 0 and full > 0, (tab, pred, full)
+    monkeypatch.setenv("GKL_HIP_PDHMM_PIPELINE", "0")
+    with native.PdhmmContext(fma_mode=pd_ctx.fma_mode, reference_tail=False) as c:
+        assert c.compute(big).tobytes() == got.tobytes()
+        assert c.last_routing() != (0, 0, 0)
+    # the random pairs sit at positions at[k] + k
+    pos = at + np.arange(len(at))
+    st, vec = pd_oracle.compute(extra, semantics=pd_ctx.sem)
+    assert st == 0 and got[pos].tobytes() == vec.tobytes()
+    # the default mode (GKL's scalar tail on the last `batch mod 8` pairs) through the sliced call
+    monkeypatch.delenv("GKL_HIP_PDHMM_PIPELINE")
+    sub = big.subset(np.arange(big.batch - 70003, big.batch))   # (70 003 = 3 mod 8: a scalar tail)
+    with native.PdhmmContext(fma_mode=1) as c:
+        a1 = c.compute(sub)
+    monkeypatch.setenv("GKL_HIP_PDHMM_PIPELINE", "0")
+    with native.PdhmmContext(fma_mode=1) as c:
+        assert c.compute(sub).tobytes() == a1.tobytes()
+
+
+@pytest.mark.gpu
 def test_pdhmm_gpu_argument_errors(pd_ctx):
     from gkl_amd import native
     b = random_pd_batch(np.random.RandomState(5), 8)
