@@ -686,6 +686,25 @@ def main():
                                          "note": "long reads mostly underflow in fp32 (2^120 scaling), so the fp64 pass dominates the call"}
                 except Exception as e:
                     res["long_reads"] = {"error": repr(e)}
+                # reads of more rows than a workgroup's wavefronts hold (> 2047 bases): super-stripes, the carry row through HBM
+                try:
+                    lb = make_batch(a.workload, 200, 32, seed=DEFAULT_SEED, read_len=(4000, 6000), hap_len=(5000, 7000))
+                    dlb = native.DeviceBatch.upload(lb, dev)
+                    lout = torch.empty(lb.n_pairs, dtype=torch.float64, device=dev)
+                    with native.PairHmmContext(device=dev_index, record_events=1) as lc:
+                        def long5_call():
+                            lc.compute_device(dlb, lout)
+                            torch.cuda.synchronize(dev)
+                        lms = _median_ms(long5_call, 3, 1)
+                        lst = lc.stats()
+                    res["long_reads_5k"] = {"workload": "200 reads of 4000-6000 bases x 32 haplotypes of 5000-7000", "ms_per_call": round(lms, 3),
+                                            "gcups": round(lb.cells / lms / 1e6, 1), "fp32_kernel_ms": round(lst["ms_fwd_main"], 3),
+                                            "fp32_kernel_gcups": round(lb.cells / lst["ms_fwd_main"] / 1e6, 1),
+                                            "fp64_pass_ms": round(lst["ms_fwd_fallback"], 3),
+                                            "fallback_fraction": round(lst["n_fallback"] / lb.n_pairs, 4),
+                                            "note": "pairhmm_fwd_super_kernel: super-stripes of 5 (fp32) / 7 (fp64) wavefronts x 512 rows"}
+                except Exception as e:
+                    res["long_reads_5k"] = {"error": repr(e)}
                 # the same shape without fallback pairs (one real active region)
                 reg = make_batch("region", a.reads, a.haps, seed=DEFAULT_SEED)
                 dreg = native.DeviceBatch.upload(reg, dev)

@@ -273,10 +273,31 @@ void launch_long(const FwdArgs<T>& a, int fma, int n_blocks, T* carry, int carry
 
 // long reads: workgroups of kWideWaves wavefronts per (read, haplotype run) job (pairhmm_fwd_wide_kernel: the asm programs'
 // arithmetic only); the unfused arithmetic keeps the one-wavefront striped kernel
+// compute wavefronts of a super-stripe workgroup (+ 1 helper): fp32 (149 VGPRs: three wavefronts per SIMD) 5 + 1, two workgroups
+// per CU; fp64 (252 VGPRs: two per SIMD, 16 KB tables) 7 + 1, one per CU
+template <typename T> constexpr int super_waves() { return 7; }
+template <typename T> constexpr int super_blocks_max() { return sizeof(T) == 8 ? 256 : 512; }
+// carry rows of the super-stripe kernel: two per workgroup, one 32-byte slot per step of the deepest array's longest stream
+inline int64_t super_steps(int carry_len, int max_read_len, int rpl) { return (int64_t)carry_len + 64 * (int64_t)((blocks_for(max_read_len, rpl) + kLanes - 1) / kLanes); }
 template <typename T, int RPL, int RPL_STRIPED>
-void launch_long_jobs(const FwdArgs<T>& a, int fma, int n_blocks, int max_read_len, T* carry, int carry_len, hipStream_t s) {
+void launch_long_jobs(const FwdArgs<T>& a, int fma, int n_blocks, int max_read_len, T* carry, int carry_len, hipStream_t s,
+                      unsigned char* xcarry = nullptr, int64_t xsteps = 0, int32_t* next2 = nullptr) {
   static const bool wide_env = [] { const char* v = getenv("GKLHIP_WIDE_LONG"); return !v || atoi(v) != 0; }();
+  static const bool super_env = [] { const char* v = getenv("GKLHIP_SUPER_LONG"); return !v || atoi(v) != 0; }();
   if (!fma || !wide_env) { launch_long<T, RPL_STRIPED>(a, fma, n_blocks, carry, carry_len, s); return; }
+  // a read that needs more wavefronts than a wide workgroup holds: super-stripes of super_waves<T>() wavefronts, the carry row through HBM
+  if (super_env && xcarry && next2 && (blocks_for(max_read_len, RPL) + kLanes - 1) / kLanes > kWideWavesMax) {
+    static_assert(RPL == kRplSuper, "the super-stripe kernel's array depth");
+    FwdArgs<T> sa = a;
+    sa.super_steps = xsteps;
+    hipLaunchKernelGGL((pairhmm_fwd_super_kernel<T, RPL, super_waves<T>()>), dim3(std::min(n_blocks, super_blocks_max<T>())), dim3(64 * (super_waves<T>() + 1)), 0, s,
+                       sa, xcarry);
+    // ... and the jobs it leaves (a haplotype no longer than a wavefront is deep, fp64: an N haplotype): one-wavefront stripes
+    sa.long_filter = 2;
+    sa.job_next = next2;
+    launch_long<T, RPL_STRIPED>(sa, fma, n_blocks, carry, carry_len, s);
+    return;
+  }
   // wavefronts per workgroup: what the call's longest read needs, at most kWideWavesMax (longer reads are striped in-kernel)
   const int waves = std::max(2, std::min(kWideWavesMax, (blocks_for(max_read_len, RPL) + kLanes - 1) / kLanes));
   if (waves == 2)      hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 2>), dim3(n_blocks), dim3(128), 0, s, a, carry, carry_len);
@@ -685,8 +706,15 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
   // persistent wavefronts of the striped long-read kernel: one per job up to two per SIMD (each owns two carry rows of
   // the longest stream group: ~110 KB)
   const int n_long_waves = (int)std::min<size_t>(2048, std::max<size_t>(512, std::max(long_jobs.size(), (size_t)n_long64 * plan.groups.size())));
+  // ... and, when a read needs more wavefronts than a wide workgroup holds, the super-stripe kernel's carry rows behind them
+  const size_t striped_carry_bytes = (size_t)n_long_waves * 2 * (3 * (size_t)carry_len + 64) * sizeof(double);
+  const bool super_long = (blocks_for(plan.max_read_len, kRplF32) + kLanes - 1) / kLanes > kWideWavesMax;
+  const int64_t xsteps = super_long ? super_steps(carry_len, plan.max_read_len, kRplF32) : 0;   // (fp32 and fp64 both run the long reads at 8 rows per lane)
+  static_assert(kRplF32 == kRplF64Wide, "one array depth for the long reads of both precisions");
+  unsigned char* xcarry = nullptr;
   if (n_long_main > 0 || n_long64 > 0) {
-    if ((rc = c->carry.reserve((size_t)n_long_waves * 2 * (3 * (size_t)carry_len + 64) * sizeof(double)))) return rc;
+    if ((rc = c->carry.reserve(striped_carry_bytes + (size_t)super_blocks_max<float>() * 2 * (size_t)xsteps * 32))) return rc;
+    if (super_long) xcarry = c->carry.as<unsigned char>() + striped_carry_bytes;
   }
   st.n_long_pairs = (int32_t)std::min<int64_t>((int64_t)n_long_main * n_haps, 0x7fffffff);
   st.n_chunks = plan.n_chunks;
@@ -709,7 +737,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       la.jobs = reinterpret_cast<const FwdJob*>(dp + L.long_jobs);
       la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
       la.job_next = c->counters.as<int32_t>() + 7;
-      launch_long_jobs<double, kRplF64Wide, kRplF64>(la, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s);
+      launch_long_jobs<double, kRplF64Wide, kRplF64>(la, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s, xcarry, xsteps, c->counters.as<int32_t>() + 12);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
     hipLaunchKernelGGL(finalize64_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, fa, 1);
@@ -739,7 +767,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       la.job_count = reinterpret_cast<const int32_t*>(dp + L.long_count);
       la.job_next = c->counters.as<int32_t>() + 7;
       if (rpl_main <= 4) launch_long<float, 4>(la, fma, n_long_waves, c->carry.as<float>(), carry_len, s);  // (2 is only chosen without long reads)
-      else               launch_long_jobs<float, kRplF32, kRplF32>(la, fma, n_long_waves, plan.max_read_len, c->carry.as<float>(), carry_len, s);
+      else               launch_long_jobs<float, kRplF32, kRplF32>(la, fma, n_long_waves, plan.max_read_len, c->carry.as<float>(), carry_len, s, xcarry, xsteps, c->counters.as<int32_t>() + 12);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[2], s));
 
@@ -862,7 +890,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
       ld.jobs = c->jobs_long.as<FwdJob>();
       ld.job_count = cnts + 8;
       ld.job_next = cnts + 9;
-      launch_long_jobs<double, kRplF64Wide, kRplF64>(ld, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s);
+      launch_long_jobs<double, kRplF64Wide, kRplF64>(ld, fma, n_long_waves, plan.max_read_len, c->carry.as<double>(), carry_len, s, xcarry, xsteps, cnts + 13);
     }
     if (ev) HIP_TRY(hipEventRecord(c->ev[4], s));
     // (log10 of the recomputed pairs / host-buffer calls: their packed words)

@@ -235,7 +235,7 @@ struct PlanArgs {
   const int64_t* read_off;
   int32_t rpl;           // rows per lane of the fp64 kernel
   int32_t max_len;       // longest read that fits a chunk at that rpl
-  int32_t* cnts;         // [0] fp64 pairs [2] jobs [3] next job [4] affected reads [5] chunks [8] long jobs [9] next long job
+  int32_t* cnts;         // [0] fp64 pairs [2] jobs [3] next job [4] affected reads [5] chunks [7] next long job (main pass) [8] long jobs [9] next long job [10] [11] arrival counters of the plan launches [12] [13] next long job of the striped launch behind a super-stripe launch (main / fp64 pass) [16..] stamps
                          // [10] [11] arrival counters of plan_policy_kernel / plan_jobs_kernel
   int32_t* hist;         // [n_haps + 2]
   int32_t* pos;          // [n_haps + 2]

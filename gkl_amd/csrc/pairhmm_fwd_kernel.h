@@ -114,6 +114,11 @@ struct FwdArgs {
   const int32_t* job_count;
   int32_t* job_next;
   int32_t asm_general;  // whole jobs in the generated asm programs (GKLHIP_ASM_GENERAL=0: C++ general steps around the fp32 fast block, C++ fp64 -- A/B and cross-checks)
+  // long-read jobs of a call whose reads need super-stripes: pairhmm_fwd_super_kernel takes the jobs that meet its programs'
+  // preconditions (super_takes below) and the striped kernel, launched behind it over the same list with long_filter = 2
+  // and its own counter, the rest -- the C++ stripes would cost the super kernel 25 registers and a wavefront per SIMD
+  int32_t long_filter;
+  int64_t super_steps;  // steps a super-stripe carry row holds
 };
 
 // Host finalisation (reference-exact log10f / log10 of the host libm) needs, per pair, either the raw
@@ -989,6 +994,27 @@ __device__ __forceinline__ void long_job_striped(const FwdArgs<T>& a, const FwdJ
     __threadfence_block();  // this stripe's carry stores before the next stripe's carry loads
   }
 }
+// Does the super-stripe kernel (kRplSuper rows per lane) run this long-read job, or does it fall to the one-wavefront stripes?
+// (Wave-uniform; evaluated the same way by both kernels.)
+constexpr int kRplSuper = 8;
+template <typename T>
+__device__ __forceinline__ bool super_takes(const FwdArgs<T>& a, const FwdJob& j, int lane) {
+  using Job = WaveJob<T, kRplSuper, true>;
+  if (!(Job::kAsmFast || Job::kAsm64) || !a.asm_general || a.super_steps <= 0) return false;
+  const int r = a.chunk_lanes[(int64_t)j.chunk * kLanes].read;
+  const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+  const int G = ((R + kRplSuper) / kRplSuper + kLanes - 1) / kLanes;
+  const int64_t t_end = 64 * (int64_t)(G - 1) + (a.hap_pos[j.hap_end - 1] - a.hap_pos[j.hap_begin] + a.hap_len[j.hap_end - 1]) + 64;
+  if (G > kPrerollMaxWaves || t_end > a.super_steps || a.hap_len[j.hap_begin] <= kLanes - 1) return false;
+  if (Job::kAsm64) {
+    if (a.packed_out) return false;
+    bool any_n = false;
+    for (int k = j.hap_begin + lane; k < j.hap_end; k += kLanes) any_n |= a.hap_has_n[k] != 0;
+    if (__ballot(any_n) != 0) return false;
+  }
+  return true;
+}
+
 template <typename T, int RPL, bool FMA>
 __global__ __launch_bounds__(64) void pairhmm_fwd_long_kernel(FwdArgs<T> a, T* carry, int carry_len) {
   using Job = WaveJob<T, RPL, FMA>;
@@ -1003,6 +1029,7 @@ __global__ __launch_bounds__(64) void pairhmm_fwd_long_kernel(FwdArgs<T> a, T* c
     idx = __builtin_amdgcn_readfirstlane(idx);
     if (idx >= n) break;
     const FwdJob j = a.jobs[idx];
+    if (a.long_filter == 2 && super_takes(a, j, lane)) continue;   // the super-stripe kernel's
     long_job_striped<T, RPL, FMA>(a, j, my, carry_len, lds);
   }
 }
@@ -1070,6 +1097,156 @@ __global__ __launch_bounds__(64 * kWideWaves) void pairhmm_fwd_wide_kernel(FwdAr
       if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
       else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
       else                                    fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+    }
+  }
+}
+
+
+// The helper wavefront of a super-stripe (pairhmm_fwd_super_kernel): producer of the ring into the first compute wavefront
+// (slots filled from the previous super-stripe's carry row `cin`), consumer of the ring out of the last one (slots copied into
+// this super-stripe's carry row `cout`); lane l moves the slot of step 64 k + l.
+template <int kSlot>
+__device__ __attribute__((noinline)) void super_helper(const uint64_t* cin, uint64_t* cout, uint32_t* flags, unsigned char* ring_first, unsigned char* ring_last,
+                                                       int f_first, int f_last, int f_drain, bool feed, bool drain, int t_end, int lane) {
+  constexpr int kRingSlots = 64, kWords = kSlot / 8;
+  typedef volatile uint32_t __attribute__((address_space(3))) LdsU32;
+  typedef volatile uint64_t __attribute__((address_space(3))) LdsU64;
+  LdsU32* vflags = (LdsU32*)(uintptr_t)(uint32_t)(uintptr_t)flags;   // (LDS addresses: the low 32 bits of the generic pointers)
+  LdsU64* ring_f = (LdsU64*)(uintptr_t)(uint32_t)(uintptr_t)ring_first;
+  LdsU64* ring_d = (LdsU64*)(uintptr_t)(uint32_t)(uintptr_t)ring_last;
+  int tf = feed ? 0 : t_end, td = drain ? 0 : t_end;
+  // lane l carries the slot of step 64 k + l (= ring slot l): the 64 steps in hand and the 64 behind them, fetched a whole
+  // ring ahead (an HBM round trip is longer than a group of eight steps).  Every pass moves as many steps as the
+  // neighbours allow -- up to a ring's worth -- not one group: at 8 fp32 rows per lane a group of eight steps is ~2 us of a
+  // compute wavefront, no more than one pass of this loop.
+  uint64_t cur[kWords], nxt[kWords];
+  auto fetch = [&](uint64_t (&dst)[kWords], int first) {
+#pragma unroll
+    for (int w = 0; w < kWords; w++)
+      dst[w] = (feed && first + lane < t_end) ? __hip_atomic_load(const_cast<uint64_t*>(cin) + (int64_t)(first + lane) * kWords + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  };
+  fetch(cur, 0);
+  fetch(nxt, kRingSlots);
+  while (tf < t_end || td < t_end) {
+    bool moved = false;
+    if (tf < t_end) {
+      // slot T may be overwritten once the first compute wavefront has fetched step T - 64; steps in hand end at the ring's end
+      int upto = (int)vflags[f_first] + kRingSlots;
+      const int hand = (tf & ~(kRingSlots - 1)) + kRingSlots;
+      upto = upto < hand ? upto : hand;
+      upto = upto < t_end ? upto : t_end;
+      if (upto < t_end) upto &= ~7;   // whole groups of eight (the consumer waits for group ends)
+      if (upto > tf) {
+        const int first = tf & (kRingSlots - 1), cnt = upto - tf;
+        if (lane >= first && lane < first + cnt) {
+#pragma unroll
+          for (int w = 0; w < kWords; w++) ring_f[lane * kWords + w] = cur[w];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        tf = upto;
+        if (lane == 0) vflags[0] = (uint32_t)tf;
+        if ((tf & (kRingSlots - 1)) == 0) {
+#pragma unroll
+          for (int w = 0; w < kWords; w++) cur[w] = nxt[w];
+          fetch(nxt, tf + kRingSlots);
+        }
+        moved = true;
+      }
+    }
+    if (td < t_end) {
+      int done = (int)vflags[f_last];          // steps the last compute wavefront has finished (published per group of eight)
+      done = done < t_end ? done : t_end;
+      done = done < td + kRingSlots ? done : td + kRingSlots;
+      if (done > td) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int cnt = done - td;
+        if (lane < cnt) {
+          const int at = ((td + lane) & (kRingSlots - 1)) * kWords;
+#pragma unroll
+          for (int w = 0; w < kWords; w++) cout[(int64_t)(td + lane) * kWords + w] = ring_d[at + w];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        td = done;
+        if (lane == 0) vflags[f_drain] = (uint32_t)td;
+        moved = true;
+      }
+    }
+    if (!moved) __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// Reads of ANY length at the wide kernel's speed (round 5): a read whose rows need more wavefronts than one workgroup
+// holds is processed in SUPER-STRIPES of kW wavefronts -- the reference's stripes with their carry row
+// (avx-pairhmm-template.h:249, 291-323), here 64 * kW * RPL rows at a time.  Inside a super-stripe the kW compute wavefronts
+// are the wide kernel's (same generated programs, the LDS rings between them); what crosses from one super-stripe to the
+// next -- the bottom row of its last lane, one (M, X, Y) triple per step -- goes through HBM, carried by ONE helper
+// wavefront per workgroup that plays the neighbour on both open ends: towards the first compute wavefront it is the
+// producer of a ring (slots filled from the previous super-stripe's carry row), towards the last one the consumer of a
+// ring (slots copied out into this super-stripe's carry row), with the same step-counter protocol the compute
+// wavefronts use among themselves.  The programs run on GLOBAL wavefront indices (wavefront g of G: 64 g steps of
+// pre-roll, t_end of the whole array), so step T of every super-stripe is step T of the one long array and the carry
+// row is simply indexed by T; the later super-stripes pay 64 * kW * s extra pre-roll steps for it (~5 % at 15 kb).
+// A job that fails the programs' preconditions is left to the striped kernel, launched behind this one (FwdArgs::long_filter).
+template <typename T, int RPL, int kW>
+__global__ __launch_bounds__(64 * (kW + 1)) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 2 : 4))) void pairhmm_fwd_super_kernel(FwdArgs<T> a, unsigned char* xcarry) {
+  const int64_t xsteps = a.super_steps;
+  using Job = WaveJob<T, RPL, true>;
+  constexpr int kSlot = sizeof(T) == 8 ? 32 : 16;   // one (M, X, Y) triple (the wide programs' ring slot)
+  constexpr int kRingSlots = 64;
+  constexpr int kWords = kSlot / 8;                 // 64-bit words per slot
+  __shared__ __attribute__((aligned(16))) unsigned char tables[kW][Job::kLdsBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char rings[kW + 1][kRingSlots * kSlot];   // ring w: into compute wavefront w (0: from the helper); ring kW: into the helper
+  __shared__ uint32_t flags[kW + 2];   // [0] helper as producer (steps fed), [1 + w] compute wavefront w, [kW + 1] helper as consumer (steps drained)
+  __shared__ int32_t s_job;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;   // wv < kW: compute, kW: the helper
+  const int n = *a.job_count;
+  uint64_t* xbuf = reinterpret_cast<uint64_t*>(xcarry + (int64_t)blockIdx.x * 2 * xsteps * kSlot);
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_job = atomicAdd(a.job_next, 1);
+    __syncthreads();
+    const int idx = __builtin_amdgcn_readfirstlane(s_job);
+    if (idx >= n) break;
+    const FwdJob j = a.jobs[idx];
+    const int r = a.chunk_lanes[(int64_t)j.chunk * kLanes].read;
+    const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
+    const int n_blocks = (R + RPL) / RPL;
+    const int G = (n_blocks + kLanes - 1) / kLanes;          // wavefronts of the whole array
+    const int t_end = 64 * (G - 1) + (a.hap_pos[j.hap_end - 1] - a.hap_pos[j.hap_begin] + a.hap_len[j.hap_end - 1]) + 64;   // = the programs' own
+    static_assert(RPL == kRplSuper, "super_takes speaks for this kernel");
+    if (!super_takes(a, j, lane)) continue;   // (the striped kernel's, launched behind this one)
+    if constexpr ((Job::kAsmFast || Job::kAsm64) && RPL >= 8) {
+      const int n_stripes = (G + kW - 1) / kW;
+      for (int st = 0; st < n_stripes; st++) {
+        __syncthreads();   // the previous super-stripe is done in every wavefront: tables, rings and flags are free, its carry row is complete
+        if (threadIdx.x < kW + 2) flags[threadIdx.x] = 0;
+        __syncthreads();
+        const int nw = G - st * kW < kW ? G - st * kW : kW;   // compute wavefronts of this super-stripe
+        const bool feed = st > 0, drain = st + 1 < n_stripes;
+        if (wv < nw) {
+          const int g = st * kW + wv;
+          LaneSlot slot;
+          slot.block = g * kLanes + lane;
+          slot.read = slot.block < n_blocks ? r : -1;
+          Job job;
+          job.lds = tables[wv];
+          job.setup(a, lane, slot, /*full_skew=*/true);
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t ring_in = (uint32_t)(uintptr_t)rings[wv];
+          const uint32_t ring_out = (uint32_t)(uintptr_t)rings[wv + 1 < nw ? wv + 1 : kW];
+          const uint32_t f_own = (uint32_t)(uintptr_t)&flags[1 + wv], f_prod = (uint32_t)(uintptr_t)&flags[wv],
+                         f_cons = (uint32_t)(uintptr_t)&flags[wv + 1 < nw ? wv + 2 : kW + 1];
+          if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+          else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+          else                                    fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+        } else if (wv == kW && (feed || drain)) {
+          // the helper (its own function: its registers must not weigh on the compute wavefronts' allocation)
+          super_helper<kSlot>(reinterpret_cast<const uint64_t*>(xbuf + (int64_t)((st + 1) & 1) * xsteps * kWords), xbuf + (int64_t)(st & 1) * xsteps * kWords,
+                              flags, rings[0], rings[kW], /*flag of the first compute wavefront*/ 1, /*of the last*/ nw, /*own, as consumer*/ kW + 1,
+                              feed, drain, t_end, lane);
+          __threadfence();   // this super-stripe's carry row before the next one's loads
+        }
+      }
     }
   }
 }

@@ -637,7 +637,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   // jobs are found on the device.  Needs the program's 32-bit entry offsets to reach every item's stream and the step
   // marks of a job to fit the special kernel's LDS.
   const size_t n_packed = cross ? 0 : (size_t)n_general - n_striped;
-  const bool tab_paired = !cross && c->use_table && n_packed > 0 && nh * (size_t)entry_stride * 4 < ((size_t)1 << 32) && entry_stride <= 48 * 1024;
+  const bool tab_paired = !cross && c->use_table && n_packed > 0 && nh * (size_t)entry_stride * 4 < ((size_t)1 << 32) && entry_stride <= 12 * 1024;
   const bool tab_paired_asm = tab_paired && c->fma_mode == 1 && GKL_PD_ASM == 2;   // (the C++ step loops ballot on the lanes' own entries)
   const int sb_stride = entry_stride / 64, ns_stride = entry_stride;
   const size_t x_nc = 0, x_cc = up(nh), x_sb = x_cc + up(nh * 32), x_nt = x_sb + up(nh * (size_t)sb_stride * 8), x_hj = x_nt + up((size_t)n_general),
@@ -803,8 +803,9 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
           PdJobNsArgs na;
           na.lanes = a.lanes; na.job_steps = a.job_steps; na.job_striped = a.job_striped; na.job_flags = a.job_flags; na.job_notab = a.job_notab;
           na.read_len = a.read_len; na.hap_len = a.hap_len; na.special_bits = a.special_bits; na.sb_stride = sb_stride;
-          na.job_ns = reinterpret_cast<int32_t*>(dx + x_ns); na.ns_stride = ns_stride; na.rpl = kPdRpl; na.job_base = j0;
-          hipLaunchKernelGGL(pdhmm_job_special_kernel, dim3((unsigned)(j1 - j0)), dim3(kLanes), (size_t)ns_stride, s, na);
+          na.job_ns = reinterpret_cast<int32_t*>(dx + x_ns); na.ns_stride = ns_stride; na.rpl = kPdRpl; na.job_base = j0; na.job_end = j1;
+          hipLaunchKernelGGL(pdhmm_job_special_kernel, dim3((unsigned)((j1 - j0 + kPdNsJobsPerBlock - 1) / kPdNsJobsPerBlock)), dim3(kLanes * kPdNsJobsPerBlock),
+                             (size_t)ns_stride * kPdNsJobsPerBlock, s, na);
         }
         PdArgs at = a;
         at.n_cross_jobs = 0; at.job_base = j0; at.n_jobs = j1;

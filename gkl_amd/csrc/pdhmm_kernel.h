@@ -346,15 +346,19 @@ struct PdJobNsArgs {
   const uint64_t* special_bits;
   int32_t sb_stride;
   int32_t* job_ns;
-  int32_t ns_stride, rpl, job_base;
+  int32_t ns_stride, rpl, job_base, job_end;
 };
-__global__ __launch_bounds__(64) void pdhmm_job_special_kernel(PdJobNsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char pd_step_marks[];   // ns_stride bytes
-  const int j = (int)blockIdx.x + a.job_base, lane = threadIdx.x;
-  if (a.job_striped[j] || a.job_flags[j] || a.job_notab[j]) return;
+constexpr int kPdNsJobsPerBlock = 4;   // one wavefront per job, four to a workgroup (a quarter of the workgroups to dispatch)
+__global__ __launch_bounds__(64 * kPdNsJobsPerBlock) void pdhmm_job_special_kernel(PdJobNsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pd_step_marks_all[];   // ns_stride bytes per wavefront
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int j = (int)blockIdx.x * kPdNsJobsPerBlock + wave + a.job_base;
+  unsigned char* pd_step_marks = pd_step_marks_all + (size_t)wave * (size_t)a.ns_stride;
+  // (no workgroup barrier below: a wavefront works on its own job and its own marks; its LDS operations complete in order)
+  if (j >= a.job_end || a.job_striped[j] || a.job_flags[j] || a.job_notab[j]) return;
   const int n = a.job_steps[j] + 8;   // the program looks at most three steps past the job's last one
   for (int t = lane * 4; t < n; t += kLanes * 4) *reinterpret_cast<uint32_t*>(pd_step_marks + t) = 0u;
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   const LaneSlot sl = a.lanes[(int64_t)j * kLanes + lane];
   uint64_t heads = __ballot(sl.read >= 0 && sl.block == 0);
   while (heads) {
@@ -371,7 +375,8 @@ __global__ __launch_bounds__(64) void pdhmm_job_special_kernel(PdJobNsArgs a) {
       }
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   int32_t* ns = a.job_ns + (int64_t)j * a.ns_stride;
   int32_t behind = 0x7fffffff;
   for (int base = ((n - 1) / kLanes) * kLanes; base >= 0; base -= kLanes) {

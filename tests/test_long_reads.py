@@ -108,3 +108,24 @@ def test_wide_and_striped_kernels_agree_and_fallbacks_hold(native, oracle, monke
                 res[mode, dbl, 1] = check(c, oracle, b2, dbl)
     u = res["wide", False, 0][1]
     assert u.any() and not u.all()
+
+
+@pytest.mark.parametrize("use_double", [False, True])
+def test_reads_of_5kb_and_15kb_in_super_stripes(native, oracle, use_double, monkeypatch):
+    """Round 5: a read that needs more wavefronts than one workgroup holds runs in SUPER-STRIPES (pairhmm_fwd_super_kernel): the
+    wide kernel's wavefronts with their LDS rings inside a super-stripe, the carry row between super-stripes through HBM
+    by a helper wavefront that plays producer and consumer on the open ends of the workgroup's array.  5 kb and 15 kb
+    reads cut out of their haplotypes (related: the likelihood mass crosses every boundary), sizes on both sides of a
+    super-stripe's edge (5 x 512 rows in fp32, 7 x 512 in fp64), against the oracle bit for bit in both precisions; and
+    the same call with the super-stripes switched off (one-wavefront stripes through memory) gives the same bits."""
+    rng = np.random.RandomState(4711)
+    read_lens = [5000, 2559, 2560, 3583, 3584, 5119, 5121, 7168, 15000, 12000, 300]
+    b = related_batch(rng, [15500, 16000, 5200, 7400], read_lens, err=0.005)
+    with native.PairHmmContext(use_double=use_double, record_events=True) as c:
+        out, u = check(c, oracle, b, use_double)
+        assert c.stats()["n_long_pairs"] > 0
+    oo = oracle.batch(b, use_double=use_double, n_threads=8).reshape(b.n_reads, b.n_haps)
+    assert (oo[np.arange(b.n_reads), np.arange(b.n_reads) % 4] > -3000).all(), "the related pairs carry real likelihoods"
+    monkeypatch.setenv("GKLHIP_SUPER_LONG", "0")
+    with native.PairHmmContext(use_double=use_double) as c:
+        assert np.array_equal(bits(c.compute(b)), bits(out))

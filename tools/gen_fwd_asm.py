@@ -649,9 +649,11 @@ def main(path):
     o.append("namespace gklhip {")
     o.append("constexpr uint32_t kEntPreroll = 0xBFFFFFFFu;   // separator-type entry that no haplotype owns (fill and drain)")
     o.append("constexpr uint32_t kEntNoEmit = 0xBFFFFFFEu;    // separator \"in flight\" while there is none: matches no entry")
-    o.append("// the drain's entries (and a wide job's pre-roll and tail: up to 64 * 3 + 64 steps), read eight at a time")
-    o.append("__device__ const uint32_t kPrerollWords[264] = {")
-    for _ in range(33):
+    o.append("// the drain's entries (and a wide job's pre-roll and tail: up to 64 steps per wavefront of the read's array + 64), read")
+    o.append("// eight at a time; kPrerollMaxWaves: the deepest array a wide program may be run for (reads of 64 * 64 * RPL - 1 bases)")
+    o.append("constexpr int kPrerollMaxWaves = 64;")
+    o.append("__device__ const uint32_t kPrerollWords[64 * kPrerollMaxWaves + 72] = {")
+    for _ in range((64 * 64 + 72) // 8):
         o.append("    kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll, kEntPreroll,")
     o.append("};")
     o.append("typedef const int32_t __attribute__((address_space(4))) ConstI32;   // plan arrays: written by an earlier kernel, s_load here")

@@ -8,7 +8,8 @@ from gkl_amd import native  # noqa: E402
 from gkl_amd.synth import DEFAULT_SEED, make_batch  # noqa: E402
 
 for n, h, rl, hl in ((200, 16, (600, 1000), (900, 1100)), (1000, 32, (600, 1000), (900, 1100)), (1000, 32, (1000, 1000), (1200, 1400)),
-                     (2000, 32, (1500, 2000), (2000, 2400)), (1000, 32, (520, 640), (700, 900))):
+                     (2000, 32, (1500, 2000), (2000, 2400)), (1000, 32, (520, 640), (700, 900)),
+                     (200, 32, (4000, 6000), (5000, 7000)), (64, 32, (14000, 16000), (15000, 17000))):
     b = make_batch("hc", n, h, seed=DEFAULT_SEED, read_len=rl, hap_len=hl)
     db = native.DeviceBatch.upload(b)
     for dbl in (False, True):
