@@ -335,6 +335,8 @@ def main():
     ap.add_argument("--reads", type=int, default=10000)
     ap.add_argument("--haps", type=int, default=128)
     ap.add_argument("--double", action="store_true", help="useDoublePrecision (BASELINE config 3)")
+    ap.add_argument("--fma-mode", type=int, default=1, choices=[0, 1], help="1 (default): the arithmetic of GKL's AVX-512 object (gcc-contracted FMAs); "
+                                                                           "0: of its AVX object (unfused: 12 operations per cell), what GKL computes on a host without AVX-512")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single_call / small_batch / host_path / no_fallback sub-records")
     ap.add_argument("--weak", action="store_true", help="N>1: every rank owns its own --reads reads (weak scaling) instead of a "
@@ -413,7 +415,7 @@ def main():
     # record_events=2: kernels are bracketed with HIP events but no call synchronises, so the host-side planning of
     # step k+1 overlaps the kernels of step k; the event times are read after the timed region.
     n_ctx = 2 if (a.overlap or (world > 1 and not a.no_overlap)) else 1
-    ctxs = [native.PairHmmContext(use_double=a.double, device=dev_index, record_events=2) for _ in range(n_ctx)]
+    ctxs = [native.PairHmmContext(use_double=a.double, device=dev_index, record_events=2, fma_mode=a.fma_mode) for _ in range(n_ctx)]
     streams = [torch.cuda.Stream(dev) for _ in range(n_ctx)]
     # N>1: the gather of step k (RCCL, its own stream) overlaps the kernels of step k+1; result buffers rotate
     gather = PipelinedGather(rows, a.haps, comm_dev, dist if world > 1 else _SingleRank(), depth=max(2, n_ctx))
@@ -467,7 +469,7 @@ def main():
     ms_main, ms_fb, ms_dev = ([t[i] for t in times] for i in range(3))
     if rank == 0:
         st = ctxs[0].stats()
-        with native.PairHmmContext(use_double=a.double, device=dev_index, record_events=1) as probe:
+        with native.PairHmmContext(use_double=a.double, device=dev_index, record_events=1, fma_mode=a.fma_mode) as probe:
             pout = torch.empty(batch.n_pairs, dtype=torch.float64, device=dev)
             for _ in range(2):
                 probe.compute_device(dbatch, pout)
@@ -532,7 +534,8 @@ def main():
                                        f"overlapped with the next step" if strong else
                                        f"every rank its own reads x{world}; gather to rank 0" if world > 1 else "single GPU"),
                        "step_overlap": f"{n_ctx} contexts on {n_ctx} streams alternate between consecutive steps" if n_ctx > 1 else "none",
-                       "finalize": "device log10 in double"},
+                       "finalize": "device log10 in double",
+                       "arithmetic": "AVX-512 object's (gcc-contracted FMAs: 8 operations per cell)" if a.fma_mode else "AVX object's (unfused: 12 operations per cell)"},
             # "mfma" = the compute roofline of the bench contract, priced at the dense MFMA peak of the dtype (which
             # for fp32/fp64 equals the vector peak); the kernel itself is vector-ALU code, see `note`
             "roofline": {"bound": "mfma", "limiter": "valu-fp64 issue" if a.double else "valu-fp32 issue",
@@ -583,7 +586,7 @@ def main():
             "plan": {"chunks": st["n_chunks"], "hap_groups": st["n_hap_groups"], "rows_per_lane": st["rows_per_lane"],
                      "lane_fill": round(st["lane_fill"], 4)},
         }
-        if world == 1 and not a.no_extras and not a.double and n_ctx == 1:
+        if world == 1 and not a.no_extras and not a.double and n_ctx == 1 and a.fma_mode == 1:
             try:
                 # two callers on one GPU (what the JNI shim's slots give concurrent GATK threads, and what every rank of
                 # an N>1 run does): two contexts on two streams alternate between consecutive steps

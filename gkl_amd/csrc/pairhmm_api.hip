@@ -284,14 +284,14 @@ void launch_long_jobs(const FwdArgs<T>& a, int fma, int n_blocks, int max_read_l
                       unsigned char* xcarry = nullptr, int64_t xsteps = 0, int32_t* next2 = nullptr) {
   static const bool wide_env = [] { const char* v = getenv("GKLHIP_WIDE_LONG"); return !v || atoi(v) != 0; }();
   static const bool super_env = [] { const char* v = getenv("GKLHIP_SUPER_LONG"); return !v || atoi(v) != 0; }();
-  if (!fma || !wide_env) { launch_long<T, RPL_STRIPED>(a, fma, n_blocks, carry, carry_len, s); return; }
+  if (!wide_env) { launch_long<T, RPL_STRIPED>(a, fma, n_blocks, carry, carry_len, s); return; }
   // a read that needs more wavefronts than a wide workgroup holds: super-stripes of super_waves<T>() wavefronts, the carry row through HBM
   if (super_env && xcarry && next2 && (blocks_for(max_read_len, RPL) + kLanes - 1) / kLanes > kWideWavesMax) {
     static_assert(RPL == kRplSuper, "the super-stripe kernel's array depth");
     FwdArgs<T> sa = a;
     sa.super_steps = xsteps;
-    hipLaunchKernelGGL((pairhmm_fwd_super_kernel<T, RPL, super_waves<T>()>), dim3(std::min(n_blocks, super_blocks_max<T>())), dim3(64 * (super_waves<T>() + 1)), 0, s,
-                       sa, xcarry);
+    if (fma) hipLaunchKernelGGL((pairhmm_fwd_super_kernel<T, RPL, super_waves<T>(), true>), dim3(std::min(n_blocks, super_blocks_max<T>())), dim3(64 * (super_waves<T>() + 1)), 0, s, sa, xcarry);
+    else     hipLaunchKernelGGL((pairhmm_fwd_super_kernel<T, RPL, super_waves<T>(), false>), dim3(std::min(n_blocks, super_blocks_max<T>())), dim3(64 * (super_waves<T>() + 1)), 0, s, sa, xcarry);
     // ... and the jobs it leaves (a haplotype no longer than a wavefront is deep, fp64: an N haplotype): one-wavefront stripes
     sa.long_filter = 2;
     sa.job_next = next2;
@@ -300,9 +300,15 @@ void launch_long_jobs(const FwdArgs<T>& a, int fma, int n_blocks, int max_read_l
   }
   // wavefronts per workgroup: what the call's longest read needs, at most kWideWavesMax (longer reads are striped in-kernel)
   const int waves = std::max(2, std::min(kWideWavesMax, (blocks_for(max_read_len, RPL) + kLanes - 1) / kLanes));
-  if (waves == 2)      hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 2>), dim3(n_blocks), dim3(128), 0, s, a, carry, carry_len);
-  else if (waves == 3) hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 3>), dim3(n_blocks), dim3(192), 0, s, a, carry, carry_len);
-  else                 hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 4>), dim3(n_blocks), dim3(256), 0, s, a, carry, carry_len);
+  if (fma) {
+    if (waves == 2)      hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 2>), dim3(n_blocks), dim3(128), 0, s, a, carry, carry_len);
+    else if (waves == 3) hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 3>), dim3(n_blocks), dim3(192), 0, s, a, carry, carry_len);
+    else                 hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, true, 4>), dim3(n_blocks), dim3(256), 0, s, a, carry, carry_len);
+  } else {   // the unfused arithmetic (fma_mode 0): the same kernels over the "...n" programs
+    if (waves == 2)      hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, false, 2>), dim3(n_blocks), dim3(128), 0, s, a, carry, carry_len);
+    else if (waves == 3) hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, false, 3>), dim3(n_blocks), dim3(192), 0, s, a, carry, carry_len);
+    else                 hipLaunchKernelGGL((pairhmm_fwd_wide_kernel<T, RPL, false, 4>), dim3(n_blocks), dim3(256), 0, s, a, carry, carry_len);
+  }
 }
 
 // A small host-buffer call, planned and staged but not launched: SmallCombiner decides how it reaches the device (on

@@ -230,10 +230,10 @@ struct WaveJob {
   static constexpr int kCodes = sizeof(T) == 8 ? 4 : 5;
   static constexpr int kLdsBytes = kCodes * kRowBytes;  // idle columns are handled in step_any
   // fp32, 8 rows per lane, the AVX-512 object's FMA pattern (the default arithmetic): the unrolled loop is the generated asm block
-  static constexpr bool kAsmFast = GKLHIP_FAST_ASM && sizeof(T) == 4 && (RPL == 8 || RPL == 4 || RPL == 2) && FMA;
+  static constexpr bool kAsmFast = GKLHIP_FAST_ASM && sizeof(T) == 4 && (RPL == 8 || RPL == 4 || RPL == 2);   // (both arithmetics: FMA = false takes the "...n" programs)
   // fp64, 10 rows per lane (the packed recomputation pass and the all-fp64 mode), same arithmetic: whole jobs in asm
   // (and 8: the wide long-read kernel, whose workgroups hold several wavefronts' prior tables)
-  static constexpr bool kAsm64 = GKLHIP_FAST_ASM && sizeof(T) == 8 && (RPL == 10 || RPL == 8 || RPL == 6 || RPL == 4 || RPL == 2) && FMA;
+  static constexpr bool kAsm64 = GKLHIP_FAST_ASM && sizeof(T) == 8 && (RPL == 10 || RPL == 8 || RPL == 6 || RPL == 4 || RPL == 2);
   static_assert(RPL % kPerVec == 0, "RPL must fill whole 16-byte vectors");
   using Vec = T __attribute__((ext_vector_type(kPerVec)));
 
@@ -550,14 +550,25 @@ struct WaveJob {
         }
       }
       if (whole) {
-        if constexpr (kAsm64 && RPL == 10)     fwd_asm_run_f64r10(*this, a, lane, hap_begin, hap_end);
-        else if constexpr (kAsm64 && RPL == 8) fwd_asm_run_f64r8(*this, a, lane, hap_begin, hap_end);
-        else if constexpr (kAsm64 && RPL == 6) fwd_asm_run_f64r6(*this, a, lane, hap_begin, hap_end);
-        else if constexpr (kAsm64 && RPL == 4) fwd_asm_run_f64r4(*this, a, lane, hap_begin, hap_end);
-        else if constexpr (kAsm64)             fwd_asm_run_f64r2(*this, a, lane, hap_begin, hap_end);
-        else if constexpr (RPL == 8)           fwd_asm_run_f32r8(*this, a, lane, hap_begin, hap_end);
-        else if constexpr (RPL == 4)           fwd_asm_run_f32r4(*this, a, lane, hap_begin, hap_end);
-        else                                   fwd_asm_run_f32r2(*this, a, lane, hap_begin, hap_end);
+        if constexpr (FMA) {
+          if constexpr (kAsm64 && RPL == 10)     fwd_asm_run_f64r10(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (kAsm64 && RPL == 8) fwd_asm_run_f64r8(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (kAsm64 && RPL == 6) fwd_asm_run_f64r6(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (kAsm64 && RPL == 4) fwd_asm_run_f64r4(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (kAsm64)             fwd_asm_run_f64r2(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (RPL == 8)           fwd_asm_run_f32r8(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (RPL == 4)           fwd_asm_run_f32r4(*this, a, lane, hap_begin, hap_end);
+          else                                   fwd_asm_run_f32r2(*this, a, lane, hap_begin, hap_end);
+        } else {   // the AVX translation unit's unfused arithmetic (fma_mode 0)
+          if constexpr (kAsm64 && RPL == 10)     fwd_asm_run_f64r10n(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (kAsm64 && RPL == 8) fwd_asm_run_f64r8n(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (kAsm64 && RPL == 6) fwd_asm_run_f64r6n(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (kAsm64 && RPL == 4) fwd_asm_run_f64r4n(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (kAsm64)             fwd_asm_run_f64r2n(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (RPL == 8)           fwd_asm_run_f32r8n(*this, a, lane, hap_begin, hap_end);
+          else if constexpr (RPL == 4)           fwd_asm_run_f32r4n(*this, a, lane, hap_begin, hap_end);
+          else                                   fwd_asm_run_f32r2n(*this, a, lane, hap_begin, hap_end);
+        }
         return;
       }
     }
@@ -573,7 +584,7 @@ struct WaveJob {
       if (kCodes == 4 && a.hap_has_n[k]) fast_from = sep_at;  // an 'N' somewhere in it: general steps throughout
       const int slow_end = fast_from < sep_at ? fast_from : sep_at;
       run_any(a, sp, t, slow_end, lane, hap_begin, hap_end, k_cur, orig_cur, y0_next);
-      if constexpr (kAsmFast && RPL == 8) {
+      if constexpr (kAsmFast && RPL == 8 && FMA) {   // (the fast blocks alone exist for the contracted arithmetic only)
         fwd_fast_asm_f32r8(*this, sp, t, sep_at, lane);
       } else {
         for (; t + U <= sep_at; t += U) {
@@ -1094,9 +1105,15 @@ __global__ __launch_bounds__(64 * kWideWaves) void pairhmm_fwd_wide_kernel(FwdAr
       const uint32_t ring_out = wave + 1 < kWideWaves ? (uint32_t)(uintptr_t)rings[wave < kWideWaves - 1 ? wave : 0] : 0u;
       const uint32_t f_own = (uint32_t)(uintptr_t)&flags[wave], f_prod = (uint32_t)(uintptr_t)&flags[wave > 0 ? wave - 1 : 0],
                      f_cons = (uint32_t)(uintptr_t)&flags[wave + 1 < kWideWaves ? wave + 1 : wave];
-      if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
-      else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
-      else                                    fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+      if constexpr (FMA) {
+        if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+        else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+        else                                    fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+      } else {
+        if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10n(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+        else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8n(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+        else                                    fwd_asm_run_wide_f32r8n(job, a, lane, j.hap_begin, j.hap_end, wave, n_waves, ring_in, ring_out, f_own, f_prod, f_cons);
+      }
     }
   }
 }
@@ -1187,10 +1204,10 @@ __device__ __attribute__((noinline)) void super_helper(const uint64_t* cin, uint
 // pre-roll, t_end of the whole array), so step T of every super-stripe is step T of the one long array and the carry
 // row is simply indexed by T; the later super-stripes pay 64 * kW * s extra pre-roll steps for it (~5 % at 15 kb).
 // A job that fails the programs' preconditions is left to the striped kernel, launched behind this one (FwdArgs::long_filter).
-template <typename T, int RPL, int kW>
+template <typename T, int RPL, int kW, bool FMA>
 __global__ __launch_bounds__(64 * (kW + 1)) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? 2 : 4))) void pairhmm_fwd_super_kernel(FwdArgs<T> a, unsigned char* xcarry) {
   const int64_t xsteps = a.super_steps;
-  using Job = WaveJob<T, RPL, true>;
+  using Job = WaveJob<T, RPL, FMA>;
   constexpr int kSlot = sizeof(T) == 8 ? 32 : 16;   // one (M, X, Y) triple (the wide programs' ring slot)
   constexpr int kRingSlots = 64;
   constexpr int kWords = kSlot / 8;                 // 64-bit words per slot
@@ -1236,9 +1253,15 @@ __global__ __launch_bounds__(64 * (kW + 1)) __attribute__((amdgpu_waves_per_eu(s
           const uint32_t ring_out = (uint32_t)(uintptr_t)rings[wv + 1 < nw ? wv + 1 : kW];
           const uint32_t f_own = (uint32_t)(uintptr_t)&flags[1 + wv], f_prod = (uint32_t)(uintptr_t)&flags[wv],
                          f_cons = (uint32_t)(uintptr_t)&flags[wv + 1 < nw ? wv + 2 : kW + 1];
-          if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
-          else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
-          else                                    fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+          if constexpr (FMA) {
+            if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+            else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+            else                                    fwd_asm_run_wide_f32r8(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+          } else {
+            if constexpr (Job::kAsm64 && RPL == 10) fwd_asm_run_wide_f64r10n(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+            else if constexpr (Job::kAsm64)         fwd_asm_run_wide_f64r8n(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+            else                                    fwd_asm_run_wide_f32r8n(job, a, lane, j.hap_begin, j.hap_end, g, G, ring_in, ring_out, f_own, f_prod, f_cons);
+          }
         } else if (wv == kW && (feed || drain)) {
           // the helper (its own function: its registers must not weigh on the compute wavefronts' allocation)
           super_helper<kSlot>(reinterpret_cast<const uint64_t*>(xbuf + (int64_t)((st + 1) & 1) * xsteps * kWords), xbuf + (int64_t)(st & 1) * xsteps * kWords,

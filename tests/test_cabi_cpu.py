@@ -197,8 +197,9 @@ def test_generated_fp32_programs_keep_the_bank_rule_and_their_registers():
     spec.loader.exec_module(g)
     budgets = {("f32", 8): 128, ("f32", 4): 128, ("f32", 2): 128, ("f64", 10): 256, ("f64", 8): 256, ("f64", 6): 168, ("f64", 4): 128,
                ("f64", 2): 128}
-    for (kind, R), budget in budgets.items():
-        c = g.Cfg(f"{kind}r{R}", kind == "f64", R)
+    for ((kind, R), budget), fma in [(kb, f) for kb in budgets.items() for f in (True, False)]:   # both arithmetics (the unfused "...n" programs: round 5)
+        c = g.Cfg(f"{kind}r{R}", kind == "f64", R, fma)
+        assert c.name.endswith("n") == (not fma)
         for wide in ((False, True) if R >= 8 else (False,)):
             prog = g.program(c, wide)
             regs = set()
@@ -213,7 +214,9 @@ def test_generated_fp32_programs_keep_the_bank_rule_and_their_registers():
                     srcs = ops if ins.startswith("v_fmac_f32 ") else ops[1:]   # fmac reads its destination as the third source
                     assert len({r % 2 for r in srcs}) == 2, f"monochrome three-source op in {c.name}: {ins}"
             assert max(regs) < budget, (c.name, wide, max(regs), budget)
-            assert max(regs) <= c.last, (c.name, max(regs), c.last)
+            assert max(regs) <= (c.last if fma else max(c.last, max(c.TN) + c.w - 1)), (c.name, max(regs), c.last)
+            if not fma:   # the unfused arithmetic has no fused operation anywhere
+                assert not any(ins.startswith(("v_fma_f", "v_fmac_f")) for ins in prog), c.name
             # labels are unique within the one asm statement
             labels = [ins[:-1] for ins in prog if re.fullmatch(r"\d+:", ins)]
             assert len(labels) == len(set(labels)), (c.name, "duplicate label")

@@ -325,15 +325,18 @@ def test_asm_fast_loop_matches_the_cxx_build_and_the_oracle(native, oracle):
         assert np.array_equal(bits(oa[others]), bits(oc[others]))
 
 
+@pytest.mark.parametrize("fma_mode", [1, 0], ids=["avx512-arith", "avx-arith"])
 @pytest.mark.parametrize("use_double", [False, True])
-def test_whole_job_asm_programs_match_the_cxx_build(native, oracle, use_double, monkeypatch):
+def test_whole_job_asm_programs_match_the_cxx_build(native, oracle, use_double, fma_mode, monkeypatch):
     """Round 4: whole jobs -- fill, columns, separator windows, drain -- run as ONE generated asm program per haplotype
     (tools/gen_fwd_asm.py), fp32 at 8 rows per lane and fp64 at 10 (the packed recomputation pass and the all-fp64 mode).
     Three builds / modes must give the same bits as the oracle: the asm programs (default), the round-3 arrangement
     (GKLHIP_ASM_GENERAL=0: asm fast blocks inside C++ general steps; fp64 all C++) and the all-C++ cross-check library.
     Batches: the bench shape; haplotypes shorter than the array is deep (the job fails the program's precondition and
     takes the C++ steps inside the asm build); haplotypes with N (fp64: four prior planes); lower case and odd bytes;
-    reads of one base up to the longest a chunk holds; single-lane reads (every lane feeds the separator itself)."""
+    reads of one base up to the longest a chunk holds; single-lane reads (every lane feeds the separator itself).
+    Round 5: the same for the UNFUSED arithmetic of the reference's AVX translation unit (fma_mode 0: the "...n" programs,
+    12 operations per cell) -- what GKL computes on a host without AVX-512."""
     import os
     cxx = os.path.join(os.path.dirname(native.LIB_PATH), "libgklhip_pairhmm_cxxfast.so")
     rng = np.random.RandomState(4242)
@@ -349,13 +352,13 @@ def test_whole_job_asm_programs_match_the_cxx_build(native, oracle, use_double, 
             monkeypatch.setenv("GKLHIP_ASM_GENERAL", "0")
         else:
             monkeypatch.delenv("GKLHIP_ASM_GENERAL", raising=False)
-        with native.PairHmmContext(use_double=use_double, rows_per_lane=8, lib_path=cxx if mode == "cxx" else None) as c:
+        with native.PairHmmContext(use_double=use_double, rows_per_lane=8, fma_mode=fma_mode, lib_path=cxx if mode == "cxx" else None) as c:
             for i, b in enumerate(batches):
                 out = c.compute(b)
                 r32, r64, u = c.raw(b.n_pairs)
                 res[mode, i] = (out.copy(), r32.copy(), r64.copy(), u.copy())
     for i, b in enumerate(batches):
-        oo, o32, o64, ou = oracle.batch(b, use_double=use_double, want_raw=True, n_threads=8)
+        oo, o32, o64, ou = oracle.batch(b, use_double=use_double, fma_mode=fma_mode, want_raw=True, n_threads=8)
         for mode in ("asm", "round3", "cxx"):
             out, r32, r64, u = res[mode, i]
             assert np.array_equal(u, ou), (mode, i)

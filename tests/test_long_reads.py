@@ -26,10 +26,10 @@ def native():
     return n
 
 
-def check(ctx, oracle, b, use_double=False):
+def check(ctx, oracle, b, use_double=False, fma_mode=1):
     out = ctx.compute(b)
     r32, r64, u = ctx.raw(b.n_pairs)
-    oo, o32, o64, ou = oracle.batch(b, use_double=use_double, want_raw=True, n_threads=8)
+    oo, o32, o64, ou = oracle.batch(b, use_double=use_double, fma_mode=fma_mode, want_raw=True, n_threads=8)
     assert np.array_equal(u, ou), "fallback flags differ"
     if not use_double:
         assert np.array_equal(bits(r32), bits(o32)), "raw fp32 sums are not bit-identical"
@@ -129,3 +129,22 @@ def test_reads_of_5kb_and_15kb_in_super_stripes(native, oracle, use_double, monk
     monkeypatch.setenv("GKLHIP_SUPER_LONG", "0")
     with native.PairHmmContext(use_double=use_double) as c:
         assert np.array_equal(bits(c.compute(b)), bits(out))
+
+
+@pytest.mark.parametrize("use_double", [False, True])
+def test_long_reads_in_the_unfused_arithmetic(native, oracle, use_double):
+    """fma_mode 0 (the AVX translation unit's arithmetic) through the wide and the super-stripe kernels: the "...n" programs
+    (round 5; before, this arithmetic was striped by one wavefront in C++).  Reads of 2 .. 4 wavefronts and beyond,
+    related to their haplotypes, against the oracle's unfused arithmetic bit for bit."""
+    rng = np.random.RandomState(909)
+    b = related_batch(rng, [3300, 2900, 700, 64], [100, 520, 1000, 1500, 2047, 2048, 3000, 4200])
+    with native.PairHmmContext(use_double=use_double, fma_mode=0, record_events=True) as c:
+        out, u = check(c, oracle, b, use_double, fma_mode=0)
+        assert c.stats()["n_long_pairs"] > 0
+    # (the two arithmetics differ in the last bits of the raw sums: the test would not pass on the contracted programs)
+    with native.PairHmmContext(use_double=use_double, fma_mode=0) as c0, native.PairHmmContext(use_double=use_double, fma_mode=1) as c1:
+        c0.compute(b)
+        c1.compute(b)
+        r0, r1 = c0.raw(b.n_pairs), c1.raw(b.n_pairs)
+        k = 1 if use_double else 0
+        assert not np.array_equal(bits(r0[k]), bits(r1[k]))

@@ -49,8 +49,11 @@ OOB_PLANE = 512    # fp32 general step: a prior "plane" beyond the CU's 160 KB o
 
 
 class Cfg:
-    def __init__(self, name, f64, R):
-        self.name, self.f64, self.R = name, f64, R
+    def __init__(self, name, f64, R, fma=True):
+        # fma = False: the UNFUSED arithmetic of the reference's AVX translation unit (what GKL computes on a host without
+        # AVX-512, reference IntelPairHmm.cc:106-113; gklhip_config.fma_mode 0): every multiply and add rounds on its own --
+        # 12 VALU operations per cell instead of 8.  Programs of that kind carry an "n" behind their name.
+        self.name, self.f64, self.R, self.fma = name + ("" if fma else "n"), f64, R, fma
         self.w = 2 if f64 else 1
         if not f64:
             # round-3 map: E = even, O = odd registers
@@ -70,6 +73,7 @@ class Cfg:
             self.KREG = None
             self.WADDR, self.FV = 122, 123      # wide variant: ring address, flag value
             self.last = 123
+            self.TN = [124, 125, 126, 127]      # unfused arithmetic: product temporaries (two per row, two rows in flight)
             # prior table [code][plane][lane][min(R, 4) floats] (WaveJob::kVecBytes, kPlanes, kRowBytes): 2 rows per lane read
             # one ds_read_b64 per step, 4 rows one ds_read_b128, 8 rows two
             assert R in (2, 4, 8)
@@ -101,6 +105,7 @@ class Cfg:
             self.VAL, self.OUTIDX, self.PADSLOT, self.Y0N, self.A, self.P, self.KREG = m0 + 8, m0 + 10, m0 + 11, m0 + 12, m0 + 14, m0 + 16, m0 + 18
             self.WADDR, self.FV = m0 + 19, m0 + 20
             self.last = m0 + 20
+            self.TN = [t0, t0 + 2, t0 + 4, t0 + 6]   # unfused arithmetic: the four rotating product temporaries, two per row
             assert self.PR(0) % 4 == 0 and self.last < 256
             self.codes, self.planes, self.plane_stride, self.code_shift = 4, R // 2, 1024, None   # code * kRowBytes via KREG
             self.vec_bytes = 16
@@ -151,9 +156,50 @@ def prior_loads(c, code_reg):
     return o
 
 
+def recurrence_unfused(c, yo, yn, d, r, general):
+    """The same step in the reference's UNFUSED arithmetic (WaveJob::advance with FMA = false; avx-pairhmm-template.h:208-223
+    as the AVX translation unit computes it): M-inner = ((Md * pMM + Xd * pGAPM) + Yd * pGAPM), Y = M * pMY + Y * pXX,
+    X = M' * pMX + X' * pXX -- every product and every sum its own instruction (12 per cell), two product temporaries per
+    row, alternating between two sets so that consecutive rows do not wait for each other's."""
+    R, o = c.R, []
+    dM, dX, dY = d
+    rM, rX, rY = r
+    for s in range(R - 1, -1, -1):
+        md, xd, yd = (c.M(s - 1), c.X(s - 1), yo(s - 1)) if s > 0 else (dM, dX, dY)
+        t1, t2 = c.TN[2 * (s % 2)], c.TN[2 * (s % 2) + 1]
+        o.append(f"{fp(c, 'mul')} {c.v(t1)}, {c.v(xd)}, {c.v(c.GAPM(s))}")     # (before X(s) is overwritten: xd is X(s - 1), not X(s))
+        o.append(f"{fp(c, 'mul')} {c.v(c.X(s))}, {c.v(md)}, {c.v(c.PMM(s))}")
+        o.append(f"{fp(c, 'mul')} {c.v(t2)}, {c.v(c.M(s))}, {c.v(c.PMY(s))}")
+        o.append(f"{fp(c, 'add')} {c.v(c.X(s))}, {c.v(c.X(s))}, {c.v(t1)}")
+        o.append(f"{fp(c, 'mul')} {c.v(t1)}, {c.v(yd)}, {c.v(c.GAPM(s))}")
+        o.append(f"{fp(c, 'mul')} {c.v(yn(s))}, {c.v(yo(s))}, {c.v(c.PXX(s))}")
+        o.append(f"{fp(c, 'add')} {c.v(c.X(s))}, {c.v(c.X(s))}, {c.v(t1)}")
+        o.append(f"{fp(c, 'add')} {c.v(yn(s))}, {c.v(t2)}, {c.v(yn(s))}")
+    o.append("s_waitcnt lgkmcnt(0)")
+    if general and not c.f64:
+        for s in range(R):
+            o.append(f"v_mul_legacy_f32 {c.v(c.M(s))}, {c.v(c.X(s))}, {c.v(c.PR(s))}")
+    else:
+        for s in range(R):
+            o.append(f"{fp(c, 'mul')} {c.v(c.M(s))}, {c.v(c.X(s))}, {c.v(c.PR(s))}")
+        if general:
+            for s in range(R):
+                o += and_mask(c, c.M(s), c.NSEP)
+    for s in range(R):
+        ms, xs = (c.M(s - 1), c.X(s - 1)) if s else (rM, rX)
+        t1 = c.TN[2 * (s % 2)]
+        o.append(f"{fp(c, 'mul')} {c.v(t1)}, {c.v(xs)}, {c.v(c.PXX(s))}")
+        o.append(f"{fp(c, 'mul')} {c.v(c.X(s))}, {c.v(ms)}, {c.v(c.PMX(s))}")
+        o.append(f"{fp(c, 'add')} {c.v(c.X(s))}, {c.v(c.X(s))}, {c.v(t1)}")
+    o.append(f"{fp(c, 'add')} {c.v(c.SM)}, {c.v(c.SM)}, {c.v(c.M(R - 1))}")
+    return o
+
+
 def recurrence(c, yo, yn, d, r, general):
     """M-inner + Y bottom-up, prior multiply, X column top-down, running sum of M.  yo/yn: Y source / destination register
     functions (the same one: in place through v_fma with a product temporary)."""
+    if not c.fma:
+        return recurrence_unfused(c, yo, yn, d, r, general)
     R, o = c.R, []
     dM, dX, dY = d
     rM, rX, rY = r
@@ -482,6 +528,10 @@ def clobbers(c):
     for reg, n in ((c.EAB, 1), (c.ADDR, 1), (c.NSEP, 1), (c.VAL, c.w), (c.Y0N, c.w), (c.A, 2), (c.P, 2)):
         for h in range(n):
             cl.add(reg + h)
+    if not c.fma:
+        for t in c.TN:
+            for h in range(c.w):
+                cl.add(t + h)
     return [f"v{x}" for x in sorted(cl)] + S_CLOB + ["vcc", "scc", "memory"]
 
 
@@ -661,10 +711,11 @@ def main(path):
     o.append("typedef const double __attribute__((address_space(4))) ConstF64;")
     legacy_fast(o)
     stats = []
-    for c, wide in ((Cfg("f32r8", False, 8), True), (Cfg("f64r10", True, 10), True), (Cfg("f64r8", True, 8), True),
-                    # the narrow kernels of small and mid-size calls (one pair or a few reads per wavefront)
-                    (Cfg("f32r4", False, 4), False), (Cfg("f32r2", False, 2), False),
-                    (Cfg("f64r6", True, 6), False), (Cfg("f64r4", True, 4), False), (Cfg("f64r2", True, 2), False)):
+    shapes = (("f32r8", False, 8, True), ("f64r10", True, 10, True), ("f64r8", True, 8, True),
+              # the narrow kernels of small and mid-size calls (one pair or a few reads per wavefront)
+              ("f32r4", False, 4, False), ("f32r2", False, 2, False), ("f64r6", True, 6, False), ("f64r4", True, 4, False), ("f64r2", True, 2, False))
+    # every program twice: the AVX-512 object's contraction (fma_mode 1) and the AVX object's unfused arithmetic (fma_mode 0, "...n")
+    for c, wide in [(Cfg(nm, f64, R, fma), w) for fma in (True, False) for nm, f64, R, w in shapes]:
         driver(c, o)
         if wide:
             driver(c, o, wide=True)
