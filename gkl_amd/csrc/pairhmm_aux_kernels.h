@@ -225,7 +225,10 @@ __global__ void finalize64_kernel(FinalizeArgs a, int all_pairs) {
 // concurrent launches and still could not cover several processes or a partitioned device).
 // None of the arrays written here is declared const/__restrict__: data produced in one phase is read in the next,
 // and the compiler must not move such reads to the scalar cache, which the fences do not invalidate.
-constexpr int kPackWindow = 96;
+#ifndef GKL_PACK_WINDOW
+#define GKL_PACK_WINDOW 96
+#endif
+constexpr int kPackWindow = GKL_PACK_WINDOW;   // (r05 A/B on the bench batch: 64 / 96 / 128 reads per window, see docs/NOTES.md)
 constexpr int kJobClasses = 64;
 constexpr int kPlanBlock = 1024;
 
