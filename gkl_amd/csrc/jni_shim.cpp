@@ -60,15 +60,26 @@ constexpr const char* kIAE = "java/lang/IllegalArgumentException";
 constexpr const char* kOOM = "java/lang/OutOfMemoryError";
 constexpr const char* kRTE = "java/lang/RuntimeException";
 
-// Grow-only page-locked byte arena (one per marshalled field and slot).
+// Page-locked byte arena (one per marshalled field and slot): grows with the biggest call, and an arena above 32 MB that the
+// last 16 calls each filled to less than a quarter is given back (like the context's own buffers, pairhmm_api.hip: trim_due)
+// -- one 1.28 M-pair call must not keep ~100 MB pinned per slot for the life of the JVM.  clear() runs at the start of a
+// call, when nothing of the slot's previous call is in flight any more.
 struct PinnedBytes {
   uint8_t* p = nullptr;
   size_t cap = 0, len = 0;
+  int small_uses = 0;
   PinnedBytes() = default;
   PinnedBytes(const PinnedBytes&) = delete;
   PinnedBytes& operator=(const PinnedBytes&) = delete;
   ~PinnedBytes() { gklhip_host_free(p); }
-  void clear() { len = 0; }
+  void clear() {
+    if (cap > ((size_t)32 << 20) && len < cap / 4) {
+      if (++small_uses >= 16) { gklhip_host_free(p); p = nullptr; cap = 0; small_uses = 0; }
+    } else {
+      small_uses = 0;
+    }
+    len = 0;
+  }
   uint8_t* grow(size_t add) {  // returns where the new bytes go
     if (len + add > cap) {
       const size_t want = std::max<size_t>(2 * cap, std::max<size_t>(len + add, 1 << 16));
@@ -160,6 +171,7 @@ struct Slot {
   std::vector<std::unique_ptr<ReadArena>> ranges;  // a pipelined call's read ranges
   std::vector<RangeTask> tasks;
   std::vector<double> out;
+  int calls_since_pipelined = 0;       // one-shot calls since the slot's last pipelined one: after 16 its range arenas (and a result vector above 32 MB) go
   bool busy = false;
   int gen = 0;  // configuration generation (initNative with other arguments starts a new one)
   gklhip_config cfg;  // what `ctx` was created with: the second engine of a pipelined call gets the same
@@ -445,6 +457,11 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     }
     if (!pipelined) {
       // ---- one shot (a GATK active region): marshal, compute, write back ----
+      if (!sl->ranges.empty() && ++sl->calls_since_pipelined >= 16) {   // (the slot's engines are idle here: nothing reads the arenas)
+        sl->ranges.clear();
+        sl->ranges.shrink_to_fit();
+        if (sl->out.capacity() * sizeof(double) > ((size_t)32 << 20)) std::vector<double>().swap(sl->out);
+      }
       if (!marshal_reads(sl->whole, 0, n_reads)) return;
       const int64_t t_m = now_ns();
       if (n_pairs == 0) return;
@@ -481,6 +498,7 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
       }
     }
     const int n_ranges = (int)cut.size() - 1;
+    sl->calls_since_pipelined = 0;
     while ((int)sl->ranges.size() < n_ranges) sl->ranges.emplace_back(new ReadArena());
     sl->tasks.assign((size_t)n_ranges, RangeTask());
     sl->out.resize((size_t)n_pairs);

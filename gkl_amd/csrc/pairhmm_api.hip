@@ -74,12 +74,23 @@ int guarded(F&& body) noexcept {
     }                                                                                        \
   } while (0)
 
-// Grow-only device / pinned-host buffers.
+// Device / pinned-host buffers of a context: they grow with the biggest call and shrink again when the calls stay small --
+// a buffer above kTrimFloor that the last kTrimCalls calls each needed less than a quarter of is given back and re-made at
+// the size in use (one 1.28 M-pair call must not pin ~100 MB per slot for the life of the JVM).  hipFree / hipHostFree wait
+// for the device to finish with the memory, exactly as on the grow path.
+constexpr size_t kTrimFloor = (size_t)32 << 20;
+constexpr int kTrimCalls = 16;
+inline bool trim_due(size_t n, size_t cap, int* small_uses) {
+  if (cap <= kTrimFloor || n >= cap / 4) { *small_uses = 0; return false; }
+  return ++*small_uses >= kTrimCalls;
+}
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  int small_uses = 0;
   int reserve(size_t n) {
-    if (n <= cap) return GKLHIP_OK;
+    if (n <= cap && !trim_due(n, cap, &small_uses)) return GKLHIP_OK;
+    small_uses = 0;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     const size_t want = n + n / 4 + 256;
     HIP_TRY(hipMalloc(&p, want));
@@ -92,8 +103,10 @@ struct DevBuf {
 struct PinBuf {
   void* p = nullptr;
   size_t cap = 0;
+  int small_uses = 0;
   int reserve(size_t n) {
-    if (n <= cap) return GKLHIP_OK;
+    if (n <= cap && !trim_due(n, cap, &small_uses)) return GKLHIP_OK;
+    small_uses = 0;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     const size_t want = n + n / 4 + 256;
     HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));

@@ -85,11 +85,19 @@ const PdTables& pd_tables() {
   return t;
 }
 
+// (like libgklhip_pairhmm's buffers: grown by the biggest call, given back when the last 16 calls each needed less than a
+//  quarter of a buffer above 32 MB -- a 424k-pair call holds ~3 GB of streams and tables)
+inline bool pd_trim_due(size_t n, size_t cap, int* small_uses) {
+  if (cap <= ((size_t)32 << 20) || n >= cap / 4) { *small_uses = 0; return false; }
+  return ++*small_uses >= 16;
+}
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
+  int small_uses = 0;
   int reserve(size_t n) {
-    if (n <= cap) return GKLHIP_OK;
+    if (n <= cap && !pd_trim_due(n, cap, &small_uses)) return GKLHIP_OK;
+    small_uses = 0;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     const size_t want = n + n / 4 + 256;
     PD_HIP_TRY(hipMalloc(&p, want));
@@ -99,11 +107,13 @@ struct Buf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
   template <typename T> T* as() const { return static_cast<T*>(p); }
 };
-struct PinBuf {  // page-locked host memory, grow-only
+struct PinBuf {  // page-locked host memory
   void* p = nullptr;
   size_t cap = 0;
+  int small_uses = 0;
   int reserve(size_t n) {
-    if (n <= cap) return GKLHIP_OK;
+    if (n <= cap && !pd_trim_due(n, cap, &small_uses)) return GKLHIP_OK;
+    small_uses = 0;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     const size_t want = n + n / 4 + 256;
     PD_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
@@ -247,6 +257,14 @@ int gklhip_pdhmm_set_fma_mode(gklhip_pdhmm_ctx* c, int fma_mode) {
 }
 
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* c) { return c ? c->last_ms : 0.f; }
+int64_t gklhip_pdhmm_buffer_bytes(gklhip_pdhmm_ctx* c) {
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  size_t total = 0;
+  for (const Buf* b : {&c->tables, &c->inputs, &c->entries, &c->entries_tab, &c->sums, &c->misc, &c->carry, &c->jobs, &c->tabx}) total += b->cap;
+  for (const PinBuf* b : {&c->stage_in, &c->stage_jobs, &c->sums_pin}) total += b->cap;
+  return (int64_t)total;
+}
 int gklhip_pdhmm_last_routing(gklhip_pdhmm_ctx* c, int32_t out[3]) {
   if (!c || !out) return pd_fail(GKLHIP_ERR_INVALID_ARG, "NULL argument");
   std::lock_guard<std::mutex> lock(c->mu);

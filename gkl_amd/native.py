@@ -395,6 +395,8 @@ def load_pdhmm_library(path: Optional[str] = None):
     lib.gklhip_pdhmm_done.restype = C.c_int
     lib.gklhip_pdhmm_last_kernel_ms.argtypes = [C.c_void_p]
     lib.gklhip_pdhmm_last_kernel_ms.restype = C.c_float
+    lib.gklhip_pdhmm_buffer_bytes.argtypes = [C.c_void_p]
+    lib.gklhip_pdhmm_buffer_bytes.restype = C.c_int64
     lib.gklhip_pdhmm_last_routing.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.gklhip_pdhmm_last_routing.restype = C.c_int
     lib.gklhip_pdhmm_get_table.argtypes = [C.c_int, C.c_void_p, C.c_int64]
@@ -487,6 +489,10 @@ class PdhmmContext:
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.gklhip_pdhmm_last_kernel_ms(self.handle))
+
+    def buffer_bytes(self) -> int:
+        """Device + pinned host bytes the context holds right now (they shrink again after 16 small calls)."""
+        return int(self.lib.gklhip_pdhmm_buffer_bytes(self.handle))
 
     def last_routing(self):
         """Last cross call: its haplotypes by kernel (LDS prior table, predicate, byte-comparing); last paired call: its

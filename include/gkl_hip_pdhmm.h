@@ -90,6 +90,9 @@ int32_t gklhip_pdhmm_available_memory_mb(int32_t max_memory_mb);
 int64_t gklhip_pdhmm_reference_batch_pairs(int32_t max_memory_mb, int32_t max_read_len, int32_t max_hap_len, int64_t total_pairs);
 /* HIP-event time of the forward kernel of the last call, milliseconds. */
 float gklhip_pdhmm_last_kernel_ms(gklhip_pdhmm_ctx* ctx);
+/* Diagnostics: bytes of device and pinned host memory the context holds right now.  Its buffers grow with the biggest call
+ * and are given back when the last 16 calls each needed less than a quarter of a buffer above 32 MB. */
+int64_t gklhip_pdhmm_buffer_bytes(gklhip_pdhmm_ctx* ctx);
 /* Diagnostics: how the last cross call's haplotypes were routed: out[0] to the table kernel (at most six classes of
  * (base, SNP alleles, 'N') columns: the match priors come from an LDS table), out[1] to the predicate kernel, out[2] to
  * the byte-comparing kernel (a base outside ACGTN).  After a paired call (gklhip_pdhmm_compute; every pair its own haplotype

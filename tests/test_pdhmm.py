@@ -704,6 +704,27 @@ def test_pdhmm_gpu_paired_sliced_call_equals_the_unsliced_one(pd_ctx, pd_oracle,
 
 
 @pytest.mark.gpu
+def test_pdhmm_gpu_buffers_shrink_again_after_a_big_call(pd_oracle):
+    # a context's buffers grow with its biggest call; when the next 16 calls each need less than a quarter of a buffer
+    # above 32 MB it is given back (one 120k-pair call holds ~0.7 GB of streams and tables) -- and the calls after that
+    # still return the oracle's bits
+    from gkl_amd import native
+    _, _, b1, _ = holders_fixture_batch()
+    small = b1.subset(np.arange(300))
+    exp = pd_oracle.compute(small, semantics=2)[1]
+    with native.PdhmmContext(fma_mode=1, reference_tail=False) as c:
+        c.compute(b1.subset(np.tile(np.arange(b1.batch), 9)))
+        big = c.buffer_bytes()
+        assert big > 300 << 20
+        for _ in range(15):
+            assert c.compute(small).tobytes() == exp.tobytes()
+        assert c.buffer_bytes() >= big                       # fifteen small calls: nothing is given back yet (the small calls add their staging blocks)
+        for _ in range(3):
+            assert c.compute(small).tobytes() == exp.tobytes()
+        assert c.buffer_bytes() < big // 8, (big, c.buffer_bytes())
+
+
+@pytest.mark.gpu
 def test_pdhmm_gpu_argument_errors(pd_ctx):
     from gkl_amd import native
     b = random_pd_batch(np.random.RandomState(5), 8)
