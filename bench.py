@@ -705,7 +705,7 @@ def main():
                                             "fp32_kernel_gcups": round(lb.cells / lst["ms_fwd_main"] / 1e6, 1),
                                             "fp64_pass_ms": round(lst["ms_fwd_fallback"], 3),
                                             "fallback_fraction": round(lst["n_fallback"] / lb.n_pairs, 4),
-                                            "note": "pairhmm_fwd_super_kernel: super-stripes of 5 (fp32) / 7 (fp64) wavefronts x 512 rows"}
+                                            "note": "pairhmm_fwd_super_kernel: super-stripes of 7 compute wavefronts x 512 rows + a helper wavefront that carries the boundary row through HBM"}
                 except Exception as e:
                     res["long_reads_5k"] = {"error": repr(e)}
                 # the same shape without fallback pairs (one real active region)
