@@ -713,8 +713,9 @@ def main(path):
     stats = []
     shapes = (("f32r8", False, 8, True), ("f64r10", True, 10, True), ("f64r8", True, 8, True),
               # the narrow kernels of small and mid-size calls (one pair or a few reads per wavefront)
-              # (r05: wide variants of the 2- and 4-row programs too -- a lone GATK-sized call puts a pair of 128+ bases on TWO wavefronts)
-              ("f32r4", False, 4, True), ("f32r2", False, 2, True), ("f64r6", True, 6, False), ("f64r4", True, 4, True), ("f64r2", True, 2, True))
+              # (wide variants of the 2- and 4-row programs were generated and tried in round 5 -- a lone GATK-sized call with a pair of
+              #  128+ bases on TWO wavefronts -- and lost: docs/NOTES.md 42; `True` in the last column brings them back)
+              ("f32r4", False, 4, False), ("f32r2", False, 2, False), ("f64r6", True, 6, False), ("f64r4", True, 4, False), ("f64r2", True, 2, False))
     # every program twice: the AVX-512 object's contraction (fma_mode 1) and the AVX object's unfused arithmetic (fma_mode 0, "...n")
     for c, wide in [(Cfg(nm, f64, R, fma), w) for fma in (True, False) for nm, f64, R, w in shapes]:
         driver(c, o)
