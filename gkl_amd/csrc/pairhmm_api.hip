@@ -182,19 +182,27 @@ struct DevCtx {
 
 namespace {
 
+// the context's second and third stream, made on first use (see dev_init)
+int aux_streams(DevCtx* c) {
+  if (!c->upload_stream) HIP_TRY(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+  if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  return GKLHIP_OK;
+}
+
 template <typename T>
 int upload_tables(DevCtx* c, const HostTables<T>& h, DevBuf* buf, DevTables<T>* dt) {
   const size_t n = (size_t)kQuals * 2 + kMmEntries;
   int st = buf->reserve(n * sizeof(T));
   if (st) return st;
   T* base = buf->as<T>();
-  HIP_TRY(hipMemcpy(base, h.ph2pr.data(), kQuals * sizeof(T), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(base + kQuals, h.div3.data(), kQuals * sizeof(T), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(base + 2 * kQuals, h.mm.data(), kMmEntries * sizeof(T), hipMemcpyHostToDevice));
+  // (on the context's own stream: the null stream would be one more hardware queue per process)
+  HIP_TRY(hipMemcpyAsync(base, h.ph2pr.data(), kQuals * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(base + kQuals, h.div3.data(), kQuals * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(base + 2 * kQuals, h.mm.data(), kMmEntries * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   dt->ph2pr = base;
   dt->div3 = base + kQuals;
   dt->mm = base + 2 * kQuals;
-  (void)c;
   return GKLHIP_OK;
 }
 
@@ -603,6 +611,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     hs_dev = static_cast<const unsigned char*>(p);
     if (!deferred_launch) HIP_TRY(hipStreamWaitEvent(s, c->plan_unused_slot[slot], 0));
   } else {
+    if ((rc = aux_streams(c))) return rc;
     HIP_TRY(hipStreamWaitEvent(c->upload_stream, c->plan_unused_slot[slot], 0));  // readers of the old contents are done
     HIP_TRY(hipMemcpyAsync(dp, hs, L.total, hipMemcpyHostToDevice, c->upload_stream));
     HIP_TRY(hipEventRecord(c->stage_free_slot[slot], c->upload_stream));
@@ -891,6 +900,7 @@ int run_device(DevCtx* c, const gklhip_batch* db, double* out_dev, int finalize_
     }
     const bool side_finalize = finalize_mode == GKLHIP_FINALIZE_DEVICE_F64 || finalize_mode == GKLHIP_FINALIZE_DEVICE_REF32;
     if (side_finalize) {
+      if ((rc = aux_streams(c))) return rc;
       HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->policy_done, 0));
       hipLaunchKernelGGL(finalize32_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, c->copy_stream, fa);
       HIP_TRY(hipEventRecord(c->early_copy_done, c->copy_stream));
@@ -1054,12 +1064,13 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
       fprintf(stderr, "[gklhip] pairhmm: GKLHIP_SELFTEST_FAIL=lds_oob: the fp32 general steps stay in C++ for this context\n");
     }
   }
-  if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  // (upload_stream and copy_stream are made by the first call that needs them -- aux_streams() -- not here: a process that only
+  //  ever sends GATK-sized regions then holds ONE hardware queue instead of three, and sixteen such processes on one GPU
+  //  stay below the number of queues the hardware scheduler maps at once)
   for (int k = 0; k < 2; k++)
     if (hipEventCreateWithFlags(&c->stage_free_slot[k], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->plan_unused_slot[k], hipEventDisableTiming) != hipSuccess)
       return bail(fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
-  if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
   if (hipEventCreateWithFlags(&c->policy_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->early_copy_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->call_done, hipEventDisableTiming) != hipSuccess)
@@ -1384,8 +1395,8 @@ int dev_compute_host(DevCtx* c, const gklhip_batch* hb, double* out_host) {
   // finalisation worker's rethrow): the same drain, then the exception goes on
   auto drain = [c]() noexcept {
     (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->copy_stream);
-    (void)hipStreamSynchronize(c->upload_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->upload_stream) (void)hipStreamSynchronize(c->upload_stream);
     (void)hipGetLastError();
   };
   int rc;
