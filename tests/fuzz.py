@@ -68,9 +68,12 @@ def main():
                                  qual_range=(0, int(rng.choice([40, 60, 93, 255]))), related=bool(rng.randint(0, 2)))
             elif kind == 1:
                 b = make_batch("hc", int(rng.randint(1, 700)), int(rng.randint(1, 48)), seed=int(rng.randint(0, 1 << 30)))
-            elif kind == 2:   # long reads: the striped kernel
-                b = random_batch(rng, int(rng.randint(1, 12)), int(rng.randint(1, 6)), read_len=(200, int(rng.randint(520, 1500))),
-                                 hap_len=(50, int(rng.randint(100, 900))), alphabet=b"ACGTN")
+            elif kind == 2:   # long reads: the wide kernel (2-4 wavefronts per read), one time in three the super-stripe kernel
+                              # (> 2047 bases) with its striped twin for the jobs it leaves (haplotypes of <= 63 bases, fp64: N haplotypes)
+                top = int(rng.randint(2048, 4300)) if rng.randint(0, 3) == 0 else int(rng.randint(520, 1500))
+                b = random_batch(rng, int(rng.randint(1, 12)), int(rng.randint(1, 6)), read_len=(200, top),
+                                 hap_len=(int(rng.choice([20, 50, 70])), int(rng.randint(100, 900))), alphabet=b"ACGTN" if rng.randint(0, 2) else b"ACGT",
+                                 related=bool(rng.randint(0, 2)))
             else:
                 b = make_batch("mixed", int(rng.randint(1, 300)), int(rng.randint(1, 20)), seed=int(rng.randint(0, 1 << 30)),
                                read_len=(int(rng.randint(1, 40)), int(rng.randint(40, 260))), hap_len=(int(rng.randint(20, 90)), int(rng.randint(90, 500))))
