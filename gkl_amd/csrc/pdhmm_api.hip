@@ -334,7 +334,13 @@ bool has_odd_base(const int8_t* b, int64_t n) {
 // flight when those go out of scope: drain the stream first.
 int pd_run(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
   std::lock_guard<std::mutex> lock(c->mu);
-  const int rc = pd_run_locked(c, q, out_host);
+  int rc;
+  // no C++ exception leaves the C ABI (a host vector that cannot grow, a helper thread that cannot start): it becomes a
+  // status like any other error -- after the same drain
+  try { rc = pd_run_locked(c, q, out_host); }
+  catch (const std::bad_alloc&) { rc = pd_fail(GKLHIP_ERR_OOM, "host memory allocation failed"); }
+  catch (const std::exception& e) { rc = pd_fail(GKLHIP_ERR_HIP, "%s", e.what()); }
+  catch (...) { rc = pd_fail(GKLHIP_ERR_HIP, "unexpected C++ exception"); }
   if (rc != GKLHIP_OK) {
     const std::string keep = g_pd_err;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
