@@ -689,6 +689,14 @@ def test_pdhmm_gpu_paired_sliced_call_equals_the_unsliced_one(pd_ctx, pd_oracle,
     with native.PdhmmContext(fma_mode=pd_ctx.fma_mode, reference_tail=False) as c:
         assert c.compute(big).tobytes() == got.tobytes()
         assert c.last_routing() != (0, 0, 0)
+    # ... and sliced with the table route switched off (the predicate launch then walks each slice's range of listed jobs)
+    monkeypatch.delenv("GKL_HIP_PDHMM_PIPELINE")
+    monkeypatch.setenv("GKL_HIP_PDHMM_TABLE", "0")
+    with native.PdhmmContext(fma_mode=pd_ctx.fma_mode, reference_tail=False) as c:
+        assert c.compute(big).tobytes() == got.tobytes()
+        assert c.last_routing()[0] == 0 and c.last_routing()[1] > 0
+    monkeypatch.delenv("GKL_HIP_PDHMM_TABLE")
+    monkeypatch.setenv("GKL_HIP_PDHMM_PIPELINE", "0")
     # the random pairs sit at positions at[k] + k
     pos = at + np.arange(len(at))
     st, vec = pd_oracle.compute(extra, semantics=pd_ctx.sem)
