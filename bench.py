@@ -234,7 +234,7 @@ def small_proc_worker(idx, dev_index, workload, duration_s):
                       "checksum": float(out.sum())}), flush=True)
 
 
-def process_records(dev_index, workload, counts=(4, 16), duration_s=1.5):
+def process_records(dev_index, workload, counts=(4, 8, 16), duration_s=1.5):
     """P PROCESSES x one caller on one GPU -- the deployment GATK produces (HaplotypeCaller is one compute thread per JVM,
     scattered over many JVMs per node): each child owns a context and loops 100 x 10 host calls; all start together.
     Aggregate rate, median and 99th-percentile call latency over all children's calls.  The per-process SmallCombiner cannot

@@ -5,6 +5,7 @@
 // :150-169 (batch loop + fp32->fp64 policy + log10), :189-192 (done).  There is no
 // CPU compute path in this library: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types only: the library is dlopen()ed by multi-device contexts
 #include <dlfcn.h>
 
@@ -145,6 +146,7 @@ struct DevCtx {
   hipEvent_t stage_free_slot[2] = {nullptr, nullptr};   // the slot's upload has left the staging buffer
   hipEvent_t plan_unused_slot[2] = {nullptr, nullptr};  // the last call that used the slot's device copy has finished
   hipStream_t upload_stream = nullptr;
+  hipStream_t pad_stream = nullptr;   // never used: keeps the context's stream count at four once copy_stream exists (aux_streams)
   int plan_slot = 0;
   // per-call device scratch
   DevBuf raw32, raw64, used64, counters, stream_buf, out_dev;
@@ -182,10 +184,14 @@ struct DevCtx {
 
 namespace {
 
-// the context's second and third stream, made on first use (see dev_init)
+// The context's third stream, made on first use together with a padding stream (see dev_init: how many streams a process
+// holds decides how the device's scheduler treats it next to other processes; two and four are good numbers, three is not).
 int aux_streams(DevCtx* c) {
   if (!c->upload_stream) HIP_TRY(hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
-  if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->pad_stream) HIP_TRY(hipStreamCreateWithFlags(&c->pad_stream, hipStreamNonBlocking));
+  }
   return GKLHIP_OK;
 }
 
@@ -195,11 +201,26 @@ int upload_tables(DevCtx* c, const HostTables<T>& h, DevBuf* buf, DevTables<T>* 
   int st = buf->reserve(n * sizeof(T));
   if (st) return st;
   T* base = buf->as<T>();
-  // (on the context's own stream: the null stream would be one more hardware queue per process)
-  HIP_TRY(hipMemcpyAsync(base, h.ph2pr.data(), kQuals * sizeof(T), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(base + kQuals, h.div3.data(), kQuals * sizeof(T), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(base + 2 * kQuals, h.mm.data(), kMmEntries * sizeof(T), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  // (on the context's own stream -- the null stream would be one more hardware queue per process -- and pulled by a kernel
+  //  from a pinned block instead of copied: no copy-engine queue either)
+  {
+    T* pin = nullptr;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin), n * sizeof(T), hipHostMallocDefault));
+    memcpy(pin, h.ph2pr.data(), kQuals * sizeof(T));
+    memcpy(pin + kQuals, h.div3.data(), kQuals * sizeof(T));
+    memcpy(pin + 2 * kQuals, h.mm.data(), kMmEntries * sizeof(T));
+    void* pin_dev = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&pin_dev, pin, 0);
+    if (e == hipSuccess) {
+      static_assert(sizeof(T) % 4 == 0, "whole words");
+      hipLaunchKernelGGL(pull_words_kernel, dim3(64), dim3(256), 0, c->stream, static_cast<const uint32_t*>(pin_dev),
+                         reinterpret_cast<uint32_t*>(base), (int)(n * sizeof(T) / 4));
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipHostFree(pin);
+    HIP_TRY(e);
+  }
   dt->ph2pr = base;
   dt->div3 = base + kQuals;
   dt->mm = base + 2 * kQuals;
@@ -985,6 +1006,7 @@ void dev_done(DevCtx* c) {
     if (c->plan_unused_slot[k]) (void)hipEventDestroy(c->plan_unused_slot[k]);
   }
   if (c->upload_stream) { (void)hipStreamSynchronize(c->upload_stream); (void)hipStreamDestroy(c->upload_stream); }
+  if (c->pad_stream) (void)hipStreamDestroy(c->pad_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1064,9 +1086,19 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
       fprintf(stderr, "[gklhip] pairhmm: GKLHIP_SELFTEST_FAIL=lds_oob: the fp32 general steps stay in C++ for this context\n");
     }
   }
-  // (upload_stream and copy_stream are made by the first call that needs them -- aux_streams() -- not here: a process that only
-  //  ever sends GATK-sized regions then holds ONE hardware queue instead of three, and sixteen such processes on one GPU
-  //  stay below the number of queues the hardware scheduler maps at once)
+  // A context starts with TWO streams: its own and upload_stream.  copy_stream (device-side finalisation of big device-resident
+  // calls) and the combiner's flight streams are made by the first call that needs them.  Why the count matters: a process with
+  // one caller of GATK-sized regions (a HaplotypeCaller JVM) only ever uses the first stream, but every stream is a hardware
+  // queue, and how many queues each process holds decides how the device's scheduler shares the chip among processes --
+  // measured with P such processes on one GPU (tools/proc_scaling.py, docs/NOTES.md 48; GCUPS at 4 / 8 / 16 processes):
+  // 1 stream 810 / 1055 / 1325, **2 streams 974 / 1571 / 1596** (p99 of a call 0.19 / 0.26 / 11.6 ms), 3 streams
+  // 572 / 707 / 755, 4 streams 979 / 1101 / 1174, the 7 of round 4 965 / 1100 / 1130 (p99 0.19 / 11 / 25-43 ms).
+  if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  if (const char* v = getenv("GKL_HIP_EAGER_STREAMS")) {   // A/B: 7 = the r04 arrangement (every stream at init); 1..3 = that many spare streams on top of the two
+    const int k = atoi(v);
+    if (k >= 7) { if (aux_streams(c) != GKLHIP_OK) return bail(GKLHIP_ERR_HIP); }
+    else for (int i = 0; i < k; i++) { hipStream_t d = nullptr; (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking); }   // (leaked on purpose: an experiment)
+  }
   for (int k = 0; k < 2; k++)
     if (hipEventCreateWithFlags(&c->stage_free_slot[k], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->plan_unused_slot[k], hipEventDisableTiming) != hipSuccess)
@@ -1138,6 +1170,8 @@ struct SmallCombiner {
   std::condition_variable cv;
   std::deque<Ticket*> queue;
   Slot slot[kFlightSlots];
+  int device = 0;
+  bool streams_made = false;       // the flight streams are created by the first COMBINED launch (make_streams)
   int flights = 0;
   int max_flights = 3;
   int min_batch = 0;               // 0: by load (see run())
@@ -1146,6 +1180,27 @@ struct SmallCombiner {
   int64_t ns_queued = 0, ns_launch = 0, ns_sync = 0;
   std::atomic<int64_t> ns_stage{0}, ns_run{0}, ns_finalize{0};  // per call, outside the lock
   static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+  // The flight streams, created together -- the runtime deals streams round-robin onto the process's hardware queues, so
+  // consecutive ones land on different queues and the sets in flight really run side by side -- but only when two calls
+  // first meet: a process with ONE caller (a HaplotypeCaller JVM) never needs them, and every stream it does not create is a
+  // hardware queue the device's scheduler does not have to rotate in -- with sixteen such processes on one GPU that is the
+  // difference between 0.9 and 1.5 TCUPS (docs/NOTES.md 48).  Called with the combiner's lock held.
+  void make_streams() {
+    if (streams_made) return;
+    streams_made = true;
+    int prev = 0;
+    const bool have_dev = hipGetDevice(&prev) == hipSuccess;
+    if (hipSetDevice(device) == hipSuccess) {
+      for (auto& sl : slot)
+        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) {
+          sl.stream = nullptr;  // (a set that gets this slot reports the failure)
+          (void)hipGetLastError();
+        }
+    }
+    if (have_dev) (void)hipSetDevice(prev);
+  }
 
   int launch_single(const SmallCall& k, hipStream_t s, bool alone) {
     hipLaunchKernelGGL(prep_kernel, dim3((unsigned)k.prep_grid), dim3(kPrepBlock), 0, s, k.prep);
@@ -1238,6 +1293,7 @@ struct SmallCombiner {
       n_launch_sets++;
       if (n > 1) n_combined += n;
       int rc = GKLHIP_OK;
+      if (n > 1) make_streams();
       if (n > 1 && !sl.stream) rc = fail(GKLHIP_ERR_HIP, "no stream for combined small calls");
       l.unlock();
       if (rc == GKLHIP_OK) rc = n == 1 ? launch_single(mine.call, own_stream, alone) : launch_multi(batch, n, mine.call.fma, sl);
@@ -1286,19 +1342,8 @@ SmallCombiner* small_combiner(int device) {
   if ((int)all.size() <= device) all.resize((size_t)device + 1, nullptr);
   if (!all[(size_t)device]) {
     SmallCombiner* k = all[(size_t)device] = new SmallCombiner();  // lives as long as the process (a handful of streams and events)
-    // The flight streams are created together: the runtime deals streams round-robin onto the device's (four) hardware
-    // queues, so consecutive ones land on different queues and the sets in flight really run side by side.
-    int prev = 0;
-    const bool have_dev = hipGetDevice(&prev) == hipSuccess;
-    if (hipSetDevice(device) == hipSuccess) {
-      for (auto& sl : k->slot)
-        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) {
-          sl.stream = nullptr;  // (a set that gets this slot reports the failure)
-          (void)hipGetLastError();
-        }
-    }
-    if (have_dev) (void)hipSetDevice(prev);
+    k->device = device;   // (its flight streams: SmallCombiner::make_streams, when two calls first meet)
+    if (const char* v = getenv("GKL_HIP_EAGER_STREAMS")) if (atoi(v) >= 7) k->make_streams();   // A/B: the r04 arrangement
     if (const char* v = getenv("GKL_HIP_COMBINE_FLIGHTS")) all[(size_t)device]->max_flights = std::max(1, std::min(kFlightSlots, atoi(v)));
     if (const char* v = getenv("GKL_HIP_COMBINE_MIN")) all[(size_t)device]->min_batch = std::max(0, std::min(kMultiMax, atoi(v)));
     if (const char* v = getenv("GKL_HIP_COMBINE_WAIT_US")) all[(size_t)device]->batch_wait_ns = (int64_t)std::max(0, atoi(v)) * 1000;

@@ -93,6 +93,13 @@ __device__ __forceinline__ void prep_block(const PrepArgs& a, int block, int gri
 }
 __global__ __launch_bounds__(kPrepBlock) void prep_kernel(PrepArgs a) { prep_block(a, (int)blockIdx.x, (int)gridDim.x); }
 
+// Tables at gklhip_init: pulled from a pinned host block by the device itself, like a small call's plan block -- a
+// hipMemcpy would be the process's only reason to open the copy engines' queues (see SmallCombiner::make_streams on why a
+// process should hold as few hardware queues as it can).
+__global__ __launch_bounds__(256) void pull_words_kernel(const uint32_t* src, uint32_t* dst, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 // ---- several small host-buffer calls in ONE set of launches (pairhmm_api.hip: SmallCombiner) ----
 // The device executes the kernels of about four queues at a time (tools/ubench_launch.hip), so sixteen callers with a
 // GATK-sized region each get no more through than four.  When calls arrive while others are in flight, their three
