@@ -231,6 +231,7 @@ def small_proc_worker(idx, dev_index, workload, duration_s):
     lat = np.sort(np.array(lat))
     print(json.dumps({"calls": int(lat.size), "elapsed_s": elapsed, "cells_per_call": int(b.cells),
                       "p50_ms": float(lat[lat.size // 2]) * 1e3, "p99_ms": float(lat[min(lat.size - 1, int(lat.size * 0.99))]) * 1e3,
+                      "max_ms": float(lat[-1]) * 1e3,
                       "checksum": float(out.sum())}), flush=True)
 
 
@@ -267,9 +268,13 @@ def process_records(dev_index, workload, counts=(4, 8, 16), duration_s=1.5):
             "calls_per_s": round(sum(r["calls"] / r["elapsed_s"] for r in res), 1),
             "p50_ms": round(float(np.median([r["p50_ms"] for r in res])), 4),
             "p99_ms": round(float(np.max([r["p99_ms"] for r in res])), 4),
+            "max_ms": round(float(np.max([r["max_ms"] for r in res])), 3),
+            "longest_child_s": round(float(np.max([r["elapsed_s"] for r in res])), 3),
             "calls": calls, "seconds": duration_s}
     rec["note"] = ("P processes, each ONE caller with its own context looping 100 x 10 regions through gklhip_compute (host arrays in, "
-                   "host doubles out), all started together; p50 = median over processes of their median call, p99 = the worst process's")
+                   "host doubles out), all started together, nothing else on the GPU (measured before this process opens the device); "
+                   "p50 = median over processes of their median call, p99 / max_ms = the worst process's, longest_child_s = the longest "
+                   "child's timed loop (seconds asked for: a stalled call shows here)")
     return rec
 
 
@@ -361,6 +366,16 @@ def main():
         return in_library_probe(a.in_library_probe, a.reads, a.haps, a.workload, a.steps, a.warmup)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return self_launch(a.gpus)
+
+    # P processes x one caller (small_batch.processes): measured FIRST, while this process has not touched the GPU yet -- an idle
+    # process that holds hardware queues of its own (this one, later: torch's and several contexts') is part of what the device's
+    # scheduler shares the chip among, and with exactly eight busy children it starves one of them for seconds (docs/NOTES.md 48)
+    early_processes = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1 and not a.no_extras and not a.double and not a.overlap and a.fma_mode == 1:
+        try:
+            early_processes = process_records(0 if os.environ.get("GKL_BENCH_SAME_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0")), a.workload)
+        except Exception as e:
+            early_processes = {"error": repr(e)}
 
     import torch
     import torch.distributed as dist
@@ -666,10 +681,7 @@ def main():
                     res["small_batch"]["concurrent"] = conc
                 except Exception as e:
                     res["jni_path"] = {"error": repr(e)}
-                try:
-                    res["small_batch"]["processes"] = process_records(dev_index, a.workload)
-                except Exception as e:
-                    res["small_batch"]["processes"] = {"error": repr(e)}
+                res["small_batch"]["processes"] = early_processes if early_processes is not None else {"error": "not measured"}
                 # reads longer than one wavefront's rows (fp32 > 511 bases, fp64 > 639): workgroups of 2-4 wavefronts per read
                 try:
                     lb = make_batch(a.workload, 1000, 32, seed=DEFAULT_SEED, read_len=(600, 1000), hap_len=(900, 1100))
