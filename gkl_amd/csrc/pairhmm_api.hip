@@ -1093,7 +1093,13 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
   // measured with P such processes on one GPU (tools/proc_scaling.py, docs/NOTES.md 48; GCUPS at 4 / 8 / 16 processes):
   // 1 stream 810 / 1055 / 1325, **2 streams 974 / 1571 / 1596** (p99 of a call 0.19 / 0.26 / 11.6 ms), 3 streams
   // 572 / 707 / 755, 4 streams 979 / 1101 / 1174, the 7 of round 4 965 / 1100 / 1130 (p99 0.19 / 11 / 25-43 ms).
-  if (hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  // ... per PROCESS: the first context of a process opens upload_stream with its own; the contexts after it (the JNI shim's
+  // slots of further Java threads) open only their own -- the runtime deals streams onto the process's (four) hardware queues
+  // in the order they are made, and with a second stream per context the own streams of four callers shared two queues
+  // (4 callers 0.72 -> 0.9 TCUPS with the pool widened to eight queues; this order gets them onto different ones as is).
+  static std::atomic<int> contexts_made{0};
+  if (contexts_made.fetch_add(1) == 0 &&
+      hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
   if (const char* v = getenv("GKL_HIP_EAGER_STREAMS")) {   // A/B: 7 = the r04 arrangement (every stream at init); 1..3 = that many spare streams on top of the two
     const int k = atoi(v);
     if (k >= 7) { if (aux_streams(c) != GKLHIP_OK) return bail(GKLHIP_ERR_HIP); }
@@ -1173,7 +1179,7 @@ struct SmallCombiner {
   int device = 0;
   bool streams_made = false;       // the flight streams are created by the first COMBINED launch (make_streams)
   int flights = 0;
-  int max_flights = 3;
+  int max_flights = 4;   // (r05, alternating on one box: 4 callers 698-723 -> 740-757 GCUPS, 16 callers 1941-2010 -> 2127-2133 with four instead of three)
   int min_batch = 0;               // 0: by load (see run())
   int64_t batch_wait_ns = 50000;
   int64_t n_calls = 0, n_combined = 0, n_launch_sets = 0;  // diagnostics (gklhip_small_call_counts)
