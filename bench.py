@@ -376,6 +376,7 @@ def main():
             early_processes = process_records(0 if os.environ.get("GKL_BENCH_SAME_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0")), a.workload)
         except Exception as e:
             early_processes = {"error": repr(e)}
+        time.sleep(float(os.environ.get("GKL_BENCH_SETTLE_S", "1")))   # (sixteen processes' worth of host and device activity just ended)
 
     import torch
     import torch.distributed as dist
