@@ -1,6 +1,7 @@
 // C-ABI implementation (include/gkl_hip_sw.h) of the MI355X Smith-Waterman path: validation, device
 // layout of a batch of pairs, one persistent-wavefront launch, read-back of the CIGAR text.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <algorithm>
 #include <cstdarg>
@@ -68,6 +69,7 @@ size_t up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 struct gklhip_sw_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t pad_stream = nullptr;   // never used: see gklhip_sw_init
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::mutex mu;
   Buf stage_in, stage_out;   // pinned: descriptors + sequences up, text + results down
@@ -100,6 +102,14 @@ int gklhip_sw_init(int device, gklhip_sw_ctx** out_ctx) {
   c->device = device;
   auto bail = [&](int st) { gklhip_sw_done(c); return st; };
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(sw_fail(GKLHIP_ERR_HIP, "hipStreamCreate failed"));
+  {
+    // Every stream is a hardware queue of the process, and how many each process holds decides how the device's scheduler
+    // shares the chip among processes: two per process measured best, THREE worst by a factor of two (docs/NOTES.md 48).
+    // libgklhip_pairhmm brings two; so that a JVM which loads this library beside it holds four and not three, the first
+    // context of a process here opens a second, unused stream as well.
+    static std::atomic<int> contexts_made{0};
+    if (contexts_made.fetch_add(1) == 0 && hipStreamCreateWithFlags(&c->pad_stream, hipStreamNonBlocking) != hipSuccess) { c->pad_stream = nullptr; (void)hipGetLastError(); }
+  }
   if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(sw_fail(GKLHIP_ERR_HIP, "hipEventCreate failed"));
   int rc = c->misc.reserve(256);
   if (rc) return bail(rc);
@@ -115,6 +125,7 @@ int gklhip_sw_done(gklhip_sw_ctx* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->pad_stream) (void)hipStreamDestroy(c->pad_stream);
   delete c;
   return GKLHIP_OK;
 }
