@@ -537,10 +537,10 @@ struct WaveJob {
   __device__ __forceinline__ void run(const FwdArgs<T>& a, int lane, int hap_begin, int hap_end) {
     constexpr int U = 8;
     if constexpr (kAsmFast || kAsm64) {
-      // the whole job in the generated asm program (tools/gen_fwd_asm.py) when only one separator can be in flight at a
-      // time: every haplotype of the job longer than the array is deep (stream order is by ascending length); fp64: no
-      // haplotype with an 'N' (four prior planes: such columns gather their priors row by row, see step_win)
-      bool whole = a.asm_general && a.hap_len[hap_begin] > skew_max;
+      // the whole job in the generated asm program (tools/gen_fwd_asm.py; a job with a haplotype no longer than the array
+      // is deep has several separators in flight: its lanes look their output column up themselves); fp64: no haplotype
+      // with an 'N' (four prior planes: such columns gather their priors row by row, see step_win)
+      bool whole = a.asm_general;
       if constexpr (kAsm64) {
         if (whole) {
           if (a.packed_out) whole = false;
@@ -1016,6 +1016,8 @@ __device__ __forceinline__ bool super_takes(const FwdArgs<T>& a, const FwdJob& j
   const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
   const int G = ((R + kRplSuper) / kRplSuper + kLanes - 1) / kLanes;
   const int64_t t_end = 64 * (int64_t)(G - 1) + (a.hap_pos[j.hap_end - 1] - a.hap_pos[j.hap_begin] + a.hap_len[j.hap_end - 1]) + 64;
+  // (a job that starts with a haplotype shorter than a wavefront is deep stays with the one-wavefront stripes: its streams are
+  //  short against an array of G x 64 lanes -- 300 reads of 5 kb x 128 haplotypes of 30-63 bases: 37 ms striped, 144 ms here)
   if (G > kPrerollMaxWaves || t_end > a.super_steps || a.hap_len[j.hap_begin] <= kLanes - 1) return false;
   if (Job::kAsm64) {
     if (a.packed_out) return false;
@@ -1081,7 +1083,7 @@ __global__ __launch_bounds__(64 * kWideWaves) void pairhmm_fwd_wide_kernel(FwdAr
     const int R = (int)(a.b.read_off[r + 1] - a.b.read_off[r]);
     const int n_blocks = (R + RPL) / RPL;
     const int n_waves = (n_blocks + kLanes - 1) / kLanes;
-    bool wide = (Job::kAsmFast || Job::kAsm64) && RPL >= 8 && a.asm_general && n_waves <= kWideWaves && a.hap_len[j.hap_begin] > kLanes - 1;
+    bool wide = (Job::kAsmFast || Job::kAsm64) && RPL >= 8 && a.asm_general && n_waves <= kWideWaves;
     if (Job::kAsm64 && wide) {
       if (a.packed_out) wide = false;
       bool any_n = false;

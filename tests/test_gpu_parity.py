@@ -368,6 +368,26 @@ def test_whole_job_asm_programs_match_the_cxx_build(native, oracle, use_double, 
             assert np.array_equal(bits(out), bits(oo)), (mode, i)
 
 
+@pytest.mark.parametrize("fma_mode", [1, 0], ids=["avx512-arith", "avx-arith"])
+@pytest.mark.parametrize("use_double", [False, True])
+def test_short_haplotype_jobs_in_the_asm_programs(native, oracle, use_double, fma_mode, monkeypatch):
+    """Round 5: a job with a haplotype no longer than the array is deep (several separators in flight) runs in the asm
+    programs too.  Calls big enough for the planned kernels (> 65 536 pairs: job lists, the packed fp64 pass): haplotypes
+    of 1 .. 63 bases only, and of 1 .. 200 (jobs that start with short haplotypes and go on with long ones), reads of one
+    base up to the longest a chunk holds; against the oracle bit for bit, and the same bits from the arrangement without
+    the general-step programs."""
+    rng = np.random.RandomState(6363)
+    batches = [random_batch(rng, 560, 120, read_len=(1, 500), hap_len=(1, 63), alphabet=b"ACGT"),
+               random_batch(rng, 700, 100, read_len=(1, 300), hap_len=(1, 200), alphabet=b"ACGTN")]
+    for b in batches:
+        with native.PairHmmContext(use_double=use_double, fma_mode=fma_mode) as c:
+            out, _ = check_against_oracle(c, oracle, b, fma_mode=fma_mode, use_double=use_double)
+        monkeypatch.setenv("GKLHIP_ASM_GENERAL", "0")
+        with native.PairHmmContext(use_double=use_double, fma_mode=fma_mode) as c:
+            assert np.array_equal(bits(c.compute(b)), bits(out))
+        monkeypatch.delenv("GKLHIP_ASM_GENERAL")
+
+
 def test_region_batch_no_fallback(ctx32, oracle):
     b = make_batch("region", 200, 16, seed=5)
     out, u = check_against_oracle(ctx32, oracle, b)

@@ -3,8 +3,8 @@
 Round 4: such a read spans the wavefronts of ONE workgroup -- the reference's stripes with their carry row
 (avx-pairhmm-template.h:249,291-323) side by side, the row handed on through a ring in LDS -- and every wavefront runs
 the generated asm program (pairhmm_fwd_wide_kernel, tools/gen_fwd_asm.py).  Jobs that fail the program's preconditions
-(more than four wavefronts' worth of rows, a haplotype no longer than a wavefront is deep, fp64: a haplotype with an N)
-are striped through memory by one wavefront as before.  Everything must stay bit-exact against the oracle, in both
+(fp64: a haplotype with an N) are striped through memory by one wavefront as before; round 5: more than four wavefronts'
+worth of rows run in super-stripes, and haplotypes no longer than a wavefront is deep no longer disqualify a job.  Everything must stay bit-exact against the oracle, in both
 precisions, mixed with short reads, on both sides of the precision policy."""
 import numpy as np
 import pytest
@@ -148,3 +148,26 @@ def test_long_reads_in_the_unfused_arithmetic(native, oracle, use_double):
         r0, r1 = c0.raw(b.n_pairs), c1.raw(b.n_pairs)
         k = 1 if use_double else 0
         assert not np.array_equal(bits(r0[k]), bits(r1[k]))
+
+
+@pytest.mark.parametrize("use_double", [False, True])
+def test_long_reads_against_haplotypes_shorter_than_a_wavefront(native, oracle, use_double, monkeypatch):
+    """Haplotypes of 1 .. 63 bases put SEVERAL separators into a 64-lane array at once; since round 5 the asm programs take
+    such jobs too (a storing lane looks its output column up by the index its separator carries): reads of up to four
+    wavefronts run them in the wide kernel instead of the one-wavefront stripes (longer reads keep the stripes for
+    such jobs: short streams against a very deep array).  Long reads of two wavefronts up to super-stripe sizes against
+    short, medium and long haplotypes in one call (every job's first haplotype is a short one: stream order is by
+    ascending length), both precisions; the arrangement without the programs gives the same bits."""
+    rng = np.random.RandomState(606)
+    haps = random_batch(rng, 1, 14, read_len=(10, 20), hap_len=(1, 63), alphabet=b"ACGT", qual_range=(10, 45))
+    mixed = random_batch(rng, 1, 9, read_len=(10, 20), hap_len=(1, 1400), alphabet=b"ACGT", qual_range=(10, 45))
+    longs = related_batch(rng, [1800, 1500, 5200], [600, 700, 1000, 1300, 1650, 2047, 2600, 5000])
+    for hb in (haps, mixed):
+        b = cat_reads(hb, longs)
+        with native.PairHmmContext(use_double=use_double, record_events=True) as c:
+            out, _ = check(c, oracle, b, use_double)
+            assert c.stats()["n_long_pairs"] > 0
+        monkeypatch.setenv("GKLHIP_ASM_GENERAL", "0")
+        with native.PairHmmContext(use_double=use_double) as c:
+            assert np.array_equal(bits(c.compute(b)), bits(out))
+        monkeypatch.delenv("GKLHIP_ASM_GENERAL")

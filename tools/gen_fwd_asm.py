@@ -28,9 +28,12 @@ the fast step's arithmetic plus, for lanes on a separator-type entry, M, Y and t
 scalar branch taken only when a lane holding the END of a read is on the separator in flight, the store of the pair's sum.
 The step that FEEDS a separator also moves the next haplotype's Y0 into the pad row of every read's first lane.
 
-Preconditions (checked by the caller, WaveJob::run): every haplotype of the job is longer than the array is deep
-(skew_max + 1 columns: one separator in flight at a time -- stream order is by ascending length, so the first one decides);
-fp64: no haplotype of the job contains an 'N' (four prior planes), no packed output.
+A job whose haplotypes are all longer than the array is deep (skew_max + 1 columns; stream order is by ascending length,
+so the first one decides) has one separator in flight at a time and its output column in a scalar register; otherwise
+(`multi`) a storing lane reads hap_orig[k] for the k its separator carries -- two more scalar instructions in the store
+branch of the first kind, a dependent load per storing step in the second.
+Preconditions (checked by the caller, WaveJob::run): fp64: no haplotype of the job contains an 'N' (four prior planes), no
+packed output.
 """
 import sys
 
@@ -39,7 +42,7 @@ U = 8  # columns per fast block
 
 # scalar registers owned by the asm program (clobbered): entries of a block, loop state
 S_E0 = 72          # s[72:79]: eight stream entries (s_load_dwordx8: 4-aligned)
-S_SENT, S_ORIG, S_CNT, S_PH, S_BT, S_TMP = "s80", "s81", "s82", "s83", "s84", "s85"
+S_LIM, S_ORIG, S_CNT, S_PH, S_BT, S_TMP = "s80", "s81", "s82", "s83", "s84", "s85"
 S_SAVE = "s[86:87]"
 S_SRC = 88         # s[88:89]: the stream pointer (operand src, pinned there)
 S_T, S_NEED = "s90", "s91"   # wide variant: steps this wavefront has completed (operand st, pinned there); scratch
@@ -350,14 +353,13 @@ def fast_block(c, ents, wide=False):
 def general_step(c, e, lab, wide=False):
     """one stream column, any entry kind; parity-neutral (Y in Ya in place, row-above set in RS[0], diagonal set in RS[1]).
     `lab`: base of this copy's local labels.  Scalar state: S_CNT steps left in this run (counted here), S_BT = the value of
-    S_CNT at which the step feeds the haplotype's separator (0xffffffff: never), S_SENT / S_ORIG the separator in flight."""
+    S_CNT at which the step feeds the haplotype's separator (0xffffffff: never), S_ORIG the output column of the separator in flight."""
     R = c.R
     r, d = c.RS[0], c.RS[1]
     L = lambda k: str(lab + k)
     o = []
     # the step that feeds the separator: from here on lanes meet THIS haplotype's separator (the previous one has left the array)
     o.append(f"s_cmp_eq_u32 {S_CNT}, {S_BT}")
-    o.append(f"s_cselect_b32 {S_SENT}, %[sent], {S_SENT}")
     o.append(f"s_cselect_b32 {S_ORIG}, %[orig], {S_ORIG}")
     o += ["s_nop 1", f"v_and_b32_dpp v{c.EAB}, v{c.ENT}, v{c.NDIRECT} {DPP}"]
     o.append(f"v_and_or_b32 v{c.ENT}, {e}, v{c.DIRECT}, v{c.EAB}")
@@ -377,11 +379,22 @@ def general_step(c, e, lab, wide=False):
         o += mov(c, d[k], r[k])
     # the pair's result: lanes that hold the LAST row of a read (%[outmask]) and are on the separator in flight
     o.append(f"{fp(c, 'add')} {c.v(c.VAL)}, {c.v(c.SM)}, {c.v(c.SX)}")
-    o.append(f"v_cmp_eq_u32 vcc, {S_SENT}, v{c.ENT}")
+    # a haplotype's separator: any entry below the pre-roll words (signed; S_LIM = kEntNoEmit).  With one separator in the
+    # array at a time its output column is S_ORIG; with several (%[multi]: a haplotype no longer than the array is deep)
+    # every lane looks its own up by the stream-order index its separator carries
+    o.append(f"v_cmp_gt_i32 vcc, {S_LIM}, v{c.ENT}")
     o.append("s_and_b64 vcc, vcc, %[outmask]")                # (SCC = some lane stores)
     o.append(f"s_cbranch_scc0 {L(1)}f")
     o.append(f"s_and_saveexec_b64 {S_SAVE}, vcc")
     o.append(f"v_add_u32 v{c.Y0N}, {S_ORIG}, v{c.OUTIDX}")   # pair index (Y0N doubles as the index temporary)
+    o.append("s_cmp_eq_u32 %[multi], 0")
+    o.append(f"s_cbranch_scc1 {L(4)}f")
+    o.append(f"v_and_b32 v{c.Y0N}, 0x3fffffff, v{c.ENT}")
+    o.append(f"v_mad_u64_u32 v[{c.A}:{c.A + 1}], vcc, v{c.Y0N}, 4, %[haporig]")
+    o.append(f"global_load_dword v{c.Y0N}, v[{c.A}:{c.A + 1}], off")
+    o.append("s_waitcnt vmcnt(0)")
+    o.append(f"v_add_u32 v{c.Y0N}, v{c.Y0N}, v{c.OUTIDX}")
+    o.append(f"{L(4)}:")
     o.append(f"v_mad_u64_u32 v[{c.A}:{c.A + 1}], vcc, v{c.Y0N}, {8 if c.f64 else 4}, %[raw]")
     o.append(f"global_store_dword{'x2' if c.f64 else ''} v[{c.A}:{c.A + 1}], {c.v(c.VAL)}, off")
     if not c.f64:
@@ -429,7 +442,7 @@ def program(c, wide=False):
     load = [f"s_load_dwordx8 s[{S_E0}:{S_E0 + 7}], s[{S_SRC}:{S_SRC + 1}], 0x0",
             f"s_add_u32 s{S_SRC}, s{S_SRC}, 32", f"s_addc_u32 s{S_SRC + 1}, s{S_SRC + 1}, 0",
             "s_waitcnt lgkmcnt(0)"]
-    o = [f"s_mov_b32 {S_SENT}, %[sent_old]", f"s_mov_b32 {S_ORIG}, %[orig_old]",
+    o = [f"s_mov_b32 {S_LIM}, 0xbffffffe", f"s_mov_b32 {S_ORIG}, %[orig_old]",
          f"s_mov_b32 {S_CNT}, %[n_pre]", f"s_mov_b32 {S_PH}, 0", f"s_mov_b32 {S_BT}, -1"]
     o.append("60:")                                            # ---- a run of S_CNT general steps
     o.append(f"s_cmp_eq_u32 {S_CNT}, 0")
@@ -577,7 +590,10 @@ def driver(c, o, wide=False):
         o.append("  const float minacc = 1e-28f;")
     o.append("  const int skew = j.skew_max;")
     o.append("  uint64_t src = (uint64_t)(uintptr_t)(a.stream + sb);")
-    o.append("  uint32_t sent_old = kEntNoEmit, orig_old = 0;")
+    o.append("  uint32_t orig_old = 0;")
+    o.append("  // several separators in the array at once (stream order is by ascending length: the first haplotype decides)?")
+    o.append("  const uint32_t multi = hap_len[hap_begin] <= skew ? 1u : 0u;")
+    o.append("  const uint64_t haporig = (uint64_t)(uintptr_t)a.hap_orig;")
     o.append("  int t = 0, fast_from = skew;   // the fill: the most skewed lane meets its first column at t = skew")
     if wide:
         o.append("  const int delay = 64 * wave;")
@@ -589,7 +605,7 @@ def driver(c, o, wide=False):
     else:
         o.append("  for (int k = hap_begin; k <= hap_end; k++) {")
     o.append("    int n_pre, n_blk, n_post, has_sep;")
-    o.append("    uint32_t sent = kEntNoEmit, orig = 0;")
+    o.append("    uint32_t orig = 0;")
     o.append(f"    {T} y0n = 0;")
     if wide:
         o.append("    if (k < hap_begin) {")
@@ -609,7 +625,6 @@ def driver(c, o, wide=False):
     o.append("      n_blk = rem >> 3;")
     o.append("      n_post = (rem & 7) + 1;                             // leftover columns + the separator itself")
     o.append("      has_sep = 1;")
-    o.append("      sent = kEntSep | (uint32_t)k;")
     o.append("      orig = (uint32_t)hap_orig[k];")
     o.append("      if (k + 1 < hap_end) y0n = y0s[k + 1];")
     o.append("      t = sep_at + 1;")
@@ -625,7 +640,10 @@ def driver(c, o, wide=False):
     o.append("    // (wave-uniform by construction; said explicitly so that they are SGPR operands in every kernel this is inlined into)")
     for nm in ("n_pre", "n_blk", "n_post", "has_sep"):
         o.append(f"    {nm} = __builtin_amdgcn_readfirstlane({nm});")
-    for nm in ("sent", "orig", "sent_old", "orig_old"):
+    o.append("    const uint32_t multi_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)multi);")
+    o.append("    const uint64_t haporig_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(haporig >> 32)) << 32) |")
+    o.append("                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)haporig);")
+    for nm in ("orig", "orig_old"):
         o.append(f"    {nm} = (uint32_t)__builtin_amdgcn_readfirstlane((int){nm});")
     o.append("    src = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(src >> 32)) << 32) |")
     o.append("          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)src);")
@@ -640,7 +658,7 @@ def driver(c, o, wide=False):
     outs = ", ".join(f"\"+{hard(c, reg)}\"({name})" for _, reg, name in inout) + f", \"+{hard(c, c.ENT, 1)}\"(ent), " \
         f"\"+&{{s[{S_SRC}:{S_SRC + 1}]}}\"(src)"   # (early clobber: the program advances it while it still reads its scalar inputs)
     inp = ", ".join(f"\"{hard(c, reg)}\"({name})" for _, reg, name in consts) + ", " + extra_v + \
-        ", [sent] \"s\"(sent), [orig] \"s\"(orig), [sent_old] \"s\"(sent_old), [orig_old] \"s\"(orig_old), [outmask] \"s\"(outmask), " \
+        ", [orig] \"s\"(orig), [orig_old] \"s\"(orig_old), [multi] \"s\"(multi_s), [haporig] \"s\"(haporig_s), [outmask] \"s\"(outmask), " \
         "[raw] \"s\"(raw), " + ("" if c.f64 else "[packed] \"s\"(packed), [minacc] \"s\"(minacc), ") + y0in + \
         ", [n_pre] \"s\"(n_pre), [n_blk] \"s\"(n_blk), [n_post] \"s\"(n_post), [has_sep] \"s\"(has_sep)"
     clob = clobbers(c)
@@ -654,7 +672,7 @@ def driver(c, o, wide=False):
         clob = clob + [f"v{c.WADDR}", f"v{c.FV}", S_NEED]
     prog = program(c, wide)
     emit_asm(o, prog, outs, inp, clob, "    ")
-    o.append("    sent_old = sent; orig_old = orig;")
+    o.append("    orig_old = orig;")
     o.append("  }")
     o.append("}")
     return prog
