@@ -332,8 +332,8 @@ def test_whole_job_asm_programs_match_the_cxx_build(native, oracle, use_double, 
     (tools/gen_fwd_asm.py), fp32 at 8 rows per lane and fp64 at 10 (the packed recomputation pass and the all-fp64 mode).
     Three builds / modes must give the same bits as the oracle: the asm programs (default), the round-3 arrangement
     (GKLHIP_ASM_GENERAL=0: asm fast blocks inside C++ general steps; fp64 all C++) and the all-C++ cross-check library.
-    Batches: the bench shape; haplotypes shorter than the array is deep (the job fails the program's precondition and
-    takes the C++ steps inside the asm build); haplotypes with N (fp64: four prior planes); lower case and odd bytes;
+    Batches: the bench shape; haplotypes shorter than the array is deep (several separators in flight: until round 5 such
+    a job took the C++ steps inside the asm build, now the programs look the output column up per lane); haplotypes with N (fp64: four prior planes); lower case and odd bytes;
     reads of one base up to the longest a chunk holds; single-lane reads (every lane feeds the separator itself).
     Round 5: the same for the UNFUSED arithmetic of the reference's AVX translation unit (fma_mode 0: the "...n" programs,
     12 operations per cell) -- what GKL computes on a host without AVX-512."""
