@@ -67,15 +67,8 @@ def cpu_baseline(batch, budget_s=6.0):
         isa = "scalar"
     # threads = the CPUs this process may really use: the cgroup quota when there is one (the GPU boxes expose 256
     # hardware threads but grant 16 CPUs; more threads than that only get throttled)
-    quota = None
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            quota = max(1, int(int(q) / int(per)))
-    except (OSError, ValueError):
-        pass
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(eng.max_threads(), avail, quota or avail))
+    avail, quota = _host_threads()
+    threads = max(1, min(eng.max_threads(), avail))
     probe = batch.read_slice(0, min(batch.n_reads, 2 * threads))
     t0 = time.time()
     run(probe, threads)
@@ -143,39 +136,50 @@ def host_call_record(native, batch, dev_index, calls=30, warm=15, max_threads=0)
 
 
 def jni_records(batch, c1, host_ms, host_ms_4=None):
-    """computeLikelihoodsNative itself, driven through a mock JNIEnv (tests/native/mock_jni.cpp: -Xcheck:jni-style
-    bookkeeping on every call, so its JNI functions cost several times a real JVM's): ms per call for the bench batch
-    (C2) and a GATK-sized region (C1) with the shim's own split -- marshalling on the calling thread, waiting for
-    compute that marshalling did not cover, write-back -- and the aggregate rate of 1 / 4 / 16 concurrent Java threads
-    each sending 100 x 10 regions through their own slot (GKL_HIP_SLOTS raised to the thread count)."""
+    """computeLikelihoodsNative itself, driven through a mock JVM (tests/native/mock_jni.cpp: HotSpot's reference model --
+    a jobject is a slot of the thread's handle arena -- with -Xcheck:jni's rules checked on every call; `mock_ns_per_jni_call`
+    says what its functions cost, for scale): per call of the bench batch (C2, 36 timed calls after 6 warm ones: median, p10,
+    p90) and of a GATK-sized region (C1), with the shim's own split -- marshalling on the calling thread, waiting for compute
+    that marshalling did not cover, write-back -- and the aggregate rate of 1 / 4 / 16 concurrent Java threads each sending
+    100 x 10 regions through their own slot (GKL_HIP_SLOTS raised to the thread count)."""
+    import ctypes as C
     from tests import mockjni
     rec = {}
 
     def one(b, iters, warm, threads=1, max_threads=1):
-        t = []
-        rc, _, cls, msg, wall = mockjni.run_concurrent(b, threads, iters=iters, warm=warm, timing=t, max_threads=max_threads)
+        t, calls, k = [], [], []
+        rc, _, cls, msg, wall = mockjni.run_concurrent(b, threads, iters=iters, warm=warm, timing=t, max_threads=max_threads, calls=calls, counters=k)
         if rc != 0:
             raise RuntimeError(f"mock JNI run failed: {cls} {msg}")
-        calls = max(t[4], 1)
-        return wall, t, calls
-    wall, t, calls = one(batch, 8, 4)   # (the first pipelined calls of a slot still grow its pinned arenas)
-    ms = wall / 8
-    rec["c2"] = {"ms_per_call": round(ms, 3), "gcups": round(batch.cells / ms / 1e6, 1),
-                 "marshal_ms": round(t[0] / calls / 1e6, 3), "compute_wait_ms": round(t[1] / calls / 1e6, 3),
-                 "writeback_ms": round(t[2] / calls / 1e6, 3), "pipelined": bool(t[5]),
-                 "over_host_path": round(ms / host_ms, 3) if host_ms else None}
-    rec["c2"]["max_threads"] = 1
-    wall, t, calls = one(batch, 8, 4, max_threads=4)
-    ms = wall / 8
-    rec["c2_max_threads_4"] = {"ms_per_call": round(ms, 3), "gcups": round(batch.cells / ms / 1e6, 1),
-                               "marshal_ms": round(t[0] / calls / 1e6, 3), "compute_wait_ms": round(t[1] / calls / 1e6, 3),
-                               "writeback_ms": round(t[2] / calls / 1e6, 3), "pipelined": bool(t[5]), "max_threads": 4,
-                               "over_host_path": round(ms / host_ms_4, 3) if host_ms_4 else None}
-    wall, t, calls = one(c1, 200, 30)
+        return wall, t, max(t[4], 1), calls, k
+
+    def big(max_threads, host):
+        iters, warm = 36, 6   # (the first pipelined calls of a slot still grow its pinned arenas and start its helper threads)
+        wall, t, calls, per_call, k = one(batch, iters, warm, max_threads=max_threads)
+        ms = np.array([c[0] for c in per_call])
+        med = float(np.median(ms))
+        return {"ms_per_call": round(med, 3), "p10_ms": round(float(np.percentile(ms, 10)), 3), "p90_ms": round(float(np.percentile(ms, 90)), 3),
+                "mean_ms": round(wall / iters, 3), "calls": iters, "gcups": round(batch.cells / med / 1e6, 1),
+                "marshal_ms": round(t[0] / calls / 1e6, 3), "compute_wait_ms": round(t[1] / calls / 1e6, 3),
+                "writeback_ms": round(t[2] / calls / 1e6, 3), "pipelined": bool(t[5]), "max_threads": max_threads,
+                "jni_calls_per_read": round(k[mockjni.JNI_CALLS] / (iters + warm) / batch.n_reads, 2),
+                "share_of_jni_calls_on_helper_threads": round(k[mockjni.HELPER_JNI_CALLS] / max(1, k[mockjni.JNI_CALLS]), 3),
+                "xcheck_violations": k[mockjni.VIOLATIONS],
+                "caller_cpus_seen": len({c[2] for c in per_call} | {c[3] for c in per_call}),
+                "over_host_path": round(med / host, 3) if host else None}
+    rec["c2"] = big(1, host_ms)
+    rec["c2_max_threads_4"] = big(4, host_ms_4)
+    wall, t, calls, _, _ = one(c1, 200, 30)
     ms = wall / 200
     rec["c1"] = {"ms_per_call": round(ms, 4), "gcups": round(c1.cells / ms / 1e6, 1),
                  "marshal_ms": round(t[0] / calls / 1e6, 4), "compute_wait_ms": round(t[1] / calls / 1e6, 4),
                  "writeback_ms": round(t[2] / calls / 1e6, 4)}
+    try:
+        lib = C.CDLL(mockjni.SO)
+        lib.mockjni_selfbench.restype = C.c_double
+        rec["mock_ns_per_jni_call"] = round(min(lib.mockjni_selfbench(4000, 150) for _ in range(3)), 1)
+    except (OSError, AttributeError):
+        pass
     conc = {}
     os.environ["GKL_HIP_SLOTS"] = "16"
     try:
@@ -185,13 +189,12 @@ def jni_records(batch, c1, host_ms, host_ms_4=None):
             b = make_batch("hc", 100 * threads, 10, seed=DEFAULT_SEED)
             iters = 150
             runs = sorted((one(b, iters, 20, threads) for _ in range(3)), key=lambda r: r[0])
-            wall, t, calls = runs[1]  # the median of three (the aggregate of many short calls moves +-10 % run to run)
+            wall, t, calls, _, _ = runs[1]  # the median of three (the aggregate of many short calls moves +-10 % run to run)
             conc[f"callers_{threads}"] = {"aggregate_gcups": round(b.cells * iters / wall / 1e6, 1),
                                           "calls_per_s": round(threads * iters / wall * 1e3, 1),
                                           "ms_per_call": round(t[3] / calls / 1e6, 4),
                                           "best_of_3_gcups": round(b.cells * iters / runs[0][0] / 1e6, 1)}
         try:
-            import ctypes as C
             k = (C.c_int64 * 3)()
             C.CDLL(mockjni.JNI_LIB).gklhip_small_call_counts(0, k, 0)
             conc["launched_together"] = {"small_calls": int(k[0]), "combined": int(k[1]), "launch_sets": int(k[2])}
@@ -199,10 +202,175 @@ def jni_records(batch, c1, host_ms, host_ms_4=None):
             pass
     finally:
         os.environ.pop("GKL_HIP_SLOTS", None)
-    rec["note"] = ("through Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative with a mock JNIEnv; big calls are "
-                   "pipelined (read ranges marshalled while earlier ranges compute on the slot's two engines); initNative's "
-                   "maxNumberOfThreads caps the host log10 threads per engine: c2 = 1 (the reference's default), c2_max_threads_4 = GATK's")
+    rec["note"] = ("through Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihoodsNative with a mock JVM (no JDK exists in this image or on "
+                   "the GPU boxes); ms_per_call = MEDIAN of the timed calls; big calls are pipelined (read ranges marshalled -- 13 JNI calls per "
+                   "read -- while earlier ranges compute on the slot's two engines); initNative's maxNumberOfThreads caps the host threads per "
+                   "engine's log10 pass AND the threads that marshal (the calling thread + helpers attached through the JavaVM): c2 = 1 (the "
+                   "reference's default), c2_max_threads_4 = GATK's --native-pair-hmm-threads default")
     return rec, conc
+
+
+def _host_threads():
+    """CPUs this process may really use: the cgroup quota when there is one, else its affinity mask."""
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(avail, quota or avail)), quota
+
+
+def _timed(fn, calls, warm, kernel_ms=None):
+    """(median wall ms, best kernel ms) of `calls` back-to-back calls after `warm` untimed ones."""
+    for _ in range(warm):
+        fn()
+    ts, ks = [], []
+    for _ in range(calls):
+        t = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t)
+        if kernel_ms is not None:
+            ks.append(kernel_ms())
+    return float(np.median(ts)) * 1e3, (min(ks) if ks else None)
+
+
+PEAK_FP64_VECTOR_TFLOPS = PEAK_FP32_VECTOR_TFLOPS / 2
+PEAK_INT32_TIOPS = 256 * 64 * 2.4e9 / 1e12     # one 32-bit integer operation per lane and clock
+
+
+def pdhmm_records(dev_index, fixture_x=32):
+    """BASELINE config 5 in the driver's line: the reference's own reads x haplotypes fixture (tests/golden/pdhmm_new.txt,
+    276 reads x 48 real GATK PD haplotypes) through the three ways IntelPDHMM is called -- `cross`: computeLikelihoodsNative's
+    entry point on the fixture's reads x32 against its 48 haplotypes (what fills the chip), `paired`: computePDHMMNative's
+    padded 1:1 layout on the same pairs (every pair its own haplotype item, 498 MB of input), `region_276x48_single_call`:
+    ONE fixture-sized call, what a GATK region is -- with GKL's own AVX-512 (AVX2) PDHMM kernel on the host cores beside it
+    (IntelPDHMM.cc:144-202 runs it under OpenMP).  12 flop per cell (pdhmm.h:427-443), fp64 vector peak."""
+    from gkl_amd import native
+    from gkl_amd.pdhmm_batch import PdhmmBatch
+    from tests.golden_io import load_pdhmm_holders_file
+    reads, haps, _ = load_pdhmm_holders_file()
+    one = b"\0"
+    r1 = PdhmmBatch.from_pairs([(one, one, r[0], r[1], r[2], r[3], r[4]) for r in reads])
+    hb = PdhmmBatch.from_pairs([(h[0], h[1], one, one, one, one, one) for h in haps])
+    rx = r1.subset(np.tile(np.arange(r1.batch), fixture_x))
+    cells1 = int(r1.read_lengths.sum()) * int(hb.hap_lengths.sum())
+    cells = cells1 * fixture_x
+
+    def roof(kernel, k_ms, n_cells):
+        ach = FLOP_PER_CELL * n_cells / (k_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "limiter": "valu-fp64 issue", "kernel": kernel, "flop_per_cell": FLOP_PER_CELL, "achieved": round(ach, 2),
+                "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP64_VECTOR_TFLOPS, 4), "traffic": None}
+    rec = {"data": "the reference's own fixture pdhmm_new.txt (276 reads x 48 PD haplotypes)", "dtype": "f64", "unit": "GCUPS"}
+    with native.PdhmmContext(device=dev_index, fma_mode=1) as c:
+        ms, k = _timed(lambda: c.compute_cross(rx, hb), 5, 2, c.last_kernel_ms)
+        routing = c.last_routing()
+        rec["cross"] = {"workload": f"IntelPDHMM.computeLikelihoods: {rx.batch} reads x {hb.batch} haplotypes (the fixture's reads x{fixture_x})",
+                        "cells": cells, "kernel_ms": round(k, 4), "kernel_gcups": round(cells / k / 1e6, 1), "host_to_host_ms": round(ms, 3),
+                        "gcups": round(cells / ms / 1e6, 1), "haplotypes_by_kernel": {"lds_prior_table": routing[0], "predicate": routing[1], "byte_comparing": routing[2]},
+                        "roofline": roof("pdhmm_fwd_tab_kernel", k, cells)}
+        ms1, k1 = _timed(lambda: c.compute_cross(r1, hb), 30, 10, c.last_kernel_ms)
+        rec["region_276x48_single_call"] = {"workload": "ONE computeLikelihoodsNative call of the fixture: 276 reads x 48 haplotypes = 13 248 pairs",
+                                            "cells": cells1, "ms_per_call": round(ms1, 4), "gcups": round(cells1 / ms1 / 1e6, 1),
+                                            "kernel_ms": round(k1, 4), "roofline": roof("pdhmm_fwd_tab_kernel", k1, cells1)}
+    # the same pairs as padded 1:1 arrays (computePDHMMNative): pair (r, h) = read r with its own copy of haplotype h
+    ri, hi = np.repeat(np.arange(r1.batch), hb.batch), np.tile(np.arange(hb.batch), r1.batch)
+    hsub, rsub = hb.subset(hi), r1.subset(ri)
+    p1 = PdhmmBatch(rsub.batch, hb.max_hap_len, r1.max_read_len, hsub.hap_bases, hsub.hap_pdbases, rsub.read_bases, rsub.read_qual,
+                    rsub.read_ins_qual, rsub.read_del_qual, rsub.gcp, hsub.hap_lengths, rsub.read_lengths)
+    px = p1.subset(np.tile(np.arange(p1.batch), fixture_x))
+    with native.PdhmmContext(device=dev_index, fma_mode=1) as c:
+        ms, k_sliced = _timed(lambda: c.compute(px), 4, 2, c.last_kernel_ms)
+        routing = c.last_routing()
+    os.environ["GKL_HIP_PDHMM_PIPELINE"] = "0"   # the call in one piece: the kernels' own time, without the slices' tails
+    try:
+        with native.PdhmmContext(device=dev_index, fma_mode=1) as c:
+            ms_one, k = _timed(lambda: c.compute(px), 3, 1, c.last_kernel_ms)
+    finally:
+        os.environ.pop("GKL_HIP_PDHMM_PIPELINE", None)
+    rec["paired"] = {"workload": f"IntelPDHMM.computePDHMM: the same {px.batch} (read, haplotype) pairs as padded 1:1 arrays "
+                                 f"({px.batch * (2 * px.max_hap_len + 5 * px.max_read_len) / 1e6:.0f} MB of input)",
+                     "cells": int(px.cells), "kernel_ms": round(k, 4), "kernel_gcups": round(px.cells / k / 1e6, 1), "kernel_ms_sliced": round(k_sliced, 4),
+                     "host_to_host_ms": round(ms, 3), "gcups": round(px.cells / ms / 1e6, 1), "host_to_host_ms_in_one_piece": round(ms_one, 3),
+                     "packed_jobs_by_kernel": {"lds_prior_table": routing[0], "predicate": routing[1], "byte_comparing": routing[2]},
+                     "roofline": roof("pdhmm_fwd_tab_paired_kernel (+ pdhmm_job_special_kernel)", k, int(px.cells)),
+                     "note": "kernel_ms = HIP events around the launches of the call in ONE piece (GKL_HIP_PDHMM_PIPELINE=0); by default a call of "
+                             "this size is cut into seven slices whose kernels run while later slices cross PCIe (kernel_ms_sliced, host_to_host_ms)"}
+    try:
+        from oracle.pdhmm import PdhmmReference
+        ref = PdhmmReference()
+        eng = 2 if ref.simd_width(2) >= 8 else 1
+        threads, quota = _host_threads()
+        sample = p1.subset(np.tile(np.arange(p1.batch), 4))
+        ref.compute(p1, engine=eng, threads=threads)
+        t0 = time.perf_counter()
+        st, _ = ref.compute(sample, engine=eng, threads=threads)
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        ref.compute(p1.subset(np.arange(1500)), engine=eng, threads=1)
+        one_thread = p1.subset(np.arange(1500)).cells / (time.perf_counter() - t1) / 1e9
+        rec["cpu_baseline"] = {"value": round(sample.cells / dt / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "reference",
+                               "one_thread_gcups": round(one_thread, 3), "isa": "avx512" if eng == 2 else "avx2", "cgroup_cpu_quota": quota,
+                               "sample": f"the fixture's {p1.batch} pairs x4 ({sample.cells:.3e} cells, {dt:.2f} s), GKL's own PDHMM kernel under OpenMP"}
+    except Exception as e:
+        rec["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+    return rec
+
+
+def sw_records(dev_index, n_pairs=8192):
+    """SURVEY 8 f4 in the driver's line: the batch entry point (gklhip_sw_align_batch) on haplotype-to-reference shaped pairs
+    (ref 300-600, alt 250-600, GATK's 200/-150/-260/-11, SOFTCLIP) with GKL's own AVX-512 (AVX2) object -- one pair per call,
+    one thread: IntelSmithWaterman.alignNative has no batch and no OpenMP (IntelSmithWaterman.cc:70-124) -- beside it.
+    20 integer operations per cell (5 add, 5 max, compare + select for the score, 2 per back-track bit)."""
+    from gkl_amd import native
+    rng = np.random.RandomState(3)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    refs, alts = [], []
+    for _ in range(n_pairs):
+        L, M = int(rng.randint(300, 601)), int(rng.randint(250, 601))
+        ref = letters[rng.randint(0, 4, L)]
+        start = int(rng.randint(0, max(1, L - M + 1)))
+        alt = ref[start:start + M].copy()
+        u = rng.rand(alt.size)
+        sub = u < 0.01
+        alt[sub] = letters[rng.randint(0, 4, int(sub.sum()))]
+        alt = np.delete(alt, np.nonzero((u >= 0.01) & (u < 0.02))[0])
+        at = np.nonzero(rng.rand(alt.size) < 0.01)[0]
+        alt = np.insert(alt, at, letters[rng.randint(0, 4, at.size)])
+        refs.append(ref.tobytes())
+        alts.append(alt.tobytes() or b"A")
+    params = (200, -150, -260, -11)
+    with native.SwContext(device=dev_index) as c:
+        pk = c.pack(refs, alts, cigar_stride=256)
+        cells = int(pk["cells"])
+        ms, k = _timed(lambda: c.align_packed(pk, params, native.SW_SOFTCLIP), 6, 2, c.last_kernel_ms)
+    ach = 20 * cells / (k * 1e-3) / 1e12
+    rec = {"batch": {"workload": f"{n_pairs} pairs, haplotype-to-reference (ref 300-600, alt 250-600), GATK parameters 200/-150/-260/-11, SOFTCLIP, "
+                                 "gklhip_sw_align_batch", "cells": cells, "kernel_ms": round(k, 4), "kernel_gcups": round(cells / k / 1e6, 1),
+                     "host_to_host_ms": round(ms, 3), "gcups": round(cells / ms / 1e6, 1), "dtype": "int32", "data": "synthetic",
+                     "roofline": {"bound": "mfma", "limiter": "valu-int32 issue", "kernel": "sw_align_kernel", "ops_per_cell": 20, "achieved": round(ach, 2),
+                                  "peak": round(PEAK_INT32_TIOPS, 1), "unit": "Tiop/s", "frac": round(ach / PEAK_INT32_TIOPS, 4), "traffic": None}}}
+    try:
+        from oracle.sw import SwReference
+        ref = SwReference()
+        eng = 2 if ref.has_avx512() else 1
+        sub = list(zip(refs, alts))[:300]
+        for r, x in sub[:20]:
+            ref.align(r, x, params, native.SW_SOFTCLIP, engine=eng)
+        t0 = time.perf_counter()
+        for r, x in sub:
+            ref.align(r, x, params, native.SW_SOFTCLIP, engine=eng)
+        per = (time.perf_counter() - t0) / len(sub)
+        sc = sum(len(r) * len(x) for r, x in sub)
+        rec["batch"]["cpu_baseline"] = {"value": round(sc / (per * len(sub)) / 1e9, 3), "unit": "GCUPS", "cores": 1, "kind": "reference",
+                                        "us_per_call": round(per * 1e6, 1), "isa": "avx512" if eng == 2 else "avx2",
+                                        "sample": f"first {len(sub)} pairs of the same batch, one alignNative-style call per pair on one thread "
+                                                  "(the reference's entry point has no batch and no OpenMP)"}
+    except Exception as e:
+        rec["batch"]["cpu_baseline"] = {"value": None, "unit": "GCUPS", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+    return rec
 
 
 def small_proc_worker(idx, dev_index, workload, duration_s):
@@ -696,6 +864,15 @@ def main():
                 except Exception as e:
                     res["jni_path"] = {"error": repr(e)}
                 res["small_batch"]["processes"] = {"error": "measured by the parent run (see main)"}
+                # BASELINE config 5 (PDHMM) and SURVEY 8 f4 (Smith-Waterman) in the same driver-run line
+                try:
+                    res["pdhmm"] = pdhmm_records(dev_index)
+                except Exception as e:
+                    res["pdhmm"] = {"error": repr(e)}
+                try:
+                    res["sw"] = sw_records(dev_index)
+                except Exception as e:
+                    res["sw"] = {"error": repr(e)}
                 # reads longer than one wavefront's rows (fp32 > 511 bases, fp64 > 639): workgroups of 2-4 wavefronts per read
                 try:
                     lb = make_batch(a.workload, 1000, 32, seed=DEFAULT_SEED, read_len=(600, 1000), hap_len=(900, 1100))

@@ -13,7 +13,10 @@
 // DeleteLocalRef 23, GetFieldID 94, GetObjectField 95, GetArrayLength 171,
 // GetObjectArrayElement 173, GetByteArrayRegion 200, SetDoubleArrayRegion 214,
 // ExceptionCheck 228; the PDHMM shim adds NewDoubleArray 182 and GetLongArrayRegion 204, the
-// Smith-Waterman shim SetByteArrayRegion 208 and SetIntArrayRegion 211.
+// Smith-Waterman shim SetByteArrayRegion 208 and SetIntArrayRegion 211.  The PairHMM shim's block-wise marshalling
+// uses PushLocalFrame 19 / PopLocalFrame 20, and its helper threads NewGlobalRef 21 / DeleteGlobalRef 22, GetJavaVM
+// 219 and, of the invocation interface (JavaVM: "The Invocation API", JNIInvokeInterface), DetachCurrentThread 5,
+// GetEnv 6 and AttachCurrentThreadAsDaemon 7.
 #pragma once
 #include <stdint.h>
 
@@ -55,6 +58,10 @@ enum {
   kJniSlotFindClass = 6,
   kJniSlotThrowNew = 14,
   kJniSlotExceptionClear = 17,
+  kJniSlotPushLocalFrame = 19,
+  kJniSlotPopLocalFrame = 20,
+  kJniSlotNewGlobalRef = 21,
+  kJniSlotDeleteGlobalRef = 22,
   kJniSlotDeleteLocalRef = 23,
   kJniSlotGetFieldID = 94,
   kJniSlotGetObjectField = 95,
@@ -66,6 +73,7 @@ enum {
   kJniSlotSetByteArrayRegion = 208,
   kJniSlotSetIntArrayRegion = 211,
   kJniSlotSetDoubleArrayRegion = 214,
+  kJniSlotGetJavaVM = 219,
   kJniSlotExceptionCheck = 228,
   kJniSlotCount = 235  // JNI 9+: GetModule is 233, IsVirtualThread (21) is 234
 };
@@ -80,6 +88,24 @@ struct JNIEnv_ {
 };
 typedef struct JNIEnv_ JNIEnv;
 
+// The invocation interface: JavaVM is a pointer to a pointer to a table of eight slots (three reserved, DestroyJavaVM,
+// AttachCurrentThread, DetachCurrentThread, GetEnv, AttachCurrentThreadAsDaemon).
+enum {
+  kJvmSlotDetachCurrentThread = 5,
+  kJvmSlotGetEnv = 6,
+  kJvmSlotAttachCurrentThreadAsDaemon = 7,
+  kJvmSlotCount = 8
+};
+struct JNIInvokeInterface_ {
+  void* slot[kJvmSlotCount];
+};
+struct JavaVM_ {
+  const struct JNIInvokeInterface_* functions;
+};
+typedef struct JavaVM_ JavaVM;
+#define JNI_ERR (-1)
+#define JNI_EDETACHED (-2)
+
 }  // extern "C"
 
 namespace gkljni {
@@ -93,6 +119,15 @@ inline jint ThrowNew(JNIEnv* e, jclass c, const char* msg) {
   return fn<jint (*)(JNIEnv*, jclass, const char*)>(e, kJniSlotThrowNew)(e, c, msg);
 }
 inline void ExceptionClear(JNIEnv* e) { fn<void (*)(JNIEnv*)>(e, kJniSlotExceptionClear)(e); }
+inline jint PushLocalFrame(JNIEnv* e, jint capacity) { return fn<jint (*)(JNIEnv*, jint)>(e, kJniSlotPushLocalFrame)(e, capacity); }
+inline jobject PopLocalFrame(JNIEnv* e, jobject result) { return fn<jobject (*)(JNIEnv*, jobject)>(e, kJniSlotPopLocalFrame)(e, result); }
+inline jobject NewGlobalRef(JNIEnv* e, jobject o) { return fn<jobject (*)(JNIEnv*, jobject)>(e, kJniSlotNewGlobalRef)(e, o); }
+inline void DeleteGlobalRef(JNIEnv* e, jobject o) { fn<void (*)(JNIEnv*, jobject)>(e, kJniSlotDeleteGlobalRef)(e, o); }
+inline jint GetJavaVM(JNIEnv* e, JavaVM** vm) { return fn<jint (*)(JNIEnv*, JavaVM**)>(e, kJniSlotGetJavaVM)(e, vm); }
+inline jint AttachCurrentThreadAsDaemon(JavaVM* vm, JNIEnv** penv) {
+  return reinterpret_cast<jint (*)(JavaVM*, void**, void*)>(vm->functions->slot[kJvmSlotAttachCurrentThreadAsDaemon])(vm, reinterpret_cast<void**>(penv), nullptr);
+}
+inline jint DetachCurrentThread(JavaVM* vm) { return reinterpret_cast<jint (*)(JavaVM*)>(vm->functions->slot[kJvmSlotDetachCurrentThread])(vm); }
 inline jboolean ExceptionCheck(JNIEnv* e) { return fn<jboolean (*)(JNIEnv*)>(e, kJniSlotExceptionCheck)(e); }
 inline void DeleteLocalRef(JNIEnv* e, jobject o) { fn<void (*)(JNIEnv*, jobject)>(e, kJniSlotDeleteLocalRef)(e, o); }
 inline jfieldID GetFieldID(JNIEnv* e, jclass c, const char* name, const char* sig) {

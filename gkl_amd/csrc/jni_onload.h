@@ -12,14 +12,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#ifndef GKL_USE_SYSTEM_JNI
-extern "C" {
-struct JavaVM_;
-typedef struct JavaVM_ JavaVM;
-}
-#define JNI_ERR (-1)
-#endif
-
 extern "C" JNIEXPORT jint JNICALL JNI_OnLoad(JavaVM*, void*) {
   const char* force = getenv("GKL_HIP_LOAD_WITHOUT_DEVICE");
   if (force && *force == '1') return JNI_VERSION_1_8;

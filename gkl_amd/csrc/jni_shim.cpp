@@ -10,10 +10,19 @@
 //     the host-to-device copies are plain DMA, and every concurrent caller gets its own slot
 //     (context + stream + arenas, up to GKL_HIP_SLOTS, default 4): one Java thread marshals or
 //     finalises while another one's kernels run;
-//   * a BIG call is pipelined: the reads are marshalled range by range on the calling thread (the only one that may
-//     use its JNIEnv) while two engines of the slot compute the ranges already marshalled and the finished ranges
-//     are written back to the Java array -- the 250 000 JNI calls of a 10k-read batch then hide behind the kernels
-//     (the reference pins everything, computes, releases: JavaData.h:65-111, IntelPairHmm.cc:150-186);
+//   * a read costs 13 JNI calls (r05: 28): the holder, its five byte[] fields, ONE GetArrayLength (readBases), five
+//     GetByteArrayRegion and one ExceptionCheck -- a quality array shorter than readBases surfaces as the region copy's
+//     ArrayIndexOutOfBoundsException and becomes IllegalArgumentException -- inside PushLocalFrame / PopLocalFrame
+//     per block of 32 reads instead of six DeleteLocalRef per read;
+//   * a BIG call is pipelined: the reads are marshalled range by range while two engines of the slot compute the
+//     ranges already marshalled and the finished ranges are written back to the Java array -- the JNI calls of a
+//     10k-read batch then hide behind the kernels (the reference pins everything, computes, releases:
+//     JavaData.h:65-111, IntelPairHmm.cc:150-186).  With maxNumberOfThreads > 1 the ranges are marshalled by up to
+//     that many threads: helpers of the slot that attach to the JVM (JavaVM from GetJavaVM, AttachCurrentThreadAsDaemon)
+//     and read the holders through a global reference to readDataArray; Java exceptions are only ever raised on the
+//     calling thread;
+//   * a HIP failure inside a call is retried ONCE on fresh contexts (the reference never fails mid-run: it always has a
+//     CPU kernel, IntelPairHmm.cc:99-113) before it becomes a RuntimeException;
 //   * null holders / null byte[] fields / a too-short likelihood array raise
 //     IllegalArgumentException instead of crashing the JVM;
 //   * HIP failures raise java/lang/RuntimeException, allocation failures
@@ -27,6 +36,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -51,6 +61,13 @@ inline jsize GetArrayLength(JNIEnv* e, jarray a) { return e->GetArrayLength(a); 
 inline jobject GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) { return e->GetObjectArrayElement(a, i); }
 inline void GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize s, jsize l, jbyte* b) { e->GetByteArrayRegion(a, s, l, b); }
 inline void SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize s, jsize l, const jdouble* b) { e->SetDoubleArrayRegion(a, s, l, b); }
+inline jint PushLocalFrame(JNIEnv* e, jint capacity) { return e->PushLocalFrame(capacity); }
+inline jobject PopLocalFrame(JNIEnv* e, jobject result) { return e->PopLocalFrame(result); }
+inline jobject NewGlobalRef(JNIEnv* e, jobject o) { return e->NewGlobalRef(o); }
+inline void DeleteGlobalRef(JNIEnv* e, jobject o) { e->DeleteGlobalRef(o); }
+inline jint GetJavaVM(JNIEnv* e, JavaVM** vm) { return e->GetJavaVM(vm); }
+inline jint AttachCurrentThreadAsDaemon(JavaVM* vm, JNIEnv** penv) { return vm->AttachCurrentThreadAsDaemon(reinterpret_cast<void**>(penv), nullptr); }
+inline jint DetachCurrentThread(JavaVM* vm) { return vm->DetachCurrentThread(); }
 }  // namespace gkljni
 #endif
 
@@ -104,19 +121,21 @@ struct ReadArena {
 };
 
 // Pipelined big calls: a compute thread bound to one engine of the slot takes read ranges from `todo`, runs
-// gklhip_compute on them and reports on `done`.  The JNI side (marshalling, write-back, exceptions) stays on the
-// calling thread.
+// gklhip_compute on them and reports on `done`.  Write-back and exceptions stay on the calling thread; marshalling is
+// the calling thread's and, with maxNumberOfThreads > 1, the slot's helper threads' (MarshalHelpers below).
 struct RangeTask {
   int k = 0;
   gklhip_batch batch;
   double* out = nullptr;
   int status = GKLHIP_OK;
+  bool computed = false;   // gklhip_compute returned GKLHIP_OK for it
   std::string error;
 };
 struct Pipeline {
   std::mutex mu;
   std::condition_variable has_todo, has_done;
   std::deque<RangeTask*> todo, done;
+  int marshalling = 0;   // helper threads still inside the current call's marshalling job (take_done's other wake-up reason)
   bool quit = false;
   std::vector<std::thread> threads;
   void start(gklhip_ctx* ctx) {
@@ -131,6 +150,7 @@ struct Pipeline {
         // (gklhip_compute itself lets no exception out; the string below can still fail to allocate)
         try {
           t->status = gklhip_compute(ctx, &t->batch, t->out);
+          t->computed = t->status == GKLHIP_OK;
           if (t->status != GKLHIP_OK) { const char* d = gklhip_last_error(); t->error = d ? d : ""; }  // (thread-local detail)
         } catch (...) {
           t->status = GKLHIP_ERR_OOM;
@@ -145,9 +165,10 @@ struct Pipeline {
     { std::lock_guard<std::mutex> l(mu); todo.push_back(t); }
     has_todo.notify_one();
   }
+  // a finished range; with wait: blocks until there is one, or -- NULL -- until no helper is marshalling any more
   RangeTask* take_done(bool wait) {
     std::unique_lock<std::mutex> l(mu);
-    if (wait) has_done.wait(l, [&] { return !done.empty(); });
+    if (wait) has_done.wait(l, [&] { return !done.empty() || marshalling == 0; });
     if (done.empty()) return nullptr;
     RangeTask* t = done.front();
     done.pop_front();
@@ -160,11 +181,66 @@ struct Pipeline {
   }
 };
 
+// Helper threads of a slot that marshal read ranges beside the calling thread (maxNumberOfThreads > 1).  A thread the
+// library starts has no JNIEnv: it attaches to the JVM once (as a daemon: it never keeps the JVM alive), keeps its env
+// for the life of the slot and detaches when the slot goes (doneNative, a re-configuration, process exit).  What it may
+// touch: GLOBAL references only (the calling thread's jobjectArray is a local reference of THAT thread).
+struct MarshalHelpers {
+  JavaVM* vm = nullptr;
+  std::mutex mu;
+  std::condition_variable wake, reported;
+  std::function<void(JNIEnv*)> job;   // what a helper that takes a ticket runs once
+  int tickets = 0;                    // helpers the current job still wants
+  int started = 0, live = 0;          // threads that have reported in / that hold a JNIEnv
+  bool quit = false;
+  std::vector<std::thread> threads;
+  explicit MarshalHelpers(JavaVM* v) : vm(v) {}
+  // at least n helper threads, if the JVM lets them attach; returns how many are usable
+  int ensure(int n) {
+    while ((int)threads.size() < n) {
+      threads.emplace_back([this] {
+        JNIEnv* env = nullptr;
+        const bool ok = gkljni::AttachCurrentThreadAsDaemon(vm, &env) == JNI_OK && env;
+        std::unique_lock<std::mutex> l(mu);
+        started++;
+        if (ok) live++;
+        reported.notify_all();
+        if (!ok) return;   // (jobs simply run with fewer threads)
+        for (;;) {
+          wake.wait(l, [&] { return quit || tickets > 0; });
+          if (quit) break;
+          tickets--;
+          auto fn = job;
+          l.unlock();
+          fn(env);
+          l.lock();
+        }
+        live--;
+        l.unlock();
+        gkljni::DetachCurrentThread(vm);
+      });
+    }
+    std::unique_lock<std::mutex> l(mu);
+    reported.wait(l, [&] { return started == (int)threads.size(); });
+    return live;
+  }
+  void run(int n, std::function<void(JNIEnv*)>&& fn) noexcept {   // n <= ensure()'s answer helpers run fn once each; returns at once
+    { std::lock_guard<std::mutex> l(mu); job = std::move(fn); tickets = n; }
+    wake.notify_all();
+  }
+  ~MarshalHelpers() {
+    { std::lock_guard<std::mutex> l(mu); quit = true; }
+    wake.notify_all();
+    for (auto& th : threads) th.join();
+  }
+};
+
 // Everything one call needs; a slot serves one caller at a time.
 struct Slot {
   gklhip_ctx* ctx = nullptr;
   gklhip_ctx* ctx2 = nullptr;          // second engine of pipelined big calls (created by the first of them)
   std::unique_ptr<Pipeline> pipe;      // declared after the contexts: its threads are joined before they go
+  std::unique_ptr<MarshalHelpers> helpers;
   PinnedBytes hap_bases;
   std::vector<int64_t> hap_off;
   ReadArena whole;                     // a small call's reads
@@ -176,6 +252,7 @@ struct Slot {
   int gen = 0;  // configuration generation (initNative with other arguments starts a new one)
   gklhip_config cfg;  // what `ctx` was created with: the second engine of a pipelined call gets the same
   ~Slot() {
+    helpers.reset();
     pipe.reset();
     if (ctx2) gklhip_done(ctx2);
     if (ctx) gklhip_done(ctx);
@@ -186,12 +263,19 @@ struct Slot {
 // [0] marshalling on the calling thread, [1] waiting for compute that marshalling did not cover (a small call: the
 // whole gklhip_compute), [2] write-back into the Java array, [3] whole calls, [4] number of calls, [5] pipelined calls.
 std::atomic<int64_t> g_timing[6];
+// gkl_pairhmm_jni_helpers: [0] ns of marshalling on helper threads, [1] read ranges marshalled by helpers, [2] by
+// calling threads, [3] calls retried after a HIP failure
+std::atomic<int64_t> g_helpers[4];
 int64_t now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // Process-wide state, like the reference's globals (IntelPairHmm.cc:41-48) and the
 // static field IDs of JavaData (JavaData.h:160-176).
+struct FieldIds {
+  jfieldID readBases = nullptr, readQuals = nullptr, insertionGOP = nullptr, deletionGOP = nullptr,
+           overallGCP = nullptr, haplotypeBases = nullptr;
+};
 struct State {
   std::mutex mu;
   std::condition_variable slot_free;
@@ -201,8 +285,8 @@ struct State {
   bool ready = false;  // initNative has run: configuration and field IDs are valid (stays true after doneNative)
   int gen = 0;         // current configuration generation; slots of older generations die when they come back
   gklhip_config cfg;
-  jfieldID readBases = nullptr, readQuals = nullptr, insertionGOP = nullptr, deletionGOP = nullptr,
-           overallGCP = nullptr, haplotypeBases = nullptr;
+  FieldIds f;
+  JavaVM* vm = nullptr;   // from initNative's GetJavaVM: what helper threads attach to
 } g;
 
 void throw_java(JNIEnv* env, const char* class_path, const char* msg) {
@@ -211,51 +295,107 @@ void throw_java(JNIEnv* env, const char* class_path, const char* msg) {
   if (c) gkljni::ThrowNew(env, c, msg);
 }
 
-void throw_status(JNIEnv* env, int status) {
-  const char* detail = gklhip_last_error();
+void throw_status_text(JNIEnv* env, int status, const char* detail) {
   char msg[600];
   snprintf(msg, sizeof msg, "GKL-HIP PairHMM: %s%s%s", gklhip_strerror(status),
            (detail && *detail) ? ": " : "", (detail && *detail) ? detail : "");
   const char* cls = status == GKLHIP_ERR_INVALID_ARG ? kIAE : status == GKLHIP_ERR_OOM ? kOOM : kRTE;
   throw_java(env, cls, msg);
 }
+void throw_status(JNIEnv* env, int status) { throw_status_text(env, status, gklhip_last_error()); }
 
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// Append holder.<field> (a byte[]) to dst; returns its length, or -1 after throwing.
-long append_field(JNIEnv* env, jobject holder, jfieldID fid, PinnedBytes& dst, long expect_at_least) {
-  jbyteArray bytes = (jbyteArray)gkljni::GetObjectField(env, holder, fid);
-  if (!bytes) {
-    throw_java(env, kIAE, "null byte[] field in data holder");
-    return -1;
+// Marshalling errors travel as (class, message): a helper thread must not raise them on ITS JNIEnv -- nobody would see
+// them -- so every marshalling function reports, and the calling thread throws.
+struct MarshalError {
+  const char* cls = nullptr;   // nullptr = fine
+  const char* msg = nullptr;
+  explicit operator bool() const { return cls != nullptr; }
+};
+
+constexpr jsize kFrameReads = 32;   // reads per local frame: 6 references each
+
+// PushLocalFrame / PopLocalFrame around a block (also when a C++ exception -- an arena that cannot grow -- passes through)
+struct LocalFrame {
+  JNIEnv* env;
+  bool pushed;
+  LocalFrame(JNIEnv* e, jint capacity) : env(e), pushed(gkljni::PushLocalFrame(e, capacity) == 0) {
+    if (!pushed) gkljni::ExceptionClear(env);   // (PushLocalFrame raised OutOfMemoryError)
   }
-  const jsize len = gkljni::GetArrayLength(env, bytes);
-  long take = len;
-  if (expect_at_least >= 0) {
-    // JavaData.h:86-91: the read length is readBases.length; the other four arrays are read
-    // for that many bytes. A shorter array is an error here (the reference reads past it).
-    if (len < expect_at_least) {
-      gkljni::DeleteLocalRef(env, bytes);
-      throw_java(env, kIAE, "read quality array shorter than readBases");
-      return -1;
+  ~LocalFrame() { if (pushed) gkljni::PopLocalFrame(env, nullptr); }
+  LocalFrame(const LocalFrame&) = delete;
+};
+
+// Reads [r0, r1) of `reads` (a reference valid on THIS thread) into `a`, offsets rebased to 0.  Per read: the holder,
+// its five fields, readBases' length, five region copies, one ExceptionCheck = 13 JNI calls (JavaData.h:84-105 pins
+// five arrays per read and keeps them until the call returns).  JavaData.h:86-91: the read length is readBases.length
+// and the other four arrays are read for that many bytes; a shorter one is an error here (the reference reads past it)
+// -- it shows as the region copy's ArrayIndexOutOfBoundsException, which is cleared and reported as IllegalArgumentException.
+MarshalError marshal_reads(JNIEnv* env, jobjectArray reads, const FieldIds& f, ReadArena& a, jsize r0, jsize r1) {
+  a.clear();
+  a.read_off.assign((size_t)(r1 - r0) + 1, 0);
+  for (jsize b0 = r0; b0 < r1; b0 += kFrameReads) {
+    const jsize b1 = std::min<jsize>(r1, b0 + kFrameReads);
+    LocalFrame frame(env, 6 * kFrameReads);
+    if (!frame.pushed) return {kOOM, "Unable to allocate a local reference frame"};
+    MarshalError err;
+    for (jsize r = b0; r < b1; r++) {
+      jobject holder = gkljni::GetObjectArrayElement(env, reads, r);
+      if (!holder) { err = {kIAE, "null element in data holder array"}; break; }
+      jbyteArray bases = (jbyteArray)gkljni::GetObjectField(env, holder, f.readBases);
+      jbyteArray ins = (jbyteArray)gkljni::GetObjectField(env, holder, f.insertionGOP);
+      jbyteArray del = (jbyteArray)gkljni::GetObjectField(env, holder, f.deletionGOP);
+      jbyteArray gcp = (jbyteArray)gkljni::GetObjectField(env, holder, f.overallGCP);
+      jbyteArray quals = (jbyteArray)gkljni::GetObjectField(env, holder, f.readQuals);
+      if (!bases || !ins || !del || !gcp || !quals) { err = {kIAE, "null byte[] field in data holder"}; break; }
+      const jsize len = gkljni::GetArrayLength(env, bases);
+      const size_t n = (size_t)len;
+      // (space for all five first: a failed allocation must not leave a region copy half-way)
+      jbyte* dst[5] = {reinterpret_cast<jbyte*>(a.read_bases.grow(n)), reinterpret_cast<jbyte*>(a.ins.grow(n)),
+                       reinterpret_cast<jbyte*>(a.del.grow(n)), reinterpret_cast<jbyte*>(a.gcp.grow(n)),
+                       reinterpret_cast<jbyte*>(a.read_quals.grow(n))};
+      gkljni::GetByteArrayRegion(env, bases, 0, len, dst[0]);
+      gkljni::GetByteArrayRegion(env, ins, 0, len, dst[1]);
+      gkljni::GetByteArrayRegion(env, del, 0, len, dst[2]);
+      gkljni::GetByteArrayRegion(env, gcp, 0, len, dst[3]);
+      gkljni::GetByteArrayRegion(env, quals, 0, len, dst[4]);
+      if (gkljni::ExceptionCheck(env)) {
+        gkljni::ExceptionClear(env);
+        err = {kIAE, "read quality array shorter than readBases"};
+        break;
+      }
+      a.read_off[(size_t)(r - r0) + 1] = a.read_off[(size_t)(r - r0)] + len;
     }
-    take = expect_at_least;
+    if (err) return err;
   }
-  if (take > 0) gkljni::GetByteArrayRegion(env, bytes, 0, (jsize)take, reinterpret_cast<jbyte*>(dst.grow((size_t)take)));
-  gkljni::DeleteLocalRef(env, bytes);
-  if (gkljni::ExceptionCheck(env)) return -1;
-  return take;
+  return {};
 }
 
-// holder = arr[i], or NULL after throwing.
-jobject holder_at(JNIEnv* env, jobjectArray arr, jsize i) {
-  jobject holder = gkljni::GetObjectArrayElement(env, arr, i);
-  if (gkljni::ExceptionCheck(env)) return nullptr;
-  if (!holder) throw_java(env, kIAE, "null element in data holder array");
-  return holder;
+// The haplotypes: four JNI calls each, one frame per block.
+MarshalError marshal_haps(JNIEnv* env, jobjectArray haps, const FieldIds& f, PinnedBytes& bytes, std::vector<int64_t>& off, jsize n_haps) {
+  bytes.clear();
+  off.assign((size_t)n_haps + 1, 0);
+  for (jsize b0 = 0; b0 < n_haps; b0 += 3 * kFrameReads) {
+    const jsize b1 = std::min<jsize>(n_haps, b0 + 3 * kFrameReads);
+    LocalFrame frame(env, 6 * kFrameReads);
+    if (!frame.pushed) return {kOOM, "Unable to allocate a local reference frame"};
+    MarshalError err;
+    for (jsize h = b0; h < b1; h++) {
+      jobject holder = gkljni::GetObjectArrayElement(env, haps, h);
+      if (!holder) { err = {kIAE, "null element in data holder array"}; break; }
+      jbyteArray bases = (jbyteArray)gkljni::GetObjectField(env, holder, f.haplotypeBases);
+      if (!bases) { err = {kIAE, "null byte[] field in data holder"}; break; }
+      const jsize len = gkljni::GetArrayLength(env, bases);
+      if (len > 0) gkljni::GetByteArrayRegion(env, bases, 0, len, reinterpret_cast<jbyte*>(bytes.grow((size_t)len)));
+      off[(size_t)h + 1] = off[(size_t)h] + len;
+    }
+    if (err) return err;
+  }
+  return {};
 }
 
 // A free slot of the current configuration, creating one (context + stream) while fewer than max_slots exist;
@@ -321,6 +461,27 @@ struct SlotLease {
   }
 };
 
+// A HIP failure inside a call (GKLHIP_ERR_HIP: a launch or copy that failed, a stream in an error state): the slot
+// drops its engines -- both contexts and the compute threads bound to them -- and makes a fresh first one.  The
+// reference cannot fail mid-run; a GATK job of hours should not die of one transient device error either.  False when
+// no new context can be had (the caller then throws the original error).
+bool renew_engines(Slot* sl, int status, const char* detail) {
+  fprintf(stderr, "GKL-HIP PairHMM: %s%s%s -- retrying the call once on a fresh device context\n", gklhip_strerror(status),
+          (detail && *detail) ? ": " : "", (detail && *detail) ? detail : "");
+  sl->pipe.reset();
+  if (sl->ctx2) { gklhip_done(sl->ctx2); sl->ctx2 = nullptr; }
+  if (sl->ctx) { gklhip_done(sl->ctx); sl->ctx = nullptr; }
+  g_helpers[3]++;
+  if (gklhip_init(&sl->cfg, &sl->ctx) != GKLHIP_OK) {
+    sl->ctx = nullptr;
+    // the slot has no engine any more: it must not be leased again
+    std::lock_guard<std::mutex> lock(g.mu);
+    sl->gen = -1;
+    return false;
+  }
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -330,9 +491,9 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
     jint max_threads) {
   std::unique_lock<std::mutex> lock(g.mu);
   struct { jfieldID* dst; jclass cls; const char* name; } fields[] = {
-      {&g.readBases, readDataHolder, "readBases"},       {&g.readQuals, readDataHolder, "readQuals"},
-      {&g.insertionGOP, readDataHolder, "insertionGOP"}, {&g.deletionGOP, readDataHolder, "deletionGOP"},
-      {&g.overallGCP, readDataHolder, "overallGCP"},     {&g.haplotypeBases, haplotypeDataHolder, "haplotypeBases"}};
+      {&g.f.readBases, readDataHolder, "readBases"},       {&g.f.readQuals, readDataHolder, "readQuals"},
+      {&g.f.insertionGOP, readDataHolder, "insertionGOP"}, {&g.f.deletionGOP, readDataHolder, "deletionGOP"},
+      {&g.f.overallGCP, readDataHolder, "overallGCP"},     {&g.f.haplotypeBases, haplotypeDataHolder, "haplotypeBases"}};
   for (auto& f : fields) {
     jfieldID id = f.cls ? gkljni::GetFieldID(env, f.cls, f.name, "[B") : nullptr;
     if (!id) {  // JavaData.h:127-133
@@ -341,6 +502,11 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
       return;
     }
     *f.dst = id;
+  }
+  {
+    JavaVM* vm = nullptr;   // for the marshalling helpers of big calls; without it they are simply not used
+    if (gkljni::GetJavaVM(env, &vm) == JNI_OK && vm) g.vm = vm;
+    else gkljni::ExceptionClear(env);
   }
   // The reference's initNative only re-sets globals (IntelPairHmm.cc:70-116) and other threads may be inside
   // computeLikelihoodsNative right now: nothing is torn down here.  Same arguments: nothing to do.  Other
@@ -393,7 +559,12 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
   Slot* sl = lease.s;
   if (!sl) return;
   const int64_t t_call = now_ns();
+  jobject reads_global = nullptr;   // for the helper threads of this call; deleted on every way out
+  struct GlobalGuard { JNIEnv* env; jobject* ref; ~GlobalGuard() { if (*ref) gkljni::DeleteGlobalRef(env, *ref); } } global_guard{env, &reads_global};
   try {
+    FieldIds fid;
+    JavaVM* vm;
+    { std::lock_guard<std::mutex> lock(g.mu); fid = g.f; vm = g.vm; }
     const jsize n_reads = gkljni::GetArrayLength(env, readDataArray);
     const jsize n_haps = gkljni::GetArrayLength(env, haplotypeDataArray);
     const int64_t n_pairs = (int64_t)n_reads * n_haps;
@@ -402,34 +573,7 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
       throw_java(env, kIAE, "likelihood array shorter than reads x haplotypes");
       return;
     }
-    sl->hap_bases.clear();
-    sl->hap_off.assign((size_t)n_haps + 1, 0);
-    for (jsize h = 0; h < n_haps; h++) {
-      jobject holder = holder_at(env, haplotypeDataArray, h);
-      if (!holder) return;
-      const long len = append_field(env, holder, g.haplotypeBases, sl->hap_bases, -1);
-      gkljni::DeleteLocalRef(env, holder);
-      if (len < 0) return;
-      sl->hap_off[h + 1] = sl->hap_off[h] + len;
-    }
-    // reads [r0, r1) into `a` (offsets rebased to 0); false after throwing
-    auto marshal_reads = [&](ReadArena& a, jsize r0, jsize r1) -> bool {
-      a.clear();
-      a.read_off.assign((size_t)(r1 - r0) + 1, 0);
-      for (jsize r = r0; r < r1; r++) {
-        jobject holder = holder_at(env, readDataArray, r);
-        if (!holder) return false;
-        const long len = append_field(env, holder, g.readBases, a.read_bases, -1);
-        const bool ok = len >= 0 && append_field(env, holder, g.insertionGOP, a.ins, len) >= 0 &&
-                        append_field(env, holder, g.deletionGOP, a.del, len) >= 0 &&
-                        append_field(env, holder, g.overallGCP, a.gcp, len) >= 0 &&
-                        append_field(env, holder, g.readQuals, a.read_quals, len) >= 0;
-        gkljni::DeleteLocalRef(env, holder);
-        if (!ok) return false;
-        a.read_off[(size_t)(r - r0) + 1] = a.read_off[(size_t)(r - r0)] + len;
-      }
-      return true;
-    };
+    if (MarshalError e = marshal_haps(env, haplotypeDataArray, fid, sl->hap_bases, sl->hap_off, n_haps)) { throw_java(env, e.cls, e.msg); return; }
     auto batch_of = [&](const ReadArena& a, int32_t n) {
       gklhip_batch b;
       b.n_reads = n; b.n_haps = n_haps;
@@ -462,12 +606,18 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
         sl->ranges.shrink_to_fit();
         if (sl->out.capacity() * sizeof(double) > ((size_t)32 << 20)) std::vector<double>().swap(sl->out);
       }
-      if (!marshal_reads(sl->whole, 0, n_reads)) return;
+      if (MarshalError e = marshal_reads(env, readDataArray, fid, sl->whole, 0, n_reads)) { throw_java(env, e.cls, e.msg); return; }
       const int64_t t_m = now_ns();
       if (n_pairs == 0) return;
       const gklhip_batch b = batch_of(sl->whole, n_reads);
       sl->out.resize((size_t)n_pairs);
-      const int st = gklhip_compute(sl->ctx, &b, sl->out.data());
+      int st = gklhip_compute(sl->ctx, &b, sl->out.data());
+      if (st == GKLHIP_ERR_HIP) {
+        const char* d = gklhip_last_error();
+        const std::string detail = d ? d : "";
+        if (!renew_engines(sl, st, detail.c_str())) { throw_status_text(env, st, detail.c_str()); return; }
+        st = gklhip_compute(sl->ctx, &b, sl->out.data());
+      }
       const int64_t t_c = now_ns();
       if (st != GKLHIP_OK) { throw_status(env, st); return; }
       gkljni::SetDoubleArrayRegion(env, likelihoodArray, 0, (jsize)n_pairs, sl->out.data());
@@ -475,20 +625,32 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
       g_timing[0] += t_m - t_call; g_timing[1] += t_c - t_m; g_timing[2] += t_w - t_c; g_timing[3] += t_w - t_call; g_timing[4]++;
       return;
     }
-    // ---- pipelined: read ranges of ~150k pairs (100k..320k measure the same); range k+1 is marshalled while the ranges before it compute on the
-    // slot's two engines, finished ranges go back to the Java array in between ----
+    // ---- pipelined: read ranges; range k+1 is marshalled while the ranges before it compute on the slot's two engines,
+    // finished ranges go back to the Java array in between ----
+    // Range boundaries: the first range is small (its marshalling is the only part nothing overlaps with), the later ones
+    // grow geometrically (marshalling outruns compute, and bigger ranges use the chip better: a range of 150k pairs takes
+    // 1.6-1.8 ms where an eighth of the whole batch's time would be 1.45), the last ones shrink again (what follows the
+    // last kernel -- the fp64 pairs' log10 on the host, the write-back -- is proportional to the last range):
+    // sizes first * g^k, capped so that the remaining reads end in a descending tail.
     const char* rv = getenv("GKL_HIP_JNI_RANGE_PAIRS");
     const int64_t range_pairs = rv && atoll(rv) > 0 ? atoll(rv) : 150000LL;
-    // Range boundaries: the first range is small (its marshalling is the only part nothing overlaps with), the later ones
-    // grow geometrically (marshalling outruns compute, and bigger ranges use the chip better): sizes range_pairs * g^k.
     const char* gv = getenv("GKL_HIP_JNI_RANGE_GROWTH");
     const double growth = gv && atof(gv) >= 1.0 ? atof(gv) : 1.0;
+    const char* lv = getenv("GKL_HIP_JNI_RANGE_LAST");
+    const int64_t last_pairs = lv && atoll(lv) > 0 ? atoll(lv) : 0;   // 0: no descending tail
     std::vector<jsize> cut{0};
     {
       double want = (double)range_pairs / (double)n_haps;   // reads in the next range
+      const double last = (double)last_pairs / (double)n_haps;
       double at = 0;
       while ((jsize)at < n_reads && cut.size() < 33) {
-        at += std::max(1.0, want);
+        double take = std::max(1.0, want);
+        if (last > 0) {
+          // never more than half of what is left beyond one `last`-sized range: the sizes come down by halves to `last`
+          const double left = (double)n_reads - at;
+          if (left > 2.0 * last) take = std::min(take, std::max(last, (left - last) / 2.0));
+        }
+        at += take;
         cut.push_back((jsize)std::min<double>(at, n_reads));
         want *= growth;
       }
@@ -502,47 +664,143 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     while ((int)sl->ranges.size() < n_ranges) sl->ranges.emplace_back(new ReadArena());
     sl->tasks.assign((size_t)n_ranges, RangeTask());
     sl->out.resize((size_t)n_pairs);
+    for (int k = 0; k < n_ranges; k++) {
+      sl->tasks[(size_t)k].k = k;
+      sl->tasks[(size_t)k].out = sl->out.data() + (int64_t)cut[(size_t)k] * n_haps;
+    }
+    // helper threads (maxNumberOfThreads - 1 of them, at most 7 and one per range beyond the first): attached to the JVM,
+    // reading the holders through a global reference
+    int n_helpers = 0;
+    {
+      const char* hv = getenv("GKL_HIP_JNI_MARSHAL_THREADS");
+      const int threads = hv && *hv ? atoi(hv) : sl->cfg.max_threads;
+      n_helpers = std::max(0, std::min({threads - 1, 7, n_ranges - 1}));
+      if (n_helpers > 0 && vm) {
+        try {
+          if (!sl->helpers || sl->helpers->vm != vm) sl->helpers.reset(new MarshalHelpers(vm));
+          n_helpers = std::min(n_helpers, sl->helpers->ensure(n_helpers));
+          if (n_helpers > 0) reads_global = gkljni::NewGlobalRef(env, readDataArray);
+        } catch (const std::exception&) { n_helpers = 0; }   // (no thread to be had: the calling thread marshals alone)
+      }
+      if (!reads_global || !sl->helpers) n_helpers = 0;
+    }
+    // shared by the marshalling threads of this call
+    struct Job {
+      std::atomic<int> next{0};
+      std::atomic<bool> stop{false};
+      std::mutex mu;
+      MarshalError error;             // first marshalling error
+      std::string exception_what;     // a C++ exception on a helper (bad_alloc of an arena)
+    } job;
+    auto marshal_range = [&](JNIEnv* e, jobjectArray arr, int k) -> bool {
+      const jsize r0 = cut[(size_t)k], r1 = cut[(size_t)k + 1];
+      MarshalError err = marshal_reads(e, arr, fid, *sl->ranges[(size_t)k], r0, r1);
+      if (err) {
+        std::lock_guard<std::mutex> l(job.mu);
+        if (!job.error) job.error = err;
+        job.stop = true;
+        return false;
+      }
+      RangeTask& t = sl->tasks[(size_t)k];
+      t.batch = batch_of(*sl->ranges[(size_t)k], r1 - r0);
+      sl->pipe->submit(&t);
+      return true;
+    };
+    std::atomic<int> submitted{0};
+    if (n_helpers > 0) {
+      std::function<void(JNIEnv*)> helper_job = [&, arr = (jobjectArray)reads_global](JNIEnv* e) {
+        const int64_t t0 = now_ns();
+        try {
+          for (;;) {
+            if (job.stop) break;
+            const int k = job.next.fetch_add(1);
+            if (k >= n_ranges) break;
+            if (!marshal_range(e, arr, k)) break;
+            submitted++;
+            g_helpers[1]++;
+          }
+        } catch (const std::exception& ex) {
+          std::lock_guard<std::mutex> l(job.mu);
+          if (job.exception_what.empty()) job.exception_what = ex.what();
+          job.stop = true;
+        }
+        g_helpers[0] += now_ns() - t0;
+        { std::lock_guard<std::mutex> l(sl->pipe->mu); sl->pipe->marshalling--; }
+        sl->pipe->has_done.notify_all();
+      };
+      { std::lock_guard<std::mutex> l(sl->pipe->mu); sl->pipe->marshalling = n_helpers; }
+      sl->helpers->run(n_helpers, std::move(helper_job));   // (from here on the helpers use this frame's variables: see the wait below)
+    }
     int64_t ns_marshal = now_ns() - t_call, ns_wait = 0, ns_write = 0;
-    int submitted = 0, finished = 0, failed_status = GKLHIP_OK;
+    int finished = 0, failed_status = GKLHIP_OK;
     std::string failed_detail;
     bool java_exception = false;
     auto retire = [&](RangeTask* t) {   // a finished range: write it back (calling thread), or remember its error
       finished++;
-      if (t->status != GKLHIP_OK) { if (failed_status == GKLHIP_OK) { failed_status = t->status; failed_detail = t->error; } return; }
+      if (t->status != GKLHIP_OK) {
+        if (failed_status == GKLHIP_OK) { failed_status = t->status; failed_detail = t->error; }
+        if (t->status != GKLHIP_ERR_HIP) job.stop = true;   // (a HIP failure: the ranges are still wanted -- the call is retried from them)
+        return;
+      }
       if (java_exception || failed_status != GKLHIP_OK) return;
       const int64_t t0 = now_ns();
       const int64_t at = t->out - sl->out.data();
       gkljni::SetDoubleArrayRegion(env, likelihoodArray, (jsize)at, (jsize)((int64_t)t->batch.n_reads * n_haps), t->out);
-      if (gkljni::ExceptionCheck(env)) java_exception = true;
+      if (gkljni::ExceptionCheck(env)) { java_exception = true; job.stop = true; }
       ns_write += now_ns() - t0;
     };
-    for (int k = 0; k < n_ranges && !java_exception && failed_status == GKLHIP_OK; k++) {
-      const jsize r0 = cut[(size_t)k], r1 = cut[(size_t)k + 1];
-      const int64_t t0 = now_ns();
-      if (!marshal_reads(*sl->ranges[(size_t)k], r0, r1)) { java_exception = true; break; }
-      ns_marshal += now_ns() - t0;
-      RangeTask& t = sl->tasks[(size_t)k];
-      t.k = k;
-      t.batch = batch_of(*sl->ranges[(size_t)k], r1 - r0);
-      t.out = sl->out.data() + (int64_t)r0 * n_haps;
-      sl->pipe->submit(&t);
-      submitted++;
-      while (RangeTask* d = sl->pipe->take_done(false)) retire(d);
+    // Whatever happens below, helpers may be marshalling into this call's arenas and ranges in flight read them: nothing
+    // leaves this block before the helpers are out of the job and every submitted range has come back.
+    std::exception_ptr pending_cxx;
+    try {
+      for (;;) {
+        if (job.stop) break;
+        const int k = job.next.fetch_add(1);
+        if (k >= n_ranges) break;
+        const int64_t t0 = now_ns();
+        const bool ok = marshal_range(env, readDataArray, k);
+        ns_marshal += now_ns() - t0;
+        if (!ok) break;
+        submitted++;
+        g_helpers[2]++;
+        while (RangeTask* d = sl->pipe->take_done(false)) retire(d);
+      }
+    } catch (...) {
+      pending_cxx = std::current_exception();
+      job.stop = true;
     }
-    // whatever happened, the ranges in flight read this call's arenas: wait for all of them
-    while (finished < submitted) {
+    for (;;) {
       const int64_t t0 = now_ns();
-      RangeTask* d = sl->pipe->take_done(true);
+      RangeTask* d = sl->pipe->take_done(true);   // NULL: no helper is marshalling any more and nothing is finished right now
       ns_wait += now_ns() - t0;
-      retire(d);
+      if (d) { try { retire(d); } catch (...) { if (!pending_cxx) pending_cxx = std::current_exception(); finished++; } continue; }
+      if (finished >= submitted.load()) break;
+      // (helpers are done, ranges are still computing: wait for one)
+      const int64_t t1 = now_ns();
+      {
+        std::unique_lock<std::mutex> l(sl->pipe->mu);
+        sl->pipe->has_done.wait(l, [&] { return !sl->pipe->done.empty(); });
+      }
+      ns_wait += now_ns() - t1;
     }
+    if (pending_cxx) std::rethrow_exception(pending_cxx);
     if (java_exception) return;
-    if (failed_status != GKLHIP_OK) {
-      char msg[600];
-      snprintf(msg, sizeof msg, "GKL-HIP PairHMM: %s%s%s", gklhip_strerror(failed_status), failed_detail.empty() ? "" : ": ", failed_detail.c_str());
-      throw_java(env, failed_status == GKLHIP_ERR_INVALID_ARG ? kIAE : failed_status == GKLHIP_ERR_OOM ? kOOM : kRTE, msg);
-      return;
+    if (job.error) { throw_java(env, job.error.cls, job.error.msg); return; }
+    if (!job.exception_what.empty()) { throw_java(env, kOOM, "Unable to allocate the PairHMM batch"); return; }
+    if (failed_status == GKLHIP_ERR_HIP) {
+      // every range is marshalled (a HIP failure does not stop the marshalling): fresh engines, and the ranges that did
+      // not come back good are computed again, one after the other on the calling thread
+      if (job.next.load() < n_ranges || !renew_engines(sl, failed_status, failed_detail.c_str())) { throw_status_text(env, failed_status, failed_detail.c_str()); return; }
+      for (int k = 0; k < n_ranges; k++) {
+        RangeTask& t = sl->tasks[(size_t)k];
+        const int st = t.computed ? GKLHIP_OK : gklhip_compute(sl->ctx, &t.batch, t.out);
+        if (st != GKLHIP_OK) { throw_status(env, st); return; }
+        gkljni::SetDoubleArrayRegion(env, likelihoodArray, (jsize)(t.out - sl->out.data()), (jsize)((int64_t)t.batch.n_reads * n_haps), t.out);
+        if (gkljni::ExceptionCheck(env)) return;
+      }
+      failed_status = GKLHIP_OK;
     }
+    if (failed_status != GKLHIP_OK) { throw_status_text(env, failed_status, failed_detail.c_str()); return; }
     g_timing[0] += ns_marshal; g_timing[1] += ns_wait; g_timing[2] += ns_write; g_timing[3] += now_ns() - t_call; g_timing[4]++; g_timing[5]++;
   } catch (const std::bad_alloc&) {
     throw_java(env, kOOM, "Unable to allocate the PairHMM batch");
@@ -557,11 +815,15 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
 __attribute__((visibility("default"))) void gkl_pairhmm_jni_timing(int64_t out[6], int reset) {
   for (int i = 0; i < 6; i++) { out[i] = g_timing[i].load(); if (reset) g_timing[i].store(0); }
 }
+// ... and what the marshalling helpers did -- see g_helpers.
+__attribute__((visibility("default"))) void gkl_pairhmm_jni_helpers(int64_t out[4], int reset) {
+  for (int i = 0; i < 4; i++) { out[i] = g_helpers[i].load(); if (reset) g_helpers[i].store(0); }
+}
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv*, jobject) {
   // The reference's doneNative is empty (IntelPairHmm.cc:189-192): other IntelPairHmm instances of the JVM keep
-  // working after one of them closes.  Here it releases what no call is using (device memory, pinned arenas) and
-  // keeps the configuration, so a later call simply gets a fresh slot.
+  // working after one of them closes.  Here it releases what no call is using (device memory, pinned arenas, the
+  // helper threads -- they detach from the JVM) and keeps the configuration, so a later call simply gets a fresh slot.
   std::vector<std::unique_ptr<Slot>> dead;   // destroyed (streams synchronised, buffers freed) after the lock is released
   {
     std::lock_guard<std::mutex> lock(g.mu);

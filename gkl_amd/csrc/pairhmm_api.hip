@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <functional>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -1964,7 +1965,10 @@ static int init_devices_impl(const gklhip_config* cfg, const int32_t* devices, i
   return GKLHIP_OK;
 }
 
+int gklhip_fault_inject(const char* spec);
 static int init_impl(const gklhip_config* cfg, gklhip_ctx** out_ctx) {
+  static std::once_flag fault_env;
+  std::call_once(fault_env, [] { if (const char* v = getenv("GKLHIP_FAULT_INJECT")) (void)gklhip_fault_inject(v); });
   // GKL_HIP_DEVICES=0,1,...: shard every call over these devices (used when the config does not pin one)
   std::vector<int32_t> list;
   if (!cfg || cfg->device < 0) {
@@ -2059,6 +2063,30 @@ static int compute_device_impl(gklhip_ctx* c, const gklhip_batch* dev_batch, dou
   return multi_compute_device(c, set, dev_batch, out_dev, mode, s);
 }
 
+// Fault injection (tests of the callers' error handling; nothing in the reference): "compute:N" or "compute:NxK" makes
+// the N-th .. (N+K-1)-th gklhip_compute of the process -- counted from the arming -- return GKLHIP_ERR_HIP before any
+// work, with the output array poisoned.  Armed by gklhip_fault_inject(), or once from GKLHIP_FAULT_INJECT by the first
+// gklhip_init of the process (read there, never on a call path).
+static std::atomic<int64_t> g_fault_from{0}, g_fault_count{0}, g_fault_calls{0};
+int gklhip_fault_inject(const char* spec) {
+  long from = 0, count = 0;
+  if (spec && *spec) {
+    if (strncmp(spec, "compute:", 8) != 0) return fail(GKLHIP_ERR_INVALID_ARG, "fault spec: compute:N or compute:NxK");
+    char* end = nullptr;
+    from = strtol(spec + 8, &end, 10);
+    count = (end && *end == 'x') ? strtol(end + 1, nullptr, 10) : 1;
+    if (from <= 0 || count <= 0) return fail(GKLHIP_ERR_INVALID_ARG, "fault spec: compute:N or compute:NxK");
+  }
+  g_fault_calls = 0; g_fault_count = count; g_fault_from = from;
+  return GKLHIP_OK;
+}
+static bool fault_due() {
+  const int64_t from = g_fault_from.load(std::memory_order_relaxed);
+  if (from <= 0) return false;
+  const int64_t nth = g_fault_calls.fetch_add(1) + 1;
+  return nth >= from && nth < from + g_fault_count.load();
+}
+
 static int compute_impl(gklhip_ctx* c, const gklhip_batch* hb, double* out_host) {
   if (!c) return fail(GKLHIP_ERR_INVALID_ARG, "context is NULL (initNative not called)");
   int rc = validate(hb);
@@ -2066,6 +2094,10 @@ static int compute_impl(gklhip_ctx* c, const gklhip_batch* hb, double* out_host)
   const int64_t n_pairs = (int64_t)hb->n_reads * hb->n_haps;
   if (n_pairs == 0) return GKLHIP_OK;
   if (!out_host) return fail(GKLHIP_ERR_INVALID_ARG, "output array is NULL");
+  if (fault_due()) {
+    for (int64_t i = 0; i < n_pairs; i++) out_host[i] = std::numeric_limits<double>::quiet_NaN();
+    return fail(GKLHIP_ERR_HIP, "injected fault (GKLHIP_FAULT_INJECT)");
+  }
   std::lock_guard<std::mutex> lock(c->mu);
   c->last_reads = hb->n_reads; c->last_haps = hb->n_haps;
   if (c->dev.size() == 1 && c->host_shards > 1 && n_pairs >= kHostShardPairs && hb->n_reads >= 2 * c->host_shards) {

@@ -461,7 +461,7 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
     shorts.reserve(nr);
     for (size_t r = 0; r < nr; r++) {
       if (blocks_for((int)q.read_lengths[r], kPdRpl) <= kLanes) { shorts.push_back((int32_t)r); continue; }
-      for (size_t h = 0; h < nh; h++) {  // a read that needs more than 64 lanes (320 bases or more): one striped job per haplotype
+      for (size_t h = 0; h < nh; h++) {  // a read that needs more than 64 lanes (64 x kPdRpl = 384 bases or more): one striped job per haplotype
         job_pair.push_back((int32_t)(r * nh + h)); job_striped.push_back(1); job_steps.push_back(0);
       }
     }
@@ -787,6 +787,13 @@ int pd_run_locked(gklhip_pdhmm_ctx* c, const PdProblem& q, double* out_host) {
 
   a.item_base = 0; a.job_base = 0;
   const bool paired_packed = !cross && !chunk_used.empty();
+  if (!paired_packed && n_slices > 1) {
+    // A sliced call without one packed chunk (every read striped): nothing below waits slice by slice, and the helper
+    // thread may still be sending -- meet ALL the uploads before the first kernel of the other branch reads the arrays.
+    if (up_th.th.joinable()) up_th.th.join();
+    PD_HIP_TRY(up_th.err);
+    for (int k = 0; k < n_slices; k++) PD_HIP_TRY(hipStreamWaitEvent(s, c->up_ev[k], 0));
+  }
   if (paired_packed) {
     // ---- paired layout: slice by slice (one slice unless the call is big, see above) ----
     PdExpandArgs x;

@@ -200,6 +200,12 @@ int gklhip_measure_issue_ceiling(gklhip_ctx* ctx, int use_double, double ms_budg
  * launches issued.  reset != 0 zeroes the counts after reading. */
 int gklhip_small_call_counts(int device, int64_t out[3], int reset);
 
+/* Fault injection for tests of a caller's error handling (the JNI shim retries a failed call once on fresh contexts):
+ * spec "compute:N" or "compute:NxK" makes the N-th .. (N+K-1)-th gklhip_compute of the process, counted from this call,
+ * fail with GKLHIP_ERR_HIP before any work (output array poisoned with NaN); NULL or "" disarms.  The first gklhip_init of
+ * a process arms it from the environment variable GKLHIP_FAULT_INJECT. */
+int gklhip_fault_inject(const char* spec);
+
 const char* gklhip_strerror(int status);
 /* Thread-local detail message of the last failing call on this thread. */
 const char* gklhip_last_error(void);

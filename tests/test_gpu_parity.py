@@ -288,6 +288,10 @@ def test_full_size_batch_properties(native, oracle):
         assert np.array_equal(bits(rev[::-1, ::-1]), bits(full[:2000]))
     with native.PairHmmContext(use_double=True) as c64:
         fulld = c64.compute(b).reshape(b.n_reads, b.n_haps)
+    # BASELINE config 3 ("bit-matched to GKL double-precision"): the same 48-read sample of the all-fp64 run against
+    # the oracle's useDoublePrecision path (IntelPairHmm.cc:153-156), bit for bit
+    expd = oracle.batch(sb, use_double=True, n_threads=8).reshape(len(subs), b.n_haps)
+    assert np.array_equal(bits(fulld[pick]), bits(expd))
     assert np.max(np.abs(full - fulld) / np.abs(fulld)) < REL_TOL
     assert np.array_equal(bits(full[u == 1]), bits(fulld[u == 1]))  # fallback pairs ARE the fp64 path
 

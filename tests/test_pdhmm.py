@@ -712,6 +712,31 @@ def test_pdhmm_gpu_paired_sliced_call_equals_the_unsliced_one(pd_ctx, pd_oracle,
 
 
 @pytest.mark.gpu
+def test_pdhmm_gpu_paired_sliced_call_of_striped_reads_only(pd_oracle, monkeypatch):
+    # A sliced paired call (>= 65 536 pairs, >= 64 MB) in which EVERY read needs more than one wavefront's lanes (384
+    # bases or more: 64 lanes x 6 rows): no packed chunk exists, the call falls to the branch the cross layout uses, and that branch must
+    # meet all seven slice uploads before its first kernel (r05 advisor finding: it launched while the helper thread was
+    # still sending).  64 random pairs x 1025 copies, three times over: every copy carries the oracle's bits.
+    from gkl_amd import native
+    rng = np.random.RandomState(7171)
+    uniq = random_pd_batch(rng, 64, read_len=(384, 460), hap_len=(40, 200))
+    st, vec = pd_oracle.compute(uniq, semantics=2)
+    assert st == 0
+    reps = 1025
+    big = uniq.subset(np.tile(np.arange(uniq.batch), reps))
+    assert big.batch >= 65536 and big.batch * (2 * big.max_hap_len + 5 * big.max_read_len) >= 64 << 20
+    with native.PdhmmContext(fma_mode=1, reference_tail=False) as c:
+        for _ in range(3):
+            got = c.compute(big).reshape(reps, -1)
+            assert c.last_routing()[0] == 0
+            bad = [k for k in range(reps) if got[k].tobytes() != vec.tobytes()]
+            assert not bad, bad[:5]
+    monkeypatch.setenv("GKL_HIP_PDHMM_PIPELINE", "0")
+    with native.PdhmmContext(fma_mode=1, reference_tail=False) as c:
+        assert c.compute(big).reshape(reps, -1)[reps - 1].tobytes() == vec.tobytes()
+
+
+@pytest.mark.gpu
 def test_pdhmm_gpu_buffers_shrink_again_after_a_big_call(pd_oracle):
     # a context's buffers grow with its biggest call; when the next 16 calls each need less than a quarter of a buffer
     # above 32 MB it is given back (one 120k-pair call holds ~0.7 GB of streams and tables) -- and the calls after that

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Where computeLikelihoodsNative's time goes on the C2 batch, call by call (GPU box): per-call wall time with the CPU the
+calling thread was on, the shim's marshal / wait / write-back split, by calling-thread placement (scheduler's choice, the
+NUMA node of the process's main thread, the other node), by maxNumberOfThreads and by range schedule.  One JSON object per
+line on stdout.  usage: tools/jni_marshal_probe.py [placement] [threads] [ranges]   (default: all three)"""
+import ctypes as C
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gkl_amd.synth import make_batch  # noqa: E402
+from tests import mockjni  # noqa: E402
+
+
+def cpulist(txt):
+    out = []
+    for part in txt.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out += list(range(int(a), int(b) + 1))
+        elif part:
+            out.append(int(part))
+    return out
+
+
+nodes = {int(p.rsplit("node", 1)[1].split("/")[0]): cpulist(open(p).read()) for p in glob.glob("/sys/devices/system/node/node*/cpulist")}
+libc = C.CDLL(None)
+main_cpu = libc.sched_getcpu()
+main_node = next((n for n, cpus in nodes.items() if main_cpu in cpus), None)
+b = make_batch("hc", 10000, 128)
+
+
+def measure(tag, iters=30, warm=6, max_threads=1, affinity=None, env=None):
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = str(v)
+    try:
+        t, calls, k = [], [], []
+        rc, _, cls, msg, wall = mockjni.run_concurrent(b, 1, iters=iters, warm=warm, max_threads=max_threads, timing=t, calls=calls, counters=k,
+                                                       affinity=affinity)
+    finally:
+        for kk, v in old.items():
+            if v is None:
+                os.environ.pop(kk, None)
+            else:
+                os.environ[kk] = v
+    if rc != 0:
+        print(json.dumps({"tag": tag, "error": f"{cls} {msg}"}), flush=True)
+        return None
+    ms = np.array([c[0] for c in calls])
+    cpus = sorted({c[2] for c in calls} | {c[3] for c in calls})
+    rec = {"tag": tag, "max_threads": max_threads, "env": env or {}, "median_ms": round(float(np.median(ms)), 3),
+           "p10_ms": round(float(np.percentile(ms, 10)), 3), "p90_ms": round(float(np.percentile(ms, 90)), 3), "max_ms": round(float(ms.max()), 3),
+           "marshal_ms": round(t[0] / t[4] / 1e6, 3), "wait_ms": round(t[1] / t[4] / 1e6, 3), "writeback_ms": round(t[2] / t[4] / 1e6, 3),
+           "caller_cpus": cpus, "caller_nodes": sorted({n for n, cl in nodes.items() for c in cpus if c in cl}),
+           "helper_share_of_jni_calls": round(k[mockjni.HELPER_JNI_CALLS] / max(1, k[mockjni.JNI_CALLS]), 3), "violations": k[mockjni.VIOLATIONS]}
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
+what = sys.argv[1:] or ["placement", "threads", "ranges"]
+print(json.dumps({"nodes": {n: f"{c[0]}..{c[-1]} ({len(c)})" for n, c in nodes.items()}, "main_cpu": main_cpu, "main_node": main_node,
+                  "affinity": len(os.sched_getaffinity(0))}), flush=True)
+if "placement" in what:
+    for rep in range(4):
+        measure(f"scheduler's choice #{rep}")
+    if main_node is not None and len(nodes) > 1:
+        other = next(n for n in nodes if n != main_node)
+        for rep in range(2):
+            measure(f"caller on the main thread's node {main_node} #{rep}", affinity=nodes[main_node])
+            measure(f"caller on the other node {other} #{rep}", affinity=nodes[other])
+        measure("caller on ONE cpu of the main node", affinity=[c for c in nodes[main_node] if c != main_cpu][:1])
+if "threads" in what:
+    for mt in (1, 2, 4, 8):
+        measure(f"max_threads {mt}", max_threads=mt)
+        measure(f"max_threads {mt}, marshalling on the calling thread only", max_threads=mt, env={"GKL_HIP_JNI_MARSHAL_THREADS": 1})
+if "ranges" in what:
+    for mt in (1, 4):
+        for first in (40000, 80000, 150000):
+            for growth in (1.0, 1.5, 2.0):
+                for last in (0, 60000):
+                    measure("ranges", max_threads=mt, iters=16, warm=4,
+                            env={"GKL_HIP_JNI_RANGE_PAIRS": first, "GKL_HIP_JNI_RANGE_GROWTH": growth, "GKL_HIP_JNI_RANGE_LAST": last})
