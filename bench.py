@@ -373,20 +373,65 @@ def sw_records(dev_index, n_pairs=8192):
     return rec
 
 
+class _PdhmmRegionCaller:
+    """The PDHMM twin of a small_proc_worker's caller: ONE computeLikelihoodsNative-sized call of the reference's fixture
+    (276 reads x 48 PD haplotypes) per compute()."""
+    def __init__(self, dev_index):
+        from gkl_amd import native
+        from gkl_amd.pdhmm_batch import PdhmmBatch
+        from tests.golden_io import load_pdhmm_holders_file
+        reads, haps, _ = load_pdhmm_holders_file()
+        one = b"\0"
+        self.r = PdhmmBatch.from_pairs([(one, one, r[0], r[1], r[2], r[3], r[4]) for r in reads])
+        self.h = PdhmmBatch.from_pairs([(h[0], h[1], one, one, one, one, one) for h in haps])
+        self.cells = int(self.r.read_lengths.sum()) * int(self.h.hap_lengths.sum())
+        self.ctx = native.PdhmmContext(device=dev_index, fma_mode=1)
+        self.last = None
+
+    def compute(self, *_):
+        self.last = self.ctx.compute_cross(self.r, self.h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.ctx.close()
+
+
 def small_proc_worker(idx, dev_index, workload, duration_s):
     """Child-process mode of `process_records`: ONE caller with its own context (its own process: what a GATK
-    HaplotypeCaller JVM is to the GPU), 100 x 10 regions through gklhip_compute back to back.  Says "ready" when warm, starts
-    on a line from the parent, prints one JSON object."""
+    HaplotypeCaller JVM is to the GPU), 100 x 10 regions through gklhip_compute back to back (workload "pdhmm": the PDHMM
+    fixture's 276 x 48 region through gklhip_pdhmm_compute_cross).  Says "ready" when warm, starts on a line from the parent,
+    prints one JSON object."""
+    import contextlib
     from gkl_amd import native
     from gkl_amd.synth import DEFAULT_SEED, make_batch
-    b = make_batch(workload, 100, 10, seed=DEFAULT_SEED + 17 * idx)   # every process its own region
-    out = np.empty(b.n_pairs)
-    with native.PinnedBatch(b) as pb, native.PairHmmContext(device=dev_index) as c:
+    if workload == "pdhmm":
+        b, out, pin_cm, ctx_cm = None, np.zeros(1), contextlib.nullcontext(), _PdhmmRegionCaller(dev_index)
+    else:
+        b = make_batch(workload, 100, 10, seed=DEFAULT_SEED + 17 * idx)   # every process its own region
+        out = np.empty(b.n_pairs)
+        pin_cm, ctx_cm = native.PinnedBatch(b), native.PairHmmContext(device=dev_index)
+    with pin_cm as pb, ctx_cm as c:
+        cells_per_call = int(b.cells) if b is not None else c.cells
         for _ in range(60):
             c.compute(pb, out)
         print("ready", flush=True)
         sys.stdin.readline()
-        lat = []
+        # What r05's 64-119 ms max_ms was (NOTES 56): every child's ~440th call, at the same moment in all of them -- the
+        # Python interpreter's full garbage collection (generation 2 comes due after a fixed number of allocations; with
+        # torch imported it walks ~1e6 objects: 35 ms alone, 60-85 ms with 4-16 interpreters doing it at once), not the
+        # library and not the device (a C++ loop of the same launches never shows it; rocprofv3 --hip-trace shows a 51 ms
+        # gap with no HIP call in it).  The collector is switched off for the timed loop.
+        import gc
+        gc.collect()
+        gc.disable()
+        t = time.perf_counter()
+        c.compute(pb, out)
+        first_ms = (time.perf_counter() - t) * 1e3
+        for _ in range(3):
+            c.compute(pb, out)
+        lat, at = [], []
         t0 = time.perf_counter()
         t_end = t0 + duration_s
         while True:
@@ -395,11 +440,19 @@ def small_proc_worker(idx, dev_index, workload, duration_s):
                 break
             c.compute(pb, out)
             lat.append(time.perf_counter() - t)
+            at.append(t - t0)
         elapsed = time.perf_counter() - t0
-    lat = np.sort(np.array(lat))
-    print(json.dumps({"calls": int(lat.size), "elapsed_s": elapsed, "cells_per_call": int(b.cells),
+    lat_a, at_a = np.array(lat), np.array(at)
+    slow = np.nonzero(lat_a > 5e-3)[0]
+    lat = np.sort(lat_a)
+    if b is None:
+        out = c.last
+    print(json.dumps({"calls": int(lat.size), "elapsed_s": elapsed, "cells_per_call": cells_per_call,
                       "p50_ms": float(lat[lat.size // 2]) * 1e3, "p99_ms": float(lat[min(lat.size - 1, int(lat.size * 0.99))]) * 1e3,
-                      "max_ms": float(lat[-1]) * 1e3,
+                      "max_ms": float(lat[-1]) * 1e3, "first_call_after_idle_ms": first_ms,
+                      # every call slower than 5 ms: (its index, when it started, how long it took)
+                      "slow_calls": [[int(i), round(float(at_a[i]) * 1e3, 2), round(float(lat_a[i]) * 1e3, 2)] for i in slow[:8]],
+                      "n_slow_calls": int(slow.size),
                       "checksum": float(out.sum())}), flush=True)
 
 
@@ -437,12 +490,17 @@ def process_records(dev_index, workload, counts=(4, 8, 16), duration_s=1.5):
             "p50_ms": round(float(np.median([r["p50_ms"] for r in res])), 4),
             "p99_ms": round(float(np.max([r["p99_ms"] for r in res])), 4),
             "max_ms": round(float(np.max([r["max_ms"] for r in res])), 3),
+            "first_call_after_idle_ms": round(float(np.max([r["first_call_after_idle_ms"] for r in res])), 3),
+            "calls_over_5ms": int(sum(r["n_slow_calls"] for r in res)),
+            "slowest_calls": sorted((c for r in res for c in r["slow_calls"]), key=lambda c: -c[2])[:4],   # [index in its child, start ms, ms]
             "longest_child_s": round(float(np.max([r["elapsed_s"] for r in res])), 3),
             "calls": calls, "seconds": duration_s}
     rec["note"] = ("P processes, each ONE caller with its own context looping 100 x 10 regions through gklhip_compute (host arrays in, "
                    "host doubles out), all started together, nothing else on the GPU (measured after the process of the other records has gone); "
                    "p50 = median over processes of their median call, p99 / max_ms = the worst process's, longest_child_s = the longest "
-                   "child's timed loop (seconds asked for: a stalled call shows here)")
+                   "child's timed loop (seconds asked for: a stalled call shows here); the first call of a child after the start signal is reported "
+                   "apart (first_call_after_idle_ms: the worst child's), calls_over_5ms / slowest_calls say what else stands out; the children's "
+                   "garbage collector is off during the loop (r05's 64-119 ms max_ms was its generation-2 pass, docs/NOTES.md 56)")
     return rec
 
 
@@ -504,7 +562,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="hc", choices=["hc", "region", "mixed"])
+    ap.add_argument("--workload", default="hc", choices=["hc", "region", "mixed", "pdhmm"], help='("pdhmm": only for the hidden per-process worker)')
     ap.add_argument("--reads", type=int, default=10000)
     ap.add_argument("--haps", type=int, default=128)
     ap.add_argument("--double", action="store_true", help="useDoublePrecision (BASELINE config 3)")
@@ -521,6 +579,8 @@ def main():
                                                            "their ends; at N=1 the default line stays single-stream so that the "
                                                            "roofline's kernel durations are those of kernels running alone)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one context, one stream per rank")
+    ap.add_argument("--dry-comm", action="store_true", help="N>1: only build the process group, run ONE gather of the real sizes and print the "
+                                                            "line's `comm` object (who answered, gather time per rank) -- seconds, no kernels")
     ap.add_argument("--in-library-probe", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--small-proc-worker", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--small-proc-device", type=int, default=0, help=argparse.SUPPRESS)
@@ -556,6 +616,16 @@ def main():
         except Exception as e:
             rec = {"error": repr(e)}
         res.setdefault("small_batch", {})["processes"] = rec
+        if isinstance(res.get("pdhmm"), dict) and "error" not in res["pdhmm"]:
+            # ... and the same deployment for PDHMM: P processes, each one caller looping fixture-sized regions
+            try:
+                pr = process_records(0 if os.environ.get("GKL_BENCH_SAME_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0")), "pdhmm",
+                                     counts=(4, 8), duration_s=1.0)
+                pr["note"] = ("P processes, each ONE caller with its own PDHMM context looping the fixture's 276 x 48 region through "
+                              "gklhip_pdhmm_compute_cross (= computeLikelihoodsNative after marshalling), all started together")
+            except Exception as e:
+                pr = {"error": repr(e)}
+            res["pdhmm"]["region_processes"] = pr
         print(json.dumps(res), flush=True)
         return
 
@@ -608,6 +678,35 @@ def main():
         whole = make_batch(a.workload, a.reads, a.haps, seed=DEFAULT_SEED)
         batch, bounds = shard_batch(whole, rank, world)
         rows = [bounds[g + 1] - bounds[g] for g in range(world)]
+    if a.dry_comm:
+        # the exchange step alone: one gather of the real buffers, timed on every rank, nothing computed
+        gather = PipelinedGather(rows, a.haps, comm_dev, dist if world > 1 else _SingleRank(), depth=2)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        gather.buffer(0)
+        gather.submit(0)
+        gather.finish()
+        torch.cuda.synchronize(dev)
+        mine = torch.tensor([float(rank), (time.perf_counter() - t0) * 1e3, float(batch.cells), float(batch.n_reads)], dtype=torch.float64, device=comm_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        if rank == 0:
+            cells = [float(t[2].item()) for t in allr]
+            print(json.dumps({"comm": {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else "none",
+                                       "ranks_seen": ranks_seen, "world_size": world, "dry": True,
+                                       "gather_bytes_per_rank": [int(r) * a.haps * 8 for r in rows],
+                                       "per_rank": [{"rank": int(t[0].item()), "first_gather_ms": round(float(t[1].item()), 3), "cells": int(t[2].item()),
+                                                     "reads": int(t[3].item())} for t in allr],
+                                       "imbalance": round(max(cells) / (sum(cells) / len(cells)), 4)}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     dbatch = native.DeviceBatch.upload(batch, dev)
     # record_events=2: kernels are bracketed with HIP events but no call synchronises, so the host-side planning of
     # step k+1 overlaps the kernels of step k; the event times are read after the timed region.
@@ -647,6 +746,7 @@ def main():
         step()
     drain()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed          # this rank's own clock around the same K steps (the line's time is the max over ranks)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -664,6 +764,25 @@ def main():
         n_mine = sum(1 for k in range(a.warmup, a.warmup + a.steps) if k % n_ctx == i)
         times += [c.step_times(k) for k in range(min(n_mine, 64))]
     ms_main, ms_fb, ms_dev = ([t[i] for t in times] for i in range(3))
+    # Every rank's own numbers, for the line's comm.per_rank: when N = 8 lands under 6x this says whether it was one slow
+    # rank (ms_per_step), an uneven split (cells), a slow kernel (fwd_main_ms / fwd_fp64_ms: HIP events of the timed steps;
+    # with two contexts alternating they include the other stream's kernels) or everything around the kernels (fixed_cost_ms)
+    mine = torch.tensor([float(rank), float(batch.cells), float(batch.n_pairs), float(batch.n_reads), my_elapsed / a.steps * 1e3,
+                         float(np.mean(ms_main)) if ms_main else 0.0, float(np.mean(ms_fb)) if ms_fb else 0.0,
+                         float(np.mean(ms_dev)) if ms_dev else 0.0], dtype=torch.float64, device=comm_dev)
+    per_rank_t = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank_t, mine)
+    else:
+        per_rank_t = [mine]
+    per_rank = []
+    for t in per_rank_t:
+        v = [float(x) for x in t.tolist()]
+        # fixed cost of a rank's step: with one context = step - kernels; with alternating contexts a step's wall time is
+        # shorter than its kernels' event-to-event times, so the figure can be negative (the other step's kernels fill the gaps)
+        per_rank.append({"rank": int(v[0]), "cells": int(v[1]), "pairs": int(v[2]), "reads": int(v[3]), "ms_per_step": round(v[4], 3),
+                         "fwd_main_ms": round(v[5], 3), "fwd_fp64_ms": round(v[6], 3), "device_total_ms": round(v[7], 3),
+                         "fixed_cost_ms": round(v[4] - v[5] - v[6], 3), "gcups": round(v[1] / v[4] / 1e6, 1) if v[4] > 0 else None})
     if rank == 0:
         st = ctxs[0].stats()
         with native.PairHmmContext(use_double=a.double, device=dev_index, record_events=1, fma_mode=a.fma_mode) as probe:
@@ -770,6 +889,12 @@ def main():
                      "ranks_seen": ranks_seen, "world_size": dist.get_world_size() if world > 1 else 1,
                      "gather": "dist.gather to rank 0, asynchronous, overlapped with the next step" if world > 1 else "none",
                      "gather_bytes_per_rank": [int(r) * a.haps * 8 for r in rows] if world > 1 else [],
+                     # what to read first when N GPUs scale badly: per_rank[*].ms_per_step against the line's
+                     # ms_per_step (= the slowest rank), then imbalance (cells: max / mean over ranks; 1.0 = even), then
+                     # time_imbalance (ms_per_step: max / mean), then each rank's kernels against its fixed cost
+                     "per_rank": per_rank,
+                     "imbalance": round(max(r["cells"] for r in per_rank) / (sum(r["cells"] for r in per_rank) / len(per_rank)), 4),
+                     "time_imbalance": round(max(r["ms_per_step"] for r in per_rank) / (sum(r["ms_per_step"] for r in per_rank) / len(per_rank)), 4),
                      "in_library_gather": None},   # filled from the in-library child below (N>1)
             "kernels_ms": {"fwd_main": round(k_ms, 3), "fwd_fp64_fallback": round(fb_ms, 3),
                            "device_total": round(dev_ms, 3), "from": kernel_times_from},
@@ -943,8 +1068,8 @@ def main():
             # left their GPUs), in a child process with a time limit: a problem there must not cost the line.
             try:
                 p = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-library-probe", str(world), "--reads", str(a.reads),
-                                    "--haps", str(a.haps), "--workload", a.workload, "--steps", str(a.steps), "--warmup", str(a.warmup)],
-                                   capture_output=True, text=True, timeout=240,
+                                    "--haps", str(a.haps), "--workload", a.workload, "--steps", str(min(a.steps, 10)), "--warmup", str(min(a.warmup, 3))],
+                                   capture_output=True, text=True, timeout=60,   # (a stuck child must not cost the line: 60 s, then it is killed)
                                    env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
                 line = next((ln for ln in reversed(p.stdout.splitlines()) if ln.startswith("{")), None)
                 res["in_library"] = json.loads(line) if line else {"error": (p.stderr or p.stdout)[-300:]}

@@ -78,20 +78,23 @@ constexpr const char* kOOM = "java/lang/OutOfMemoryError";
 constexpr const char* kRTE = "java/lang/RuntimeException";
 
 // Page-locked byte arena (one per marshalled field and slot): grows with the biggest call, and an arena above 32 MB that the
-// last 16 calls each filled to less than a quarter is given back (like the context's own buffers, pairhmm_api.hip: trim_due)
-// -- one 1.28 M-pair call must not keep ~100 MB pinned per slot for the life of the JVM.  clear() runs at the start of a
-// call, when nothing of the slot's previous call is in flight any more.
+// last 16 calls each filled to less than a quarter -- and that has not grown for 64 calls: hipHostFree synchronises the whole
+// device -- is given back (like the context's own buffers, pairhmm_api.hip: trim_due) -- one 1.28 M-pair call must not keep
+// ~100 MB pinned per slot for the life of the JVM.  clear() runs at the start of a call, when nothing of the slot's previous
+// call is in flight any more.
 struct PinnedBytes {
   uint8_t* p = nullptr;
   size_t cap = 0, len = 0;
-  int small_uses = 0;
+  int small_uses = 0, since_grow = 64;
   PinnedBytes() = default;
   PinnedBytes(const PinnedBytes&) = delete;
   PinnedBytes& operator=(const PinnedBytes&) = delete;
   ~PinnedBytes() { gklhip_host_free(p); }
   void clear() {
+    if (since_grow < 64) since_grow++;
     if (cap > ((size_t)32 << 20) && len < cap / 4) {
-      if (++small_uses >= 16) { gklhip_host_free(p); p = nullptr; cap = 0; small_uses = 0; }
+      if (small_uses < 16) small_uses++;
+      if (small_uses >= 16 && since_grow >= 64) { gklhip_host_free(p); p = nullptr; cap = 0; small_uses = 0; }
     } else {
       small_uses = 0;
     }
@@ -106,6 +109,7 @@ struct PinnedBytes {
       gklhip_host_free(p);
       p = q;
       cap = want;
+      since_grow = 0;
     }
     uint8_t* at = p + len;
     len += add;
@@ -249,6 +253,8 @@ struct Slot {
   std::vector<double> out;
   int calls_since_pipelined = 0;       // one-shot calls since the slot's last pipelined one: after 16 its range arenas (and a result vector above 32 MB) go
   bool busy = false;
+  int64_t idle_since = 0;              // when the last call returned it (steady clock, ns)
+  bool idle_released = false;          // the janitor has been through it since then
   int gen = 0;  // configuration generation (initNative with other arguments starts a new one)
   gklhip_config cfg;  // what `ctx` was created with: the second engine of a pipelined call gets the same
   ~Slot() {
@@ -264,7 +270,7 @@ struct Slot {
 // whole gklhip_compute), [2] write-back into the Java array, [3] whole calls, [4] number of calls, [5] pipelined calls.
 std::atomic<int64_t> g_timing[6];
 // gkl_pairhmm_jni_helpers: [0] ns of marshalling on helper threads, [1] read ranges marshalled by helpers, [2] by
-// calling threads, [3] calls retried after a HIP failure
+// calling threads, [3] calls retried after a HIP failure ([4]: streams / engines the janitor gave back, g_idle_released)
 std::atomic<int64_t> g_helpers[4];
 int64_t now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -287,7 +293,21 @@ struct State {
   gklhip_config cfg;
   FieldIds f;
   JavaVM* vm = nullptr;   // from initNative's GetJavaVM: what helper threads attach to
+  // The janitor: a slot nobody has used for a second (GKL_HIP_IDLE_RELEASE_MS; 0 = never) gives back what it holds only
+  // for speed -- the second engine and compute threads of pipelined calls, the first engine's extra streams and twin
+  // engines (gklhip_release_idle) -- so that an idle JVM that once sent a big batch holds one or two hardware queues on
+  // the device, not a dozen (docs/NOTES.md 49, 55: the device's scheduler rotates every process's queues).
+  std::thread janitor;
+  std::condition_variable janitor_wake;
+  bool janitor_quit = false;
+  int64_t idle_release_ns = 1000000000LL;
+  ~State() {
+    { std::lock_guard<std::mutex> l(mu); janitor_quit = true; }
+    janitor_wake.notify_all();
+    if (janitor.joinable()) janitor.join();
+  }
 } g;
+std::atomic<int64_t> g_idle_released{0};   // streams given back by the janitor so far (gkl_pairhmm_jni_helpers [4])
 
 void throw_java(JNIEnv* env, const char* class_path, const char* msg) {
   gkljni::ExceptionClear(env);  // IntelPairHmm.cc:65-66
@@ -398,6 +418,60 @@ MarshalError marshal_haps(JNIEnv* env, jobjectArray haps, const FieldIds& f, Pin
   return {};
 }
 
+// Read ranges of a pipelined call: boundaries cut[0] = 0 < ... < cut.back() = n_reads (at most 32 ranges).
+// What the schedule trades (measured on the 10 000 x 128 batch, tools/jni_marshal_probe.py, docs/NOTES.md 54): the first
+// range's marshalling is the only part nothing overlaps with -- small first range; a range is one gklhip_compute, and
+// small ones use the chip badly (nine ranges of 150k pairs: 13.7 ms of GPU time for 11.7 ms of work) -- few, big
+// ranges; what follows the last kernel (the fp64 pairs' log10 on the host, the write-back) is proportional to the last
+// range, and with ONE marshalling thread the big ranges arrive late anyway -- a descending tail there.
+//   marshalling threads >= 3:  4 / 32 / 32 / 32 per cent of the reads          (10k x 128: 13.0-13.1 ms per call)
+//   fewer:                     4 / 12 / 28 / 36 / 14 / 6                       (14.1-14.3 ms; r05's equal 150k ranges: 14.9-15.3)
+// A range below 40 000 pairs (the first) / 60 000 pairs (the others) is merged with its neighbour: a call of 200k pairs
+// becomes two ranges.  GKL_HIP_JNI_RANGE_SHARES="a,b,c" sets the per cents, GKL_HIP_JNI_RANGE_PAIRS=n asks for equal
+// ranges of n pairs (tests force many small ranges with it); both are read per call.
+std::vector<jsize> plan_ranges(jsize n_reads, jsize n_haps, int marshal_threads) {
+  std::vector<jsize> cut{0};
+  const char* rv = getenv("GKL_HIP_JNI_RANGE_PAIRS");
+  if (rv && atoll(rv) > 0) {
+    const double per = std::max(1.0, (double)atoll(rv) / (double)std::max<jsize>(1, n_haps));
+    for (double at = per; cut.size() < 32 && (jsize)at < n_reads; at += per) if ((jsize)at > cut.back()) cut.push_back((jsize)at);
+    cut.push_back(n_reads);
+    if (cut.size() >= 4 && cut.back() - cut[cut.size() - 2] < (cut[cut.size() - 2] - cut[cut.size() - 3]) / 3) cut.erase(cut.end() - 2);  // no sliver at the end
+    return cut;
+  }
+  std::vector<double> shares;
+  const char* sv = getenv("GKL_HIP_JNI_RANGE_SHARES");
+  bool floors = true;
+  if (sv && *sv) {
+    floors = false;   // (an explicit schedule is taken as given)
+    for (const char* q = sv; *q && shares.size() < 32;) {
+      char* end = nullptr;
+      const double v = strtod(q, &end);
+      if (end == q) break;
+      if (v > 0) shares.push_back(v);
+      q = *end ? end + 1 : end;
+    }
+  }
+  if (shares.empty()) {
+    floors = true;
+    if (marshal_threads >= 3) shares = {4, 32, 32, 32};
+    else shares = {4, 12, 28, 36, 14, 6};
+  }
+  double total = 0;
+  for (double v : shares) total += v;
+  const double floor_first = 40000.0 / std::max<jsize>(1, n_haps), floor_rest = 60000.0 / std::max<jsize>(1, n_haps);   // in reads
+  double acc = 0;
+  for (size_t k = 0; k + 1 < shares.size(); k++) {
+    acc += shares[k];
+    const jsize at = (jsize)std::min<double>(n_reads, acc / total * n_reads);
+    const double need = floors ? (cut.size() == 1 ? floor_first : floor_rest) : 1.0;
+    if (at - cut.back() >= need && at < n_reads) cut.push_back(at);
+  }
+  if (floors && cut.size() > 1 && n_reads - cut.back() < floor_rest) cut.pop_back();   // (the last range takes a too-small remainder in)
+  cut.push_back(n_reads);
+  return cut;
+}
+
 // A free slot of the current configuration, creating one (context + stream) while fewer than max_slots exist;
 // blocks otherwise.  Returns NULL after throwing.
 Slot* acquire_slot(JNIEnv* env) {
@@ -447,12 +521,15 @@ Slot* acquire_slot(JNIEnv* env) {
 
 struct SlotLease {
   Slot* s;
+  bool janitor = false;
   ~SlotLease() {
     if (!s) return;
     std::unique_ptr<Slot> dead;
     {
       std::lock_guard<std::mutex> lock(g.mu);
       s->busy = false;
+      if (janitor) s->idle_released = true;
+      else { s->idle_since = now_ns(); s->idle_released = false; }
       if (s->gen != g.gen)  // initNative changed the configuration while this call ran: the slot is not reused
         for (auto it = g.slots.begin(); it != g.slots.end(); ++it)
           if (it->get() == s) { dead = std::move(*it); g.slots.erase(it); break; }
@@ -480,6 +557,37 @@ bool renew_engines(Slot* sl, int status, const char* detail) {
     return false;
   }
   return true;
+}
+
+void janitor_loop() {
+  std::unique_lock<std::mutex> lock(g.mu);
+  while (!g.janitor_quit) {
+    g.janitor_wake.wait_for(lock, std::chrono::milliseconds(250));
+    if (g.janitor_quit) break;
+    if (g.idle_release_ns <= 0) continue;
+    const int64_t now = now_ns();
+    Slot* pick = nullptr;
+    for (auto& s : g.slots)
+      if (!s->busy && !s->idle_released && now - s->idle_since >= g.idle_release_ns) { pick = s.get(); break; }
+    if (!pick) continue;
+    pick->busy = true;   // leased like a caller would: nobody else touches it, doneNative / initNative skip it
+    lock.unlock();
+    {
+      SlotLease lease{pick, true};
+      pick->pipe.reset();
+      if (pick->ctx2) { gklhip_done(pick->ctx2); pick->ctx2 = nullptr; g_idle_released += 1; }
+      pick->ranges.clear();
+      int32_t n = 0;
+      if (pick->ctx && gklhip_release_idle(pick->ctx, &n) == GKLHIP_OK) g_idle_released += n;
+    }
+    lock.lock();
+  }
+}
+
+void start_janitor_locked() {   // g.mu held
+  if (g.janitor.joinable()) return;
+  g.idle_release_ns = (int64_t)std::max(0, env_int("GKL_HIP_IDLE_RELEASE_MS", 1000)) * 1000000LL;
+  try { g.janitor = std::thread(janitor_loop); } catch (const std::exception&) {}   // (no thread: nothing is given back early, that is all)
 }
 
 }  // namespace
@@ -538,8 +646,10 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_initNative(
   g.max_slots = max_slots;
   first->cfg = cfg;
   first->gen = ++g.gen;   // (two racing initNative calls: the later one's generation wins, the other's slot retires like any old one)
+  first->idle_since = now_ns();
   g.slots.push_back(std::move(first));
   g.ready = true;
+  start_janitor_locked();
   for (auto it = g.slots.begin(); it != g.slots.end();) {
     if (!(*it)->busy && (*it)->gen != g.gen) { dead.push_back(std::move(*it)); it = g.slots.erase(it); }
     else ++it;
@@ -627,38 +737,13 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     }
     // ---- pipelined: read ranges; range k+1 is marshalled while the ranges before it compute on the slot's two engines,
     // finished ranges go back to the Java array in between ----
-    // Range boundaries: the first range is small (its marshalling is the only part nothing overlaps with), the later ones
-    // grow geometrically (marshalling outruns compute, and bigger ranges use the chip better: a range of 150k pairs takes
-    // 1.6-1.8 ms where an eighth of the whole batch's time would be 1.45), the last ones shrink again (what follows the
-    // last kernel -- the fp64 pairs' log10 on the host, the write-back -- is proportional to the last range):
-    // sizes first * g^k, capped so that the remaining reads end in a descending tail.
-    const char* rv = getenv("GKL_HIP_JNI_RANGE_PAIRS");
-    const int64_t range_pairs = rv && atoll(rv) > 0 ? atoll(rv) : 150000LL;
-    const char* gv = getenv("GKL_HIP_JNI_RANGE_GROWTH");
-    const double growth = gv && atof(gv) >= 1.0 ? atof(gv) : 1.0;
-    const char* lv = getenv("GKL_HIP_JNI_RANGE_LAST");
-    const int64_t last_pairs = lv && atoll(lv) > 0 ? atoll(lv) : 0;   // 0: no descending tail
-    std::vector<jsize> cut{0};
+    int want_threads;   // marshalling threads this call may use: the calling thread + helpers
     {
-      double want = (double)range_pairs / (double)n_haps;   // reads in the next range
-      const double last = (double)last_pairs / (double)n_haps;
-      double at = 0;
-      while ((jsize)at < n_reads && cut.size() < 33) {
-        double take = std::max(1.0, want);
-        if (last > 0) {
-          // never more than half of what is left beyond one `last`-sized range: the sizes come down by halves to `last`
-          const double left = (double)n_reads - at;
-          if (left > 2.0 * last) take = std::min(take, std::max(last, (left - last) / 2.0));
-        }
-        at += take;
-        cut.push_back((jsize)std::min<double>(at, n_reads));
-        want *= growth;
-      }
-      cut.back() = n_reads;
-      if (cut.size() >= 3 && cut.back() - cut[cut.size() - 2] < (cut[cut.size() - 2] - cut[cut.size() - 3]) / 3) {  // no sliver at the end
-        cut.erase(cut.end() - 2);
-      }
+      const char* hv = getenv("GKL_HIP_JNI_MARSHAL_THREADS");
+      want_threads = std::max(1, std::min(hv && *hv ? atoi(hv) : sl->cfg.max_threads, 8));
+      if (!vm) want_threads = 1;
     }
+    const std::vector<jsize> cut = plan_ranges(n_reads, n_haps, want_threads);
     const int n_ranges = (int)cut.size() - 1;
     sl->calls_since_pipelined = 0;
     while ((int)sl->ranges.size() < n_ranges) sl->ranges.emplace_back(new ReadArena());
@@ -670,11 +755,8 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
     }
     // helper threads (maxNumberOfThreads - 1 of them, at most 7 and one per range beyond the first): attached to the JVM,
     // reading the holders through a global reference
-    int n_helpers = 0;
+    int n_helpers = std::min(want_threads - 1, n_ranges - 1);
     {
-      const char* hv = getenv("GKL_HIP_JNI_MARSHAL_THREADS");
-      const int threads = hv && *hv ? atoi(hv) : sl->cfg.max_threads;
-      n_helpers = std::max(0, std::min({threads - 1, 7, n_ranges - 1}));
       if (n_helpers > 0 && vm) {
         try {
           if (!sl->helpers || sl->helpers->vm != vm) sl->helpers.reset(new MarshalHelpers(vm));
@@ -816,8 +898,10 @@ __attribute__((visibility("default"))) void gkl_pairhmm_jni_timing(int64_t out[6
   for (int i = 0; i < 6; i++) { out[i] = g_timing[i].load(); if (reset) g_timing[i].store(0); }
 }
 // ... and what the marshalling helpers did -- see g_helpers.
-__attribute__((visibility("default"))) void gkl_pairhmm_jni_helpers(int64_t out[4], int reset) {
+__attribute__((visibility("default"))) void gkl_pairhmm_jni_helpers(int64_t out[5], int reset) {
   for (int i = 0; i < 4; i++) { out[i] = g_helpers[i].load(); if (reset) g_helpers[i].store(0); }
+  out[4] = g_idle_released.load();
+  if (reset) g_idle_released.store(0);
 }
 
 JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv*, jobject) {

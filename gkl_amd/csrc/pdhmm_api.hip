@@ -86,17 +86,23 @@ const PdTables& pd_tables() {
 }
 
 // (like libgklhip_pairhmm's buffers: grown by the biggest call, given back when the last 16 calls each needed less than a
-//  quarter of a buffer above 32 MB -- a 424k-pair call holds ~3 GB of streams and tables)
-inline bool pd_trim_due(size_t n, size_t cap, int* small_uses) {
+//  quarter of a buffer above 32 MB -- a 424k-pair call holds ~3 GB of streams and tables -- but not within 64 calls of the
+//  buffer's last growth: hipFree / hipHostFree synchronise the whole device, and a workload that alternates one big call
+//  with a few small ones must not free and re-make its buffers every round)
+constexpr int kPdTrimCalls = 16, kPdTrimQuiet = 64;
+inline bool pd_trim_due(size_t n, size_t cap, int* small_uses, int* since_grow) {
+  if (*since_grow < kPdTrimQuiet) ++*since_grow;
   if (cap <= ((size_t)32 << 20) || n >= cap / 4) { *small_uses = 0; return false; }
-  return ++*small_uses >= 16;
+  if (*small_uses < kPdTrimCalls) ++*small_uses;
+  return *small_uses >= kPdTrimCalls && *since_grow >= kPdTrimQuiet;
 }
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
-  int small_uses = 0;
+  int small_uses = 0, since_grow = kPdTrimQuiet;
   int reserve(size_t n) {
-    if (n <= cap && !pd_trim_due(n, cap, &small_uses)) return GKLHIP_OK;
+    if (n <= cap && !pd_trim_due(n, cap, &small_uses, &since_grow)) return GKLHIP_OK;
+    if (n > cap) since_grow = 0;
     small_uses = 0;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     const size_t want = n + n / 4 + 256;
@@ -110,9 +116,10 @@ struct Buf {
 struct PinBuf {  // page-locked host memory
   void* p = nullptr;
   size_t cap = 0;
-  int small_uses = 0;
+  int small_uses = 0, since_grow = kPdTrimQuiet;
   int reserve(size_t n) {
-    if (n <= cap && !pd_trim_due(n, cap, &small_uses)) return GKLHIP_OK;
+    if (n <= cap && !pd_trim_due(n, cap, &small_uses, &since_grow)) return GKLHIP_OK;
+    if (n > cap) since_grow = 0;
     small_uses = 0;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     const size_t want = n + n / 4 + 256;

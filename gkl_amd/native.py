@@ -84,6 +84,10 @@ def load_library(path: Optional[str] = None):
     lib.gklhip_measure_issue_ceiling.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.gklhip_measure_issue_ceiling.restype = C.c_int
     lib.gklhip_small_call_counts.argtypes = [C.c_int, C.POINTER(C.c_int64), C.c_int]
+    lib.gklhip_release_idle.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.gklhip_release_idle.restype = C.c_int
+    lib.gklhip_fault_inject.argtypes = [C.c_char_p]
+    lib.gklhip_fault_inject.restype = C.c_int
     lib.gklhip_small_call_counts.restype = C.c_int
     lib.gklhip_gather_note.argtypes = [C.c_void_p]
     lib.gklhip_gather_note.restype = C.c_char_p
@@ -253,6 +257,15 @@ class PairHmmContext:
         """none | peer | rccl (lazily created: before the first device-resident call, what it will try) |
         peer-after-rccl-failure (gather_note says why)"""
         return ("none", "peer", "rccl", "peer-after-rccl-failure")[self.lib.gklhip_gather_backend(self.handle)]
+
+    def release_idle(self) -> int:
+        """Give back the streams / twin engines the context holds only for speed, if it is idle (gklhip_release_idle);
+        returns how many streams went."""
+        n = C.c_int32(0)
+        st = self.lib.gklhip_release_idle(self.handle, C.byref(n))
+        if st != OK:
+            _raise(self.lib, st)
+        return int(n.value)
 
     def issue_ceiling(self, use_double: bool = False, ms_budget: float = 50.0):
         """(cells per second of the recurrence's bare instruction mix, sustained clock in GHz) -- diagnostics."""

@@ -200,6 +200,13 @@ int gklhip_measure_issue_ceiling(gklhip_ctx* ctx, int use_double, double ms_budg
  * launches issued.  reset != 0 zeroes the counts after reading. */
 int gklhip_small_call_counts(int device, int64_t out[3], int reset);
 
+/* Gives back what an IDLE context holds only for speed: the streams it made for big calls (every stream is a hardware
+ * queue the device's scheduler rotates among all processes' -- an idle process should hold one or two, not seven), its
+ * twin engines of big host-buffer calls and second engines of two-stream device-resident callers.  Nothing happens while a
+ * call is running or work is queued; what went is made again by the first call that needs it.  The JNI library calls
+ * this for every slot that has been idle for a second (GKL_HIP_IDLE_RELEASE_MS).  *streams_released: how many streams went. */
+int gklhip_release_idle(gklhip_ctx* ctx, int32_t* streams_released);
+
 /* Fault injection for tests of a caller's error handling (the JNI shim retries a failed call once on fresh contexts):
  * spec "compute:N" or "compute:NxK" makes the N-th .. (N+K-1)-th gklhip_compute of the process, counted from this call,
  * fail with GKLHIP_ERR_HIP before any work (output array poisoned with NaN); NULL or "" disarms.  The first gklhip_init of

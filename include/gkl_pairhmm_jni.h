@@ -60,6 +60,11 @@ JNIEXPORT jint JNICALL JNI_OnLoad(struct JavaVM_* vm, void* reserved);
  * likelihoods back, [3] whole calls, [4] number of calls, [5] calls that were pipelined (read ranges marshalled while
  * earlier ranges compute; GKL_HIP_JNI_PIPELINE_PAIRS, default 160000 pairs, sets the size from which that happens). */
 void gkl_pairhmm_jni_timing(int64_t out[6], int reset);
+/* ... and: [0] ns of marshalling done on the slots' helper threads (maxNumberOfThreads > 1: threads attached through the
+ * JavaVM marshal read ranges beside the calling thread), [1] read ranges marshalled by helpers, [2] by calling threads,
+ * [3] calls retried once on fresh contexts after a HIP failure, [4] streams / engines given back by idle slots
+ * (GKL_HIP_IDLE_RELEASE_MS, default 1000: a slot unused for that long keeps one engine with its own stream). */
+void gkl_pairhmm_jni_helpers(int64_t out[5], int reset);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,4 @@
-// Test harness: a mock JVM side for libgkl_pairhmm.so (no JDK in this image, none on the GPU boxes: docs/NOTES.md 50).
+// Test harness: a mock JVM side for libgkl_pairhmm.so (no JDK in this image, none on the GPU boxes: docs/NOTES.md 52).
 //
 // Builds a JNINativeInterface_ function table (spec slot indices, gkl_amd/csrc/jni_min.h) and a JavaVM invocation
 // table over a small object model, dlopen()s the drop-in library the way NativeLibraryLoader/System.load would (reference
@@ -11,7 +11,7 @@
 // slots of the thread's own handle arena, bumped by every function that returns a reference, rewound by PopLocalFrame
 // and on return to Java; global references: slots of a VM-wide arena), so creating, deleting and resolving a
 // reference cost a few nanoseconds like in a JVM -- r05's mock kept a std::multiset of live references and looked holder
-// fields up in a std::map<std::string>, and the "marshalling" time it reported was mostly its own (NOTES 51) -- while
+// fields up in a std::map<std::string>, and the "marshalling" time it reported was mostly its own (NOTES 53) -- while
 // everything -Xcheck:jni enforces (the reference's test JVMs run with it, build.gradle:101-104) is still checked on
 // every call:
 //  * no JNI call with an exception pending, except the handful the specification allows;
@@ -42,17 +42,24 @@ namespace {
 
 constexpr int kMaxFields = 8;
 
+// A Java-heap object: an 8-byte header with the payload right behind it, bump-allocated from the VM's heap chunks in the
+// order the harness creates them -- a read's holder and its five byte[] lie next to each other like objects a Java thread
+// allocates in its TLAB (r06: the first slot-based mock still kept every object as a ~280-byte struct of std::vectors, a
+// 150 MB graph for the C2 batch whose cache and TLB misses were most of the "marshalling" time; this heap is 10 MB).
+struct ClassInfo { std::string name; std::set<std::string> fields; };
 struct Obj {
-  enum Kind { CLASS, BYTES, DOUBLES, LONGS, INTS, OBJARRAY, HOLDER } kind;
-  std::string name;                      // CLASS
-  std::set<std::string> class_fields;    // CLASS
-  std::vector<int8_t> bytes;             // BYTES
-  std::vector<double> doubles;           // DOUBLES
-  std::vector<int64_t> longs;            // LONGS
-  std::vector<int32_t> ints;             // INTS
-  std::vector<Obj*> elems;               // OBJARRAY
-  Obj* field[kMaxFields] = {};           // HOLDER: by field index (jfieldID = index + 1); nullptr = Java null
+  enum Kind : uint32_t { CLASS, BYTES, DOUBLES, LONGS, INTS, OBJARRAY, HOLDER } kind;
+  uint32_t n;   // array length; HOLDER: number of field slots (kMaxFields); CLASS: 1 (a ClassInfo*)
+  template <typename T> T* data() { return reinterpret_cast<T*>(this + 1); }
+  int8_t* bytes() { return data<int8_t>(); }
+  double* doubles() { return data<double>(); }
+  int64_t* longs() { return data<int64_t>(); }
+  int32_t* ints() { return data<int32_t>(); }
+  Obj** elems() { return data<Obj*>(); }     // OBJARRAY
+  Obj** fields() { return data<Obj*>(); }    // HOLDER: by field index (jfieldID = index + 1); nullptr = Java null
+  ClassInfo* cls() { return *data<ClassInfo*>(); }
 };
+static_assert(sizeof(Obj) == 8, "payload stays 8-byte aligned");
 
 // interned field names: jfieldID k + 1 <-> name k (VM-independent, like a symbol table)
 std::mutex g_names_mu;
@@ -70,7 +77,11 @@ struct MockVM {
   JavaVM_ vm;                  // must be first: JavaVM* == MockVM*
   JNIInvokeInterface_ itable;
   std::mutex mu;
-  std::vector<std::unique_ptr<Obj>> heap;
+  static constexpr size_t kChunk = (size_t)32 << 20;
+  std::vector<std::unique_ptr<char[]>> chunks;   // the Java heap: bump-allocated
+  size_t chunk_left = 0;
+  char* chunk_at = nullptr;
+  std::vector<std::unique_ptr<ClassInfo>> classes;
   std::vector<std::unique_ptr<Mock>> owned;   // every JNIEnv of this VM
   std::vector<Mock*> envs;
   static constexpr size_t kGlobalCap = 1 << 12;
@@ -84,11 +95,32 @@ struct MockVM {
   void violation(const std::string& what) {
     if (!violations.fetch_add(1)) { std::lock_guard<std::mutex> l(mu); first_violation = what; }
   }
-  Obj* make(Obj::Kind k) {
+  Obj* make(Obj::Kind k, size_t n, size_t payload_bytes) {   // zeroed
+    const size_t want = (sizeof(Obj) + payload_bytes + 7) & ~(size_t)7;
     std::lock_guard<std::mutex> l(mu);
-    heap.emplace_back(new Obj());
-    heap.back()->kind = k;
-    return heap.back().get();
+    if (want > chunk_left) {
+      const size_t sz = std::max(kChunk, want);
+      chunks.emplace_back(new char[sz]());
+      chunk_at = chunks.back().get();
+      chunk_left = sz;
+    }
+    Obj* o = reinterpret_cast<Obj*>(chunk_at);
+    chunk_at += want; chunk_left -= want;
+    o->kind = k; o->n = (uint32_t)n;
+    return o;
+  }
+  Obj* make_bytes(const void* p, size_t n) { Obj* o = make(Obj::BYTES, n, n); if (p && n) memcpy(o->bytes(), p, n); return o; }
+  Obj* make_doubles(size_t n, double fill) { Obj* o = make(Obj::DOUBLES, n, 8 * n); std::fill(o->doubles(), o->doubles() + n, fill); return o; }
+  Obj* make_longs(const int64_t* p, size_t n) { Obj* o = make(Obj::LONGS, n, 8 * n); if (n) memcpy(o->longs(), p, 8 * n); return o; }
+  Obj* make_ints(size_t n, int32_t fill) { Obj* o = make(Obj::INTS, n, 4 * n); std::fill(o->ints(), o->ints() + n, fill); return o; }
+  Obj* make_array(size_t n) { return make(Obj::OBJARRAY, n, 8 * n); }
+  Obj* make_holder() { return make(Obj::HOLDER, kMaxFields, 8 * kMaxFields); }
+  Obj* make_class(const std::string& name, std::set<std::string> fields) {
+    Obj* o = make(Obj::CLASS, 1, 8);
+    std::lock_guard<std::mutex> l(mu);
+    classes.emplace_back(new ClassInfo{name, std::move(fields)});
+    *o->data<ClassInfo*>() = classes.back().get();
+    return o;
   }
   Mock* new_env();
 };
@@ -180,14 +212,13 @@ void unimplemented() {
 
 jclass m_FindClass(JNIEnv* e, const char* name) {
   M(e)->enter("FindClass");
-  Obj* c = M(e)->vm->make(Obj::CLASS);
-  c->name = name;
+  Obj* c = M(e)->vm->make_class(name, {});
   return reinterpret_cast<jclass>(M(e)->hand_out(c));
 }
 jint m_ThrowNew(JNIEnv* e, jclass c, const char* msg) {
   M(e)->enter("ThrowNew");
   Obj* o = M(e)->deref(c, "ThrowNew");
-  M(e)->raise(o ? o->name.c_str() : "?", msg ? msg : "");
+  M(e)->raise(o ? o->cls()->name.c_str() : "?", msg ? msg : "");
   return 0;
 }
 void m_ExceptionClear(JNIEnv* e) { M(e)->enter("ExceptionClear", true); M(e)->pending = false; }
@@ -261,7 +292,7 @@ jint m_GetJavaVM(JNIEnv* e, JavaVM** out) {
 jfieldID m_GetFieldID(JNIEnv* e, jclass c, const char* name, const char* sig) {
   M(e)->enter("GetFieldID");
   Obj* cls = M(e)->deref(c, "GetFieldID");
-  if (!cls || strcmp(sig, "[B") != 0 || !cls->class_fields.count(name)) {
+  if (!cls || strcmp(sig, "[B") != 0 || !cls->cls()->fields.count(name)) {
     M(e)->raise("java/lang/NoSuchFieldError", name);
     return nullptr;
   }
@@ -273,25 +304,25 @@ jobject m_GetObjectField(JNIEnv* e, jobject o, jfieldID f) {
   Obj* h = m->deref(o, "GetObjectField");
   const intptr_t k = reinterpret_cast<intptr_t>(f) - 1;
   if (!h || k < 0 || k >= kMaxFields) return nullptr;
-  return m->hand_out(h->field[k]);
+  return m->hand_out(h->fields()[k]);
 }
 jsize m_GetArrayLength(JNIEnv* e, jarray a) {
   M(e)->enter("GetArrayLength");
   Obj* o = M(e)->deref(a, "GetArrayLength");
   if (!o) return 0;
-  return (jsize)(o->kind == Obj::BYTES ? o->bytes.size() : o->kind == Obj::DOUBLES ? o->doubles.size()
-                 : o->kind == Obj::LONGS ? o->longs.size() : o->kind == Obj::INTS ? o->ints.size() : o->elems.size());
+  return (jsize)o->n;
 }
 jobject m_GetObjectArrayElement(JNIEnv* e, jobjectArray a, jsize i) {
   Mock* m = M(e);
   m->enter("GetObjectArrayElement");
   Obj* o = m->deref(a, "GetObjectArrayElement");
-  if (!o || i < 0 || (size_t)i >= o->elems.size()) { m->raise("java/lang/ArrayIndexOutOfBoundsException", "element"); return nullptr; }
-  return m->hand_out(o->elems[i]);
+  if (!o || i < 0 || (uint32_t)i >= o->n) { m->raise("java/lang/ArrayIndexOutOfBoundsException", "element"); return nullptr; }
+  return m->hand_out(o->elems()[i]);
 }
-template <typename T>
-bool region_ok(Mock* m, const std::vector<T>& v, jsize start, jsize len, const char* what) {
-  if (start < 0 || len < 0 || (size_t)start + (size_t)len > v.size()) {
+bool region_ok(Mock* m, Obj* o, Obj::Kind kind, jsize start, jsize len, const char* what) {
+  if (!o) return false;
+  if (o->kind != kind) { m->violation(std::string(what) + " of an array of another type"); return false; }
+  if (start < 0 || len < 0 || (size_t)start + (size_t)len > o->n) {
     m->raise("java/lang/ArrayIndexOutOfBoundsException", what);
     return false;
   }
@@ -300,33 +331,31 @@ bool region_ok(Mock* m, const std::vector<T>& v, jsize start, jsize len, const c
 void m_GetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, jbyte* buf) {
   M(e)->enter("GetByteArrayRegion");
   Obj* o = M(e)->deref(a, "GetByteArrayRegion");
-  if (o && region_ok(M(e), o->bytes, start, len, "byte region")) memcpy(buf, o->bytes.data() + start, (size_t)len);
+  if (region_ok(M(e), o, Obj::BYTES, start, len, "byte region")) memcpy(buf, o->bytes() + start, (size_t)len);
 }
 void m_SetByteArrayRegion(JNIEnv* e, jbyteArray a, jsize start, jsize len, const jbyte* buf) {
   M(e)->enter("SetByteArrayRegion");
   Obj* o = M(e)->deref(a, "SetByteArrayRegion");
-  if (o && region_ok(M(e), o->bytes, start, len, "byte region")) memcpy(o->bytes.data() + start, buf, (size_t)len);
+  if (region_ok(M(e), o, Obj::BYTES, start, len, "byte region")) memcpy(o->bytes() + start, buf, (size_t)len);
 }
 void m_SetIntArrayRegion(JNIEnv* e, jintArray a, jsize start, jsize len, const jint* buf) {
   M(e)->enter("SetIntArrayRegion");
   Obj* o = M(e)->deref(a, "SetIntArrayRegion");
-  if (o && region_ok(M(e), o->ints, start, len, "int region")) memcpy(o->ints.data() + start, buf, sizeof(int32_t) * (size_t)len);
+  if (region_ok(M(e), o, Obj::INTS, start, len, "int region")) memcpy(o->ints() + start, buf, sizeof(int32_t) * (size_t)len);
 }
 void m_SetDoubleArrayRegion(JNIEnv* e, jdoubleArray a, jsize start, jsize len, const jdouble* buf) {
   M(e)->enter("SetDoubleArrayRegion");
   Obj* o = M(e)->deref(a, "SetDoubleArrayRegion");
-  if (o && region_ok(M(e), o->doubles, start, len, "double region")) memcpy(o->doubles.data() + start, buf, sizeof(double) * (size_t)len);
+  if (region_ok(M(e), o, Obj::DOUBLES, start, len, "double region")) memcpy(o->doubles() + start, buf, sizeof(double) * (size_t)len);
 }
 jdoubleArray m_NewDoubleArray(JNIEnv* e, jsize len) {
   M(e)->enter("NewDoubleArray");
-  Obj* o = M(e)->vm->make(Obj::DOUBLES);
-  o->doubles.assign((size_t)len, 0.0);
-  return reinterpret_cast<jdoubleArray>(M(e)->hand_out(o));
+  return reinterpret_cast<jdoubleArray>(M(e)->hand_out(M(e)->vm->make_doubles((size_t)len, 0.0)));
 }
 void m_GetLongArrayRegion(JNIEnv* e, jlongArray a, jsize start, jsize len, jlong* buf) {
   M(e)->enter("GetLongArrayRegion");
   Obj* o = M(e)->deref(a, "GetLongArrayRegion");
-  if (o && region_ok(M(e), o->longs, start, len, "long region")) memcpy(buf, o->longs.data() + start, sizeof(int64_t) * (size_t)len);
+  if (region_ok(M(e), o, Obj::LONGS, start, len, "long region")) memcpy(buf, o->longs() + start, sizeof(int64_t) * (size_t)len);
 }
 
 void install_table(Mock& m) {
@@ -403,12 +432,8 @@ void install_vm(MockVM& vm) {
   vm.vm.functions = &vm.itable;
 }
 
-Obj* bytes_obj(MockVM& vm, const uint8_t* p, int64_t n) {
-  Obj* o = vm.make(Obj::BYTES);
-  o->bytes.assign(reinterpret_cast<const int8_t*>(p), reinterpret_cast<const int8_t*>(p) + n);
-  return o;
-}
-void set_field(Obj* holder, const char* name, Obj* value) { holder->field[field_index(name)] = value; }
+Obj* bytes_obj(MockVM& vm, const uint8_t* p, int64_t n) { return vm.make_bytes(p, (size_t)n); }
+void set_field(Obj* holder, const char* name, Obj* value) { holder->fields()[field_index(name)] = value; }
 
 // totals over every env of the VM: [0] local refs handed out, [1] released (DeleteLocalRef, PopLocalFrame, return to
 // Java), [2] -Xcheck:jni-style violations, [3] most local references live at once in one thread, [4] JNI function
@@ -457,16 +482,10 @@ struct PairHmmLib {
 };
 
 Obj* read_class(MockVM& vm) {
-  Obj* c = vm.make(Obj::CLASS);
-  c->name = "org/broadinstitute/gatk/nativebindings/pairhmm/ReadDataHolder";
-  c->class_fields = {"readBases", "readQuals", "insertionGOP", "deletionGOP", "overallGCP"};
-  return c;
+  return vm.make_class("org/broadinstitute/gatk/nativebindings/pairhmm/ReadDataHolder", {"readBases", "readQuals", "insertionGOP", "deletionGOP", "overallGCP"});
 }
 Obj* hap_class(MockVM& vm) {
-  Obj* c = vm.make(Obj::CLASS);
-  c->name = "org/broadinstitute/gatk/nativebindings/pairhmm/HaplotypeDataHolder";
-  c->class_fields = {"haplotypeBases"};
-  return c;
+  return vm.make_class("org/broadinstitute/gatk/nativebindings/pairhmm/HaplotypeDataHolder", {"haplotypeBases"});
 }
 
 }  // namespace
@@ -481,7 +500,8 @@ enum {
   MOCK_NULL_READ_ELEMENT = 16, // readDataArray[0] == null
   MOCK_COMPUTE_AFTER_DONE = 32, // initNative, doneNative, THEN computeLikelihoodsNative (the reference keeps working)
   MOCK_REINIT_TWICE = 64,       // initNative again (same arguments, then the other precision and back) before computing
-  MOCK_LAST_READ_BAD = 128      // NULL_READQUALS / SHORT_QUALS / NULL_READ_ELEMENT hit the LAST read instead of read 0
+  MOCK_LAST_READ_BAD = 128,     // NULL_READQUALS / SHORT_QUALS / NULL_READ_ELEMENT hit the LAST read instead of read 0
+  MOCK_PAUSE_AND_AGAIN = 256    // after the call: MOCKJNI_PAUSE_MS (default 700) of nothing -- an idle JVM -- then the same call again
 };
 
 // Returns 0 = ran without a Java exception, 1 = exception pending after initNative,
@@ -501,29 +521,28 @@ int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_rea
   t_attached = m;   // (a Java thread is attached: GetEnv on it answers)
 
   Obj* read_cls = read_class(vm);
-  if (flags & MOCK_DROP_GCP_FIELD) read_cls->class_fields.erase("overallGCP");
+  if (flags & MOCK_DROP_GCP_FIELD) read_cls->cls()->fields.erase("overallGCP");
   Obj* hap_cls = hap_class(vm);
 
   const int bad = (flags & MOCK_LAST_READ_BAD) ? n_reads - 1 : 0;
-  Obj* reads = vm.make(Obj::OBJARRAY);
+  Obj* reads = vm.make_array((size_t)n_reads);
   for (int r = 0; r < n_reads; r++) {
     const int64_t a = read_off[r], n = read_off[r + 1] - a;
-    Obj* holder = vm.make(Obj::HOLDER);
+    Obj* holder = vm.make_holder();
     set_field(holder, "readBases", bytes_obj(vm, rb + a, n));
     set_field(holder, "readQuals", (r == bad && (flags & MOCK_NULL_READQUALS)) ? nullptr : bytes_obj(vm, rq + a, n));
     set_field(holder, "insertionGOP", bytes_obj(vm, ri + a, (r == bad && (flags & MOCK_SHORT_QUALS)) ? n - 1 : n));
     set_field(holder, "deletionGOP", bytes_obj(vm, rd + a, n));
     set_field(holder, "overallGCP", bytes_obj(vm, rc + a, n));
-    reads->elems.push_back((r == bad && (flags & MOCK_NULL_READ_ELEMENT)) ? nullptr : holder);
+    reads->elems()[r] = (r == bad && (flags & MOCK_NULL_READ_ELEMENT)) ? nullptr : holder;
   }
-  Obj* haps = vm.make(Obj::OBJARRAY);
+  Obj* haps = vm.make_array((size_t)n_haps);
   for (int k = 0; k < n_haps; k++) {
-    Obj* holder = vm.make(Obj::HOLDER);
+    Obj* holder = vm.make_holder();
     set_field(holder, "haplotypeBases", bytes_obj(vm, hb + hap_off[k], hap_off[k + 1] - hap_off[k]));
-    haps->elems.push_back(holder);
+    haps->elems()[k] = holder;
   }
-  Obj* likelihoods = vm.make(Obj::DOUBLES);
-  likelihoods->doubles.assign((size_t)out_len, -12345.0);
+  Obj* likelihoods = vm.make_doubles((size_t)out_len, -12345.0);
 
   int rc_ = 0;
   if (!(flags & MOCK_SKIP_INIT)) {
@@ -541,9 +560,16 @@ int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_rea
     lib.compute(m, reads, haps, likelihoods);
     if (m->pending) rc_ = 2;
   }
+  if (rc_ == 0 && (flags & MOCK_PAUSE_AND_AGAIN)) {
+    const char* pv = getenv("MOCKJNI_PAUSE_MS");
+    std::this_thread::sleep_for(std::chrono::milliseconds(pv ? atoi(pv) : 700));
+    std::fill(likelihoods->doubles(), likelihoods->doubles() + likelihoods->n, -12345.0);
+    lib.compute(m, reads, haps, likelihoods);
+    if (m->pending) rc_ = 2;
+  }
   // (a JVM would have the exception pending on return to Java; doneNative takes no JNI calls)
   lib.done(m);
-  memcpy(out, likelihoods->doubles.data(), sizeof(double) * (size_t)out_len);
+  memcpy(out, likelihoods->doubles(), sizeof(double) * (size_t)out_len);
   if (m->pending) {
     snprintf(exc_class, 256, "%s", m->exc_class.c_str());
     snprintf(exc_msg, 512, "%s", m->exc_msg.c_str());
@@ -559,13 +585,30 @@ int mockjni_run(const char* lib_path, int use_double, int max_threads, int n_rea
 int g_warm_iters = 0;             // mockjni_set_warm_iters: untimed calls per thread in front of mockjni_run_concurrent's timed part
 int64_t g_last_timing[6] = {0};   // the shim's call-time split over the timed part of the last mockjni_run_concurrent
 long g_last_counters[11] = {0};   // collect_counters of the last mockjni_run_concurrent
-struct CallRecord { double ms; int32_t thread, cpu_begin, cpu_end; };
+struct CallRecord { double ms; int32_t thread, cpu_begin, cpu_end; double ghz_begin, ghz_end; };
 std::vector<CallRecord> g_last_calls;   // every timed call of the last mockjni_run_concurrent
+bool g_measure_clock = false;           // mockjni_measure_clock: sample the calling core's clock around every timed call
 std::vector<int> g_affinity;            // mockjni_set_affinity: CPUs the caller threads are bound to (empty: wherever the scheduler puts them)
 void mockjni_set_warm_iters(int n) { g_warm_iters = n < 0 ? 0 : n; }
+void mockjni_measure_clock(int on) { g_measure_clock = on != 0; }
 void mockjni_last_timing(int64_t* out) { for (int i = 0; i < 6; i++) out[i] = g_last_timing[i]; }
 void mockjni_last_counters(long* out) { for (int i = 0; i < 11; i++) out[i] = g_last_counters[i]; }
 void mockjni_set_affinity(const int* cpus, int n) { g_affinity.assign(cpus, cpus + (n > 0 ? n : 0)); }
+// How fast the calling thread's core runs right now: a chain of 30 000 dependent adds (one per clock on any x86 core),
+// ~10 us; returns adds per nanosecond = the core's effective clock in GHz at this moment.
+double core_ghz_now() {
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t x = 1;
+  for (int i = 0; i < 30000; i++) asm volatile("add %1, %0" : "+r"(x) : "r"(x | 1));
+  const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+  return x ? 30000.0 / ns : 0.0;
+}
+// ... of the last mockjni_run_concurrent's timed calls: the calling core's clock just before and just after each call
+int mockjni_last_call_clocks(double* ghz_begin, double* ghz_end, int cap) {
+  const int n = std::min<int>(cap, (int)g_last_calls.size());
+  for (int i = 0; i < n; i++) { ghz_begin[i] = g_last_calls[i].ghz_begin; ghz_end[i] = g_last_calls[i].ghz_end; }
+  return (int)g_last_calls.size();
+}
 // the timed calls of the last mockjni_run_concurrent: wall ms, caller thread, CPU at entry and at return; returns their number
 int mockjni_last_calls(double* ms, int32_t* thread, int32_t* cpu_begin, int32_t* cpu_end, int cap) {
   const int n = std::min<int>(cap, (int)g_last_calls.size());
@@ -595,7 +638,7 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
   std::vector<Obj*> read_holders;
   for (int r = 0; r < n_reads; r++) {
     const int64_t a = read_off[r], n = read_off[r + 1] - a;
-    Obj* holder = vm.make(Obj::HOLDER);
+    Obj* holder = vm.make_holder();
     set_field(holder, "readBases", bytes_obj(vm, rb + a, n));
     set_field(holder, "readQuals", bytes_obj(vm, rq + a, n));
     set_field(holder, "insertionGOP", bytes_obj(vm, ri + a, n));
@@ -603,11 +646,11 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
     set_field(holder, "overallGCP", bytes_obj(vm, rc + a, n));
     read_holders.push_back(holder);
   }
-  Obj* haps = vm.make(Obj::OBJARRAY);
+  Obj* haps = vm.make_array((size_t)n_haps);
   for (int k = 0; k < n_haps; k++) {
-    Obj* holder = vm.make(Obj::HOLDER);
+    Obj* holder = vm.make_holder();
     set_field(holder, "haplotypeBases", bytes_obj(vm, hb + hap_off[k], hap_off[k + 1] - hap_off[k]));
-    haps->elems.push_back(holder);
+    haps->elems()[k] = holder;
   }
   lib.init(m, read_cls, hap_cls, use_double, max_threads);
   if (m->pending) {
@@ -622,10 +665,9 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
   for (int t = 0; t < n_threads; t++) {
     envs.push_back(vm.new_env());
     first[t + 1] = (int)((int64_t)n_reads * (t + 1) / n_threads);
-    Obj* arr = vm.make(Obj::OBJARRAY);
-    for (int r = first[t]; r < first[t + 1]; r++) arr->elems.push_back(read_holders[r]);
-    Obj* res = vm.make(Obj::DOUBLES);
-    res->doubles.assign((size_t)(first[t + 1] - first[t]) * n_haps, -12345.0);
+    Obj* arr = vm.make_array((size_t)(first[t + 1] - first[t]));
+    for (int r = first[t]; r < first[t + 1]; r++) arr->elems()[r - first[t]] = read_holders[r];
+    Obj* res = vm.make_doubles((size_t)(first[t + 1] - first[t]) * n_haps, -12345.0);
     slices.push_back(arr);
     results.push_back(res);
   }
@@ -637,6 +679,8 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   std::mutex t0_mu;
   std::vector<std::vector<CallRecord>> records((size_t)n_threads);
+  const char* spin_env = getenv("MOCKJNI_SPIN_BETWEEN_CALLS_US");
+  const long spin_us = spin_env ? atol(spin_env) : 0;
   std::vector<std::thread> pool;
   for (int t = 0; t < n_threads; t++)
     pool.emplace_back([&, t] {
@@ -660,10 +704,15 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
       records[(size_t)t].reserve((size_t)iters);
       for (int k = 0; k < iters && !envs[t]->pending; k++) {
         const int c0 = sched_getcpu();
+        const double g0 = g_measure_clock ? core_ghz_now() : 0.0;
         const auto a = std::chrono::steady_clock::now();
         lib.compute(envs[t], slices[t], haps, results[t]);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
-        records[(size_t)t].push_back({ms, t, c0, sched_getcpu()});
+        records[(size_t)t].push_back({ms, t, c0, sched_getcpu(), g0, g_measure_clock ? core_ghz_now() : 0.0});
+        if (spin_us > 0) {   // MOCKJNI_SPIN_BETWEEN_CALLS_US: a Java thread that keeps computing between its native calls
+          const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+          while (std::chrono::steady_clock::now() < until) {}
+        }
       }
       t_attached = nullptr;
     });
@@ -695,7 +744,7 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
   lib.done(m);
   int rc_ = 0;
   for (int t = 0; t < n_threads; t++) {
-    memcpy(out + (size_t)first[t] * n_haps, results[t]->doubles.data(), sizeof(double) * results[t]->doubles.size());
+    memcpy(out + (size_t)first[t] * n_haps, results[t]->doubles(), sizeof(double) * results[t]->n);
     if (envs[t]->pending && rc_ == 0) {
       rc_ = 2;
       snprintf(exc_class, 256, "%s", envs[t]->exc_class.c_str());
@@ -738,9 +787,8 @@ int mockjni_run_pdhmm(const char* lib_path, int n_a, int n_b, int max_hap, int m
   t_attached = m;
   JNIEnv* env = &m->env;
   Obj* read_cls = read_class(vm);
-  Obj* hap_cls = vm.make(Obj::CLASS);
-  hap_cls->class_fields = {"haplotypeBases", "haplotypePDBases"};
-  if (flags & MOCKPD_DROP_PDBASES_FIELD) hap_cls->class_fields.erase("haplotypePDBases");
+  Obj* hap_cls = vm.make_class("HaplotypeDataHolder (PDHMM)", {"haplotypeBases", "haplotypePDBases"});
+  if (flags & MOCKPD_DROP_PDBASES_FIELD) hap_cls->cls()->fields.erase("haplotypePDBases");
   int rc_ = 0;
   if (!(flags & MOCKPD_SKIP_INIT)) {
     f_init(env, nullptr, (jclass)m->arg(read_cls), (jclass)m->arg(hap_cls), 0, 1, 0, max_memory_mb);
@@ -749,37 +797,36 @@ int mockjni_run_pdhmm(const char* lib_path, int n_a, int n_b, int max_hap, int m
   }
   if (rc_ == 0 && (flags & MOCKPD_HOLDERS)) {
     const int n_reads = n_a, n_haps = n_b;
-    Obj* reads = vm.make(Obj::OBJARRAY);
+    Obj* reads = vm.make_array((size_t)n_reads);
     for (int r = 0; r < n_reads; r++) {
-      Obj* holder = vm.make(Obj::HOLDER);
+      Obj* holder = vm.make_holder();
       const int64_t n = read_len[r];
       set_field(holder, "readBases", bytes_obj(vm, rb + (int64_t)r * max_read, n));
       set_field(holder, "readQuals", bytes_obj(vm, rq + (int64_t)r * max_read, n));
       set_field(holder, "insertionGOP", bytes_obj(vm, ri + (int64_t)r * max_read, n));
       set_field(holder, "deletionGOP", bytes_obj(vm, rd + (int64_t)r * max_read, n));
       set_field(holder, "overallGCP", bytes_obj(vm, rc + (int64_t)r * max_read, n));
-      reads->elems.push_back(holder);
+      reads->elems()[r] = holder;
     }
-    Obj* haps = vm.make(Obj::OBJARRAY);
+    Obj* haps = vm.make_array((size_t)n_haps);
     for (int k = 0; k < n_haps; k++) {
-      Obj* holder = vm.make(Obj::HOLDER);
+      Obj* holder = vm.make_holder();
       set_field(holder, "haplotypeBases", bytes_obj(vm, hb + (int64_t)k * max_hap, hap_len[k]));
       set_field(holder, "haplotypePDBases", bytes_obj(vm, hp + (int64_t)k * max_hap, hap_len[k]));
-      haps->elems.push_back(holder);
+      haps->elems()[k] = holder;
     }
-    Obj* lik = vm.make(Obj::DOUBLES);
-    lik->doubles.assign((size_t)out_len, -12345.0);
+    Obj* lik = vm.make_doubles((size_t)out_len, -12345.0);
     f_cl(env, nullptr, (jobjectArray)m->arg(reads), (jobjectArray)m->arg(haps), (jdoubleArray)m->arg(lik));
     m->native_return();
     if (m->pending) rc_ = 2;
-    memcpy(out, lik->doubles.data(), sizeof(double) * (size_t)out_len);
+    memcpy(out, lik->doubles(), sizeof(double) * (size_t)out_len);
   } else if (rc_ == 0) {
     const int batch = n_a;
     Obj* arrs[7];
     const uint8_t* src[7] = {hb, hp, rb, rq, ri, rd, rc};
     for (int i = 0; i < 7; i++) arrs[i] = bytes_obj(vm, src[i], (int64_t)batch * (i < 2 ? max_hap : max_read));
-    Obj* hl = vm.make(Obj::LONGS); hl->longs.assign(hap_len, hap_len + batch);
-    Obj* rl = vm.make(Obj::LONGS); rl->longs.assign(read_len, read_len + batch);
+    Obj* hl = vm.make_longs(hap_len, (size_t)batch);
+    Obj* rl = vm.make_longs(read_len, (size_t)batch);
     jdoubleArray res = f_flat(env, nullptr, (jbyteArray)m->arg(arrs[0]), (jbyteArray)m->arg(arrs[1]), (jbyteArray)m->arg(arrs[2]),
                               (jbyteArray)m->arg(arrs[3]), (jbyteArray)m->arg(arrs[4]), (jbyteArray)m->arg(arrs[5]), (jbyteArray)m->arg(arrs[6]),
                               (jlongArray)m->arg(hl), (jlongArray)m->arg(rl), batch, max_hap, max_read);
@@ -787,7 +834,7 @@ int mockjni_run_pdhmm(const char* lib_path, int n_a, int n_b, int max_hap, int m
     m->native_return();
     if (m->pending) rc_ = 2;
     else if (!ro) rc_ = 3;
-    else memcpy(out, ro->doubles.data(), sizeof(double) * (size_t)std::min<size_t>(out_len, ro->doubles.size()));
+    else memcpy(out, ro->doubles(), sizeof(double) * (size_t)std::min<size_t>(out_len, ro->n));
   }
   f_done(env, nullptr);
   m->native_return();
@@ -822,8 +869,7 @@ int mockjni_run_sw(const char* lib_path, const uint8_t* ref, int ref_len, const 
   JNIEnv* env = &m->env;
   Obj* jref = bytes_obj(vm, ref, ref_len);
   Obj* jalt = bytes_obj(vm, alt, alt_len);
-  Obj* jcig = vm.make(Obj::BYTES);
-  jcig->bytes.assign((size_t)cigar_len, 0);
+  Obj* jcig = vm.make_bytes(nullptr, (size_t)cigar_len);
   int rc_ = 0;
   if (!(flags & SW_SKIP_INIT)) {
     f_init(env, nullptr);
@@ -832,7 +878,7 @@ int mockjni_run_sw(const char* lib_path, const uint8_t* ref, int ref_len, const 
   }
   const auto t0 = std::chrono::steady_clock::now();
   for (int k = 0; k < iters && rc_ == 0; k++) {
-    std::fill(jcig->bytes.begin(), jcig->bytes.end(), 0);  // the Java wrapper allocates a fresh array per call
+    memset(jcig->bytes(), 0, jcig->n);  // the Java wrapper allocates a fresh array per call
     *offset = f_align(env, nullptr, (flags & SW_NULL_REF) ? nullptr : (jbyteArray)m->arg(jref), (jbyteArray)m->arg(jalt),
                       (jbyteArray)m->arg(jcig), match, mismatch, open, extend, (jbyte)strategy);
     m->native_return();
@@ -841,7 +887,7 @@ int mockjni_run_sw(const char* lib_path, const uint8_t* ref, int ref_len, const 
   if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   f_done(env, nullptr);
   m->native_return();
-  memcpy(cigar_out, jcig->bytes.data(), (size_t)cigar_len);
+  memcpy(cigar_out, jcig->bytes(), (size_t)cigar_len);
   if (m->pending) {
     snprintf(exc_class, 256, "%s", m->exc_class.c_str());
     snprintf(exc_msg, 512, "%s", m->exc_msg.c_str());
@@ -871,10 +917,10 @@ int mockjni_run_sw_batch(const char* lib_path, int n, const uint8_t* refs, const
   JNIEnv* env = &m->env;
   Obj* jrefs = bytes_obj(vm, refs, ref_off[n]);
   Obj* jalts = bytes_obj(vm, alts, alt_off[n]);
-  Obj* jro = vm.make(Obj::LONGS); jro->longs.assign(ref_off, ref_off + n + 1);
-  Obj* jao = vm.make(Obj::LONGS); jao->longs.assign(alt_off, alt_off + n + 1);
-  Obj* jcig = vm.make(Obj::BYTES); jcig->bytes.assign((size_t)n * stride, 0);
-  Obj* joff = vm.make(Obj::INTS); joff->ints.assign((size_t)n, -777);
+  Obj* jro = vm.make_longs(ref_off, (size_t)n + 1);
+  Obj* jao = vm.make_longs(alt_off, (size_t)n + 1);
+  Obj* jcig = vm.make_bytes(nullptr, (size_t)n * stride);
+  Obj* joff = vm.make_ints((size_t)n, -777);
   int rc_ = 0;
   f_init(env, nullptr);
   m->native_return();
@@ -887,8 +933,8 @@ int mockjni_run_sw_batch(const char* lib_path, int n, const uint8_t* refs, const
   }
   f_done(env, nullptr);
   m->native_return();
-  memcpy(cigars_out, jcig->bytes.data(), (size_t)n * stride);
-  memcpy(offsets_out, joff->ints.data(), sizeof(int32_t) * (size_t)n);
+  memcpy(cigars_out, jcig->bytes(), (size_t)n * stride);
+  memcpy(offsets_out, joff->ints(), sizeof(int32_t) * (size_t)n);
   if (m->pending) {
     snprintf(exc_class, 256, "%s", m->exc_class.c_str());
     snprintf(exc_msg, 512, "%s", m->exc_msg.c_str());
@@ -932,21 +978,21 @@ int mockjni_selfcheck() {
   auto fresh = [](MockVM& vm) { install_vm(vm); return vm.new_env(); };
   {
     MockVM vm; Mock* a = fresh(vm); Mock* b = vm.new_env();
-    Obj* arr = vm.make(Obj::OBJARRAY);
+    Obj* arr = vm.make_array(0);
     jobject la = a->hand_out(arr);
     std::thread([&] { b->adopt(); gkljni::GetArrayLength(&b->env, (jarray)la); }).join();
     if (vm.violations == 1 && vm.first_violation.find("does not own it") != std::string::npos) got |= 1;
   }
   {
     MockVM vm; Mock* a = fresh(vm);
-    Obj* arr = vm.make(Obj::OBJARRAY);
+    Obj* arr = vm.make_array(0);
     jobject la = a->hand_out(arr);
     std::thread([&] { gkljni::GetArrayLength(&a->env, (jarray)la); }).join();
     if (vm.violations == 1 && vm.first_violation.find("does not belong") != std::string::npos) got |= 2;
   }
   {
     MockVM vm; Mock* a = fresh(vm);
-    Obj* arr = vm.make(Obj::OBJARRAY);
+    Obj* arr = vm.make_array(0);
     gkljni::PushLocalFrame(&a->env, 4);
     jobject la = a->hand_out(arr);
     gkljni::PopLocalFrame(&a->env, nullptr);
@@ -955,7 +1001,7 @@ int mockjni_selfcheck() {
   }
   {
     MockVM vm; Mock* a = fresh(vm);
-    Obj* arr = vm.make(Obj::OBJARRAY);
+    Obj* arr = vm.make_array(0);
     for (int i = 0; i < 16; i++) a->hand_out(arr);
     const bool clean = vm.violations == 0;
     a->hand_out(arr);
@@ -974,11 +1020,11 @@ double mockjni_selfbench(int n_reads, int len) {
   JNIEnv* env = &m->env;
   static const char* names[5] = {"readBases", "readQuals", "insertionGOP", "deletionGOP", "overallGCP"};
   std::vector<uint8_t> bytes((size_t)len, 7);
-  Obj* reads = vm.make(Obj::OBJARRAY);
+  Obj* reads = vm.make_array((size_t)n_reads);
   for (int r = 0; r < n_reads; r++) {
-    Obj* holder = vm.make(Obj::HOLDER);
+    Obj* holder = vm.make_holder();
     for (const char* n : names) set_field(holder, n, bytes_obj(vm, bytes.data(), len));
-    reads->elems.push_back(holder);
+    reads->elems()[r] = holder;
   }
   jfieldID fid[5];
   for (int i = 0; i < 5; i++) fid[i] = reinterpret_cast<jfieldID>((intptr_t)field_index(names[i]) + 1);

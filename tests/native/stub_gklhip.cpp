@@ -16,7 +16,7 @@
 #include "../../include/gkl_hip_pairhmm.h"
 
 namespace {
-std::atomic<long> g_inits{0}, g_dones{0}, g_computes{0}, g_live{0};
+std::atomic<long> g_inits{0}, g_dones{0}, g_computes{0}, g_live{0}, g_releases{0};
 std::atomic<long> g_fail_from{0}, g_fail_count{0};   // computes [from, from + count) (1-based, counted from stub_reset) fail with GKLHIP_ERR_HIP
 std::atomic<long> g_delay_us{0};
 std::atomic<int> g_skip{0};   // stub_skip_arithmetic: gklhip_compute only counts (timing of the JNI layer alone)
@@ -71,11 +71,14 @@ int gklhip_compute(gklhip_ctx* c, const gklhip_batch* b, double* out) {
   return GKLHIP_OK;
 }
 
+int gklhip_release_idle(gklhip_ctx* c, int32_t* n) { if (n) *n = c ? 1 : 0; g_releases++; return GKLHIP_OK; }
+
 // test controls
-void stub_reset(void) { g_inits = g_dones = g_computes = 0; g_fail_from = g_fail_count = 0; g_delay_us = 0; g_skip = 0; }
+void stub_reset(void) { g_inits = g_dones = g_computes = 0; g_releases = 0; g_fail_from = g_fail_count = 0; g_delay_us = 0; g_skip = 0; }
 void stub_fail(long from, long count) { g_fail_from = from; g_fail_count = count; }
 void stub_delay_us(long us) { g_delay_us = us; }
 void stub_skip_arithmetic(int on) { g_skip = on; }
 void stub_counts(long out[4]) { out[0] = g_inits; out[1] = g_dones; out[2] = g_computes; out[3] = g_live; }
+long stub_releases(void) { return g_releases; }
 
 }  // extern "C"

@@ -50,9 +50,34 @@ def test_bench_line_single_gpu():
     assert "error" not in j, j
     for k in ("c2", "c2_max_threads_4", "c1"):
         assert j[k]["ms_per_call"] > 0 and j[k]["marshal_ms"] >= 0 and j[k]["compute_wait_ms"] >= 0 and j[k]["writeback_ms"] >= 0
+    for k in ("c2", "c2_max_threads_4"):
+        # median of >= 30 calls with its spread, the JNI-call budget per read, nothing -Xcheck:jni would flag
+        assert j[k]["calls"] >= 30 and j[k]["p10_ms"] <= j[k]["ms_per_call"] <= j[k]["p90_ms"]
+        assert j[k]["jni_calls_per_read"] <= 14 and j[k]["xcheck_violations"] == 0
+    assert 0 < j["mock_ns_per_jni_call"] < 100
+    # BASELINE config 5 (PDHMM) and SURVEY 8 f4 (Smith-Waterman) in the same line, each with its kernel time, a roofline
+    # fraction that follows from it, and the reference's own kernel on the host beside it
+    pd = d["pdhmm"]
+    assert "error" not in pd, pd
+    for k in ("cross", "paired", "region_276x48_single_call"):
+        r = pd[k]["roofline"]
+        assert pd[k]["kernel_ms"] > 0 and pd[k]["cells"] > 0
+        assert abs(r["achieved"] - 12 * pd[k]["cells"] / pd[k]["kernel_ms"] / 1e9) < 0.02 * r["achieved"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert pd["cross"]["cells"] == pd["paired"]["cells"] == 32 * pd["region_276x48_single_call"]["cells"]
+    assert pd["cpu_baseline"]["kind"] == "reference" and pd["cpu_baseline"]["value"] > 0 and pd["cpu_baseline"]["cores"] >= 1
+    # GATK calls PDHMM per region from many JVMs, like PairHMM: P processes x one caller of fixture-sized regions
+    rp = pd["region_processes"]
+    assert "error" not in rp, rp
+    assert all(rp[f"processes_{n}"]["aggregate_gcups"] > 0 and rp[f"processes_{n}"]["p50_ms"] > 0 for n in (4, 8))
+    sw = d["sw"]
+    assert "error" not in sw, sw
+    r = sw["batch"]["roofline"]
+    assert sw["batch"]["kernel_ms"] > 0 and abs(r["achieved"] - 20 * sw["batch"]["cells"] / sw["batch"]["kernel_ms"] / 1e9) < 0.02 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and sw["batch"]["cpu_baseline"]["kind"] == "reference" and sw["batch"]["cpu_baseline"]["value"] > 0
     # maxNumberOfThreads is a cap on the host log10 threads: the line says what each setting costs
     assert all(d["host_path"][k]["ms_per_call"] > 0 for k in ("max_threads_1", "max_threads_4", "max_threads_auto"))
     assert d["comm"]["ranks_seen"] == 1 and d["comm"]["backend"] == "none" and d["comm"]["gather_bytes_per_rank"] == []
+    assert len(d["comm"]["per_rank"]) == 1 and d["comm"]["imbalance"] == 1.0 and d["comm"]["per_rank"][0]["cells"] == d["config"]["cells_per_gpu"]
     conc = d["small_batch"]["concurrent"]
     assert all(conc[f"callers_{n}"]["aggregate_gcups"] > 0 for n in (1, 4, 16))
     # the deployment GATK produces: P processes x one caller on the one GPU
@@ -60,6 +85,7 @@ def test_bench_line_single_gpu():
     assert "error" not in pr, pr
     for n in (4, 8, 16):
         assert pr[f"processes_{n}"]["aggregate_gcups"] > 0 and 0 < pr[f"processes_{n}"]["p50_ms"] <= pr[f"processes_{n}"]["p99_ms"]
+        assert "first_call_after_idle_ms" in pr[f"processes_{n}"] and "calls_over_5ms" in pr[f"processes_{n}"]
     er = d["small_batch"]["eighth_device_resident"]
     assert "error" not in er and er["two_streams_one_context_ms_per_step"] > 0
 
@@ -87,6 +113,27 @@ def test_bench_line_two_ranks_on_one_gpu():
     assert c["backend"] == "gloo" and c["ranks_seen"] == 2 and c["world_size"] == 2
     assert len(c["gather_bytes_per_rank"]) == 2 and sum(c["gather_bytes_per_rank"]) == 600 * 24 * 8
     assert c["in_library_gather"]["backend"] == "peer" and c["in_library_gather"]["devices"] == 2
+    # every rank's own numbers: the first thing to read when N GPUs land under the expected scaling
+    assert [r["rank"] for r in c["per_rank"]] == [0, 1] and c["imbalance"] < 1.1 and c["time_imbalance"] >= 1.0
+    for r in c["per_rank"]:
+        assert r["cells"] > 0 and r["ms_per_step"] > 0 and r["fwd_main_ms"] > 0 and r["reads"] > 0
+        assert r["ms_per_step"] <= d["ms_per_step"] * 1.001          # the line's time is the slowest rank's
+    assert sum(r["reads"] for r in c["per_rank"]) == 600
+
+
+@pytest.mark.gpu
+def test_bench_c2_split_is_balanced_and_dry_comm_builds_the_group_only():
+    """The C2 batch cut in two (the library's partition rule): cells within 10 % of each other; `--dry-comm` only builds
+    the group, runs one gather of the real sizes and prints `comm` -- the first thing to run on a new multi-GPU node."""
+    env = dict(os.environ, GKL_BENCH_SAME_DEVICE="1", GKL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-comm"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    c = _line(p.stdout)["comm"]
+    assert c["dry"] is True and c["ranks_seen"] == 2 and len(c["per_rank"]) == 2 and c["imbalance"] < 1.1
+    assert sum(r["reads"] for r in c["per_rank"]) == 10000 and sum(c["gather_bytes_per_rank"]) == 10000 * 128 * 8
+    assert all(r["first_gather_ms"] > 0 for r in c["per_rank"])
 
 
 def test_bench_without_a_launcher_starts_the_launcher_cpu():

@@ -71,12 +71,32 @@ def test_pipelined_call_with_and_without_helper_threads(stub, monkeypatch, max_t
         assert rc == 0 and out.tobytes() == mockjni.stub_expected(big).tobytes() and k[VIOLATIONS] == 0, (cls, msg)
         assert k[HELPER_JNI_CALLS] > 13 * 300, k
         assert k[ATTACHES] == k[DETACHES] == 3 and k[GLOBALS_CREATED] == k[GLOBALS_DELETED] == 8
-    # growing ranges with a descending tail
-    monkeypatch.setenv("GKL_HIP_JNI_RANGE_PAIRS", "240")
-    monkeypatch.setenv("GKL_HIP_JNI_RANGE_GROWTH", "1.7")
-    monkeypatch.setenv("GKL_HIP_JNI_RANGE_LAST", "360")
-    rc, out, cls, msg, k = run(b, max_threads=max_threads)
-    assert rc == 0 and out.tobytes() == exp.tobytes() and k[VIOLATIONS] == 0, (cls, msg)
+    # the default schedules (4/32/32/32 with helpers, 4/12/28/36/14/6 without; small ranges merged) and explicit shares
+    monkeypatch.delenv("GKL_HIP_JNI_RANGE_PAIRS")
+    for sh in (None, "6,47,47", "1,1,1,1,96", "100"):
+        if sh:
+            monkeypatch.setenv("GKL_HIP_JNI_RANGE_SHARES", sh)
+        rc, out, cls, msg, k = run(b, max_threads=max_threads)
+        assert rc == 0 and out.tobytes() == exp.tobytes() and k[VIOLATIONS] == 0, (sh, cls, msg)
+
+
+def test_default_range_schedule_follows_the_marshalling_threads(stub, monkeypatch):
+    """plan_ranges (jni_shim.cpp): 10 000 x 128 -> four ranges with helper threads, six without; a 2000 x 100 call (200k
+    pairs) -> three / two ranges (ranges below 40k / 60k pairs are merged with their neighbour)."""
+    monkeypatch.setenv("GKL_HIP_JNI_PIPELINE_PAIRS", "1")
+    stub.stub_skip_arithmetic(1)
+    try:
+        n = (mockjni.C.c_long * 4)()
+        for reads, haps, mt, ranges in ((10000, 128, 4, 4), (10000, 128, 1, 6), (10000, 128, 2, 6), (2000, 100, 4, 3), (2000, 100, 1, 2), (300, 100, 1, 1)):
+            b = make_batch("hc", reads, haps, seed=11)
+            stub.stub_reset()
+            stub.stub_skip_arithmetic(1)
+            rc, _, cls, msg, k = run(b, max_threads=mt)
+            assert rc == 0 and k[VIOLATIONS] == 0, (cls, msg)
+            stub.stub_counts(n)
+            assert n[2] == ranges, (reads, haps, mt, n[2])
+    finally:
+        stub.stub_reset()
 
 
 def test_helper_threads_serve_consecutive_and_concurrent_calls(stub, monkeypatch):
@@ -147,6 +167,33 @@ def test_a_hip_failure_is_retried_once_on_fresh_contexts(stub, monkeypatch, capf
     stub.stub_reset()
     rc, out, cls, msg, _ = run(b)
     assert rc == 0 and out.tobytes() == exp.tobytes()            # the library is usable afterwards
+
+
+def test_an_idle_slot_gives_back_its_second_engine_and_streams(stub, monkeypatch):
+    """An idle JVM that once sent a big batch must not keep the device queues of its pipelined engines (the device's
+    scheduler rotates every process's queues: docs/NOTES.md 49, 55): after GKL_HIP_IDLE_RELEASE_MS without a call the
+    slot's second context and compute threads go and the first is asked to release what it holds for speed; the next
+    call simply makes them again."""
+    monkeypatch.setenv("GKL_HIP_JNI_PIPELINE_PAIRS", "1")
+    monkeypatch.setenv("GKL_HIP_IDLE_RELEASE_MS", "150")
+    monkeypatch.setenv("MOCKJNI_PAUSE_MS", "900")
+    b = make_batch("hc", 400, 10, seed=12)
+    stub.stub_reset()
+    # (the janitor thread reads GKL_HIP_IDLE_RELEASE_MS when the process's first initNative starts it: a fresh process)
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests import mockjni\nfrom gkl_amd.synth import make_batch\n"
+            "lib = mockjni.build_stub(); b = make_batch('hc', 400, 10, seed=12)\n"
+            "rc, out, cls, msg, k = mockjni.run(b, lib_path=mockjni.STUB_LIB, flags=mockjni.PAUSE_AND_AGAIN, max_threads=2)\n"
+            "n = (mockjni.C.c_long * 4)(); lib.stub_counts(n); lib.stub_releases.restype = mockjni.C.c_long\n"
+            "print(rc, (out == mockjni.stub_expected(b)).all(), k[mockjni.VIOLATIONS], n[0], n[1], n[3], lib.stub_releases())\n") % mockjni.ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1500:]
+    rc, ok, viol, inits, dones, live, releases = p.stdout.split()[-7:]
+    assert (rc, ok, viol) == ("0", "True", "0")
+    # two contexts for the first call, the second one given back while idle and made again by the second call: 3 made
+    assert (int(inits), int(dones), int(live)) == (3, 3, 0) and int(releases) >= 1
 
 
 def test_mock_flags_what_xcheck_jni_would():

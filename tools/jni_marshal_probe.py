@@ -40,9 +40,9 @@ def measure(tag, iters=30, warm=6, max_threads=1, affinity=None, env=None):
         old[k] = os.environ.get(k)
         os.environ[k] = str(v)
     try:
-        t, calls, k = [], [], []
+        t, calls, k, clocks = [], [], [], []
         rc, _, cls, msg, wall = mockjni.run_concurrent(b, 1, iters=iters, warm=warm, max_threads=max_threads, timing=t, calls=calls, counters=k,
-                                                       affinity=affinity)
+                                                       affinity=affinity, clocks=clocks)
     finally:
         for kk, v in old.items():
             if v is None:
@@ -57,6 +57,7 @@ def measure(tag, iters=30, warm=6, max_threads=1, affinity=None, env=None):
     rec = {"tag": tag, "max_threads": max_threads, "env": env or {}, "median_ms": round(float(np.median(ms)), 3),
            "p10_ms": round(float(np.percentile(ms, 10)), 3), "p90_ms": round(float(np.percentile(ms, 90)), 3), "max_ms": round(float(ms.max()), 3),
            "marshal_ms": round(t[0] / t[4] / 1e6, 3), "wait_ms": round(t[1] / t[4] / 1e6, 3), "writeback_ms": round(t[2] / t[4] / 1e6, 3),
+           "core_ghz_before_call": round(float(np.median([c[0] for c in clocks])), 2), "core_ghz_after_call": round(float(np.median([c[1] for c in clocks])), 2),
            "caller_cpus": cpus, "caller_nodes": sorted({n for n, cl in nodes.items() for c in cpus if c in cl}),
            "helper_share_of_jni_calls": round(k[mockjni.HELPER_JNI_CALLS] / max(1, k[mockjni.JNI_CALLS]), 3), "violations": k[mockjni.VIOLATIONS]}
     print(json.dumps(rec), flush=True)
@@ -75,6 +76,34 @@ if "placement" in what:
             measure(f"caller on the main thread's node {main_node} #{rep}", affinity=nodes[main_node])
             measure(f"caller on the other node {other} #{rep}", affinity=nodes[other])
         measure("caller on ONE cpu of the main node", affinity=[c for c in nodes[main_node] if c != main_cpu][:1])
+if "numa" in what and len(nodes) > 1:
+    # the holders are built (first touched) by the main thread inside every measure(): put IT on a node, then the caller on
+    # the same / the other one; marshalling on the calling thread only, so marshal_ms is all of it
+    everything = sorted(os.sched_getaffinity(0))
+    for heap_node in sorted(nodes):
+        os.sched_setaffinity(0, nodes[heap_node])
+        for caller_node in sorted(nodes):
+            for rep in range(3):
+                measure(f"holders built on node {heap_node}, caller on node {caller_node} #{rep}", iters=20, warm=4, affinity=nodes[caller_node],
+                        env={"GKL_HIP_JNI_MARSHAL_THREADS": 1})
+    os.sched_setaffinity(0, everything)
+if "clock" in what:
+    # is marshal_ms the calling core's clock?  (a thread that works 4 ms of every 15 and sleeps the rest)
+    for rep in range(8):
+        measure(f"clock #{rep}", iters=20, warm=4, env={"GKL_HIP_JNI_MARSHAL_THREADS": 1})
+    for rep in range(4):
+        measure(f"clock, caller spins between calls #{rep}", iters=20, warm=4, env={"GKL_HIP_JNI_MARSHAL_THREADS": 1, "MOCKJNI_SPIN_BETWEEN_CALLS_US": 3000})
+if "spin" in what:
+    # do the library's own waiting threads (two engines in hipStreamSynchronize: HIP spins by default) slow the marshalling thread?
+    # (one process per setting: the flag is read when the device is first opened -- run as  GKL_HIP_SCHEDULE=blocking tools/jni_marshal_probe.py spin)
+    for rep in range(8):
+        measure(f"GKL_HIP_SCHEDULE={os.environ.get('GKL_HIP_SCHEDULE', 'default (spin)')} #{rep}", iters=20, warm=4, env={"GKL_HIP_JNI_MARSHAL_THREADS": 1})
+if "shares" in what:
+    lists = ("4,12,28,36,14,6", "6,30,40,18,6", "5,25,35,25,10", "8,40,40,12", "3,9,22,30,22,10,4", "4,32,32,32", "4,20,36,30,10", "10,30,30,20,10")
+    for mt in (1, 4):
+        for rep in range(2):
+            for sh in lists:
+                measure(f"shares {sh}", max_threads=mt, iters=24, warm=4, env={"GKL_HIP_JNI_RANGE_SHARES": sh})
 if "threads" in what:
     for mt in (1, 2, 4, 8):
         measure(f"max_threads {mt}", max_threads=mt)
