@@ -695,6 +695,36 @@ __global__ __launch_bounds__(256) void lds_oob_selftest_kernel(uint32_t* out) {
   if (lds[threadIdx.x] == 0) atomicOr(out, 0x80000000u);   // (keeps the stores above alive)
 }
 
+// The same question in the shape of the kernels with the biggest allocations (r05 advisor): the super-stripe kernel's
+// 512 threads and ~78 KB of LDS (two such workgroups fill a CU's 160 KB, so a neighbour's LDS lies right behind this one's),
+// the wide kernels' 128-256 threads and up to 128 KB.  kWords 32-bit words, every byte non-zero; each
+// wavefront reads what a separator lane of its 10 KB table region reads.  Launched with enough workgroups to fill every
+// CU several times over.  (Static allocation, like the kernels it stands for.)
+template <int kWords, int kThreads>
+__global__ __launch_bounds__(kThreads) void lds_oob_selftest_big_kernel(uint32_t* out) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[kWords];
+  constexpr int words = kWords;
+  for (int i = threadIdx.x; i < words; i += blockDim.x) lds_dyn[i] = 0x5A5A0000u | (uint32_t)(i & 0xffff) | 1u;
+  __syncthreads();
+  const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const uint32_t region = ((uint32_t)words * 4u / waves) & ~15u;
+  const uint32_t loff = (uint32_t)(uintptr_t)lds_dyn + wave * region + (threadIdx.x & 63u) * 16u;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int shift = 9; shift <= 11; shift++) {
+    const uint32_t addr = (512u << shift) + loff;
+    uint32_t v0, v1, v2, v3, w0, w1, w2, w3, x0, x1;
+    asm volatile("ds_read_b128 v[40:43], %10\n\tds_read_b128 v[44:47], %10 offset:1024\n\tds_read_b64 v[48:49], %10\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 "v_mov_b32 %0, v40\n\tv_mov_b32 %1, v41\n\tv_mov_b32 %2, v42\n\tv_mov_b32 %3, v43\n\t"
+                 "v_mov_b32 %4, v44\n\tv_mov_b32 %5, v45\n\tv_mov_b32 %6, v46\n\tv_mov_b32 %7, v47\n\tv_mov_b32 %8, v48\n\tv_mov_b32 %9, v49"
+                 : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3), "=v"(x0), "=v"(x1)
+                 : "v"(addr) : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "memory");
+    acc |= v0 | v1 | v2 | v3 | w0 | w1 | w2 | w3 | x0 | x1;
+  }
+  if (acc) atomicOr(out, acc);
+  if (lds_dyn[threadIdx.x] == 0) atomicOr(out, 0x80000000u);   // (keeps the stores above alive)
+}
+
 // ---- diagnostics: the VALU issue ceiling of the forward recurrence's instruction mix ----------------------------
 // Eight "cells" of 4 multiplies + 4 fused multiply-adds per loop iteration, operands in registers chosen so that no
 // three-source op has all sources in one VGPR bank (even / odd), four wavefronts per SIMD on every CU: what the chip

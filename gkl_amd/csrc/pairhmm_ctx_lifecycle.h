@@ -103,6 +103,10 @@ int dev_init(const gklhip_config& cfg, int dev, int ndev, DevCtx** out) {
       bool ok = hipMemsetAsync(d_out, 0, 12, c->stream) == hipSuccess;
       hipLaunchKernelGGL(flush_selftest_kernel, dim3(1), dim3(1), 0, c->stream, d_out, f_den, d_den);
       hipLaunchKernelGGL(lds_oob_selftest_kernel, dim3(1024), dim3(256), 0, c->stream, d_out + 2);
+      // ... and in the shapes of the biggest allocations: the super-stripe kernel's (512 threads, 78 KB: two per CU, a neighbour's
+      // LDS right behind) and the wide kernels' (256 threads, 128 KB: one per CU), every CU loaded four times over
+      hipLaunchKernelGGL((lds_oob_selftest_big_kernel<78 * 256, 512>), dim3(4 * 2 * (unsigned)c->n_cus), dim3(512), 0, c->stream, d_out + 2);
+      hipLaunchKernelGGL((lds_oob_selftest_big_kernel<128 * 256, 256>), dim3(4 * (unsigned)c->n_cus), dim3(256), 0, c->stream, d_out + 2);
       ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(h_out, d_out, 12, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
            hipStreamSynchronize(c->stream) == hipSuccess;
       (void)hipFree(d_out);

@@ -31,8 +31,10 @@ class WorkerPool {
   // Exceptions (a slice's vector growing under memory pressure, a thread that cannot be created) never unwind
   // through a worker thread: the pool runs with the threads it has, a failing slice is remembered, every slice is
   // waited for, and the failure is re-thrown on the calling thread (the C ABI maps it to GKLHIP_ERR_OOM).
-  void parallel_for(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn) {
-    if (threads <= 1 || n < 16384) { fn(0, n); return; }
+  // (min_n: below this many items the hand-off to the workers costs more than it saves -- 16384 log10f's; the PDHMM
+  //  library's fp64 log10 of a region's 13k pairs already pays at 4096)
+  void parallel_for(int64_t n, int threads, const std::function<void(int64_t, int64_t)>& fn, int64_t min_n = 16384) {
+    if (threads <= 1 || n < min_n) { fn(0, n); return; }
     try { ensure(threads - 1); } catch (...) {}
     threads = std::min(threads, (int)workers_.size() + 1);
     if (threads <= 1) { fn(0, n); return; }

@@ -154,3 +154,33 @@ def test_forced_lds_selftest_failure_keeps_the_fp32_general_steps_in_cxx(oracle,
             assert np.array_equal(u, ou) and r32.tobytes() == o32.tobytes()
             assert r64[u == 1].tobytes() == o64[ou == 1].tobytes()
             assert out.tobytes() == oo.tobytes() == ref.tobytes()
+
+
+def test_an_idle_context_gives_back_its_streams_and_twin_engines_and_works_on(native, oracle):
+    """gklhip_release_idle (what the JNI library's janitor calls for a slot unused for a second): after a 410k-pair host
+    call -- twin engines, upload / copy streams -- and a device-resident call on a second stream (a second engine set) the
+    context gives them back, and the calls after that -- small, big, device-resident -- return the same bits as before."""
+    import torch
+    big = make_batch("hc", 3200, 128, seed=3)
+    small = make_batch("hc", 100, 10, seed=4)
+    with native.PairHmmContext() as c:
+        ref_big = c.compute(big).copy()
+        ref_small = c.compute(small).copy()
+        assert np.array_equal(bits(ref_small), bits(oracle.batch(small, n_threads=4)))
+        db = native.DeviceBatch.upload(small, "cuda:0")
+        s2 = torch.cuda.Stream()
+        dev0 = c.compute_device(db)                    # the caller's current stream: first engine set
+        with torch.cuda.stream(s2):
+            dev1 = c.compute_device(db, None, s2)      # another stream while the first set is that stream's: second engine set
+        torch.cuda.synchronize()
+        assert torch.equal(dev0, dev1)
+        first = c.release_idle()
+        assert first >= 1, first                       # at least the twin engine's stream
+        assert c.release_idle() == 0                   # nothing left to give
+        assert np.array_equal(bits(c.compute(small)), bits(ref_small))
+        assert np.array_equal(bits(c.compute(big)), bits(ref_big))     # (makes the twin engine again)
+        with torch.cuda.stream(s2):
+            dev2 = c.compute_device(db, None, s2)
+        torch.cuda.synchronize()
+        assert torch.equal(dev1, dev2)
+        assert c.release_idle() >= 1

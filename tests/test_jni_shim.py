@@ -194,6 +194,26 @@ def test_jni_retries_a_failed_call_once_on_a_fresh_context(oracle, monkeypatch, 
     assert rc == 0 and out.tobytes() == exp.tobytes()
 
 
+@pytest.mark.gpu
+def test_jni_idle_slot_releases_its_second_engine_and_computes_again(oracle):
+    """The JNI library's janitor (GKL_HIP_IDLE_RELEASE_MS): a pipelined call, 0.9 s of nothing -- the slot's second context,
+    compute threads and extra streams go -- and the same call again: the oracle's bits both times (a fresh process: the
+    janitor reads its setting when the first initNative starts it)."""
+    import subprocess
+    import sys
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "import numpy as np\nfrom tests import mockjni\nfrom gkl_amd.synth import make_batch\nfrom oracle.oracle import Oracle\n"
+            "b = make_batch('hc', 400, 24, seed=77)\n"
+            "rc, out, cls, msg, k = mockjni.run(b, flags=mockjni.PAUSE_AND_AGAIN, max_threads=2)\n"
+            "h = (C.c_int64 * 5)(); C.CDLL(mockjni.JNI_LIB).gkl_pairhmm_jni_helpers(h, 0)\n"
+            "print(rc, out.tobytes() == Oracle().batch(b, n_threads=8).tobytes(), k[mockjni.VIOLATIONS], h[4])\n") % ROOT
+    env = dict(os.environ, GKL_HIP_JNI_PIPELINE_PAIRS="1", GKL_HIP_JNI_RANGE_PAIRS="2400", GKL_HIP_IDLE_RELEASE_MS="150", MOCKJNI_PAUSE_MS="900")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-1500:]
+    rc, same, viol, released = p.stdout.split()[-4:]
+    assert (rc, same, viol) == ("0", "True", "0") and int(released) >= 1, p.stdout
+
+
 def _check_jni_onload(monkeypatch, have_gpu):
     # JNI_OnLoad (not in the reference): JNI_ERR without a usable gfx950 device, so that System.load fails and
     # NativeLibraryLoader.load() returns false (GATK then falls back); JNI_VERSION_1_8 with one, or when forced

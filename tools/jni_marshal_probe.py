@@ -98,6 +98,12 @@ if "spin" in what:
     # (one process per setting: the flag is read when the device is first opened -- run as  GKL_HIP_SCHEDULE=blocking tools/jni_marshal_probe.py spin)
     for rep in range(8):
         measure(f"GKL_HIP_SCHEDULE={os.environ.get('GKL_HIP_SCHEDULE', 'default (spin)')} #{rep}", iters=20, warm=4, env={"GKL_HIP_JNI_MARSHAL_THREADS": 1})
+if "shards" in what:
+    # ranges of >= 400k pairs are cut in two by the C ABI's twin engines (GKL_HIP_HOST_SHARDS, default 2): good or bad inside a pipelined call?
+    for rep in range(3):
+        for mt in (1, 4):
+            for hs in (2, 1):
+                measure(f"GKL_HIP_HOST_SHARDS={hs}", max_threads=mt, iters=24, warm=4, env={"GKL_HIP_HOST_SHARDS": hs})
 if "shares" in what:
     lists = ("4,12,28,36,14,6", "6,30,40,18,6", "5,25,35,25,10", "8,40,40,12", "3,9,22,30,22,10,4", "4,32,32,32", "4,20,36,30,10", "10,30,30,20,10")
     for mt in (1, 4):
