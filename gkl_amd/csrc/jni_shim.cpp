@@ -189,6 +189,7 @@ struct Pipeline {
 // library starts has no JNIEnv: it attaches to the JVM once (as a daemon: it never keeps the JVM alive), keeps its env
 // for the life of the slot and detaches when the slot goes (doneNative, a re-configuration, process exit).  What it may
 // touch: GLOBAL references only (the calling thread's jobjectArray is a local reference of THAT thread).
+std::atomic<bool> g_process_exiting{false};   // set by the process-wide state's destructor: the JVM may be gone -- no JNI call from then on
 struct MarshalHelpers {
   JavaVM* vm = nullptr;
   std::mutex mu;
@@ -221,7 +222,9 @@ struct MarshalHelpers {
         }
         live--;
         l.unlock();
-        gkljni::DetachCurrentThread(vm);
+        // (not at process exit: static destructors run after the JVM has shut down, and the invocation interface of a
+        //  destroyed VM must not be called -- the thread simply ends)
+        if (!g_process_exiting.load()) gkljni::DetachCurrentThread(vm);
       });
     }
     std::unique_lock<std::mutex> l(mu);
@@ -302,6 +305,7 @@ struct State {
   bool janitor_quit = false;
   int64_t idle_release_ns = 1000000000LL;
   ~State() {
+    g_process_exiting = true;
     { std::lock_guard<std::mutex> l(mu); janitor_quit = true; }
     janitor_wake.notify_all();
     if (janitor.joinable()) janitor.join();
