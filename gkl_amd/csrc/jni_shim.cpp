@@ -258,6 +258,7 @@ struct Slot {
   bool busy = false;
   int64_t idle_since = 0;              // when the last call returned it (steady clock, ns)
   bool idle_released = false;          // the janitor has been through it since then
+  bool with_janitor = false;           // leased by the janitor right now (doneNative waits for it: milliseconds)
   int gen = 0;  // configuration generation (initNative with other arguments starts a new one)
   gklhip_config cfg;  // what `ctx` was created with: the second engine of a pipelined call gets the same
   ~Slot() {
@@ -532,7 +533,7 @@ struct SlotLease {
     {
       std::lock_guard<std::mutex> lock(g.mu);
       s->busy = false;
-      if (janitor) s->idle_released = true;
+      if (janitor) { s->idle_released = true; s->with_janitor = false; }
       else { s->idle_since = now_ns(); s->idle_released = false; }
       if (s->gen != g.gen)  // initNative changed the configuration while this call ran: the slot is not reused
         for (auto it = g.slots.begin(); it != g.slots.end(); ++it)
@@ -574,7 +575,8 @@ void janitor_loop() {
     for (auto& s : g.slots)
       if (!s->busy && !s->idle_released && now - s->idle_since >= g.idle_release_ns) { pick = s.get(); break; }
     if (!pick) continue;
-    pick->busy = true;   // leased like a caller would: nobody else touches it, doneNative / initNative skip it
+    pick->busy = true;   // leased like a caller would: nobody else touches it, initNative skips it, doneNative waits for it
+    pick->with_janitor = true;
     lock.unlock();
     {
       SlotLease lease{pick, true};
@@ -914,7 +916,9 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_doneNative(JNIEnv
   // helper threads -- they detach from the JVM) and keeps the configuration, so a later call simply gets a fresh slot.
   std::vector<std::unique_ptr<Slot>> dead;   // destroyed (streams synchronised, buffers freed) after the lock is released
   {
-    std::lock_guard<std::mutex> lock(g.mu);
+    std::unique_lock<std::mutex> lock(g.mu);
+    // (a slot the janitor is tidying right now is idle, not in use: it goes too, once the janitor has let go of it)
+    g.slot_free.wait(lock, [] { for (auto& s : g.slots) if (s->with_janitor) return false; return true; });
     for (auto it = g.slots.begin(); it != g.slots.end();) {
       if (!(*it)->busy) { dead.push_back(std::move(*it)); it = g.slots.erase(it); }
       else ++it;
