@@ -851,7 +851,7 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
         if (!ok) break;
         submitted++;
         g_helpers[2]++;
-        while (RangeTask* d = sl->pipe->take_done(false)) retire(d);
+        while (RangeTask* d = sl->pipe->take_done(false)) retire(d);   // (an exception in here: the range is counted, see retire)
       }
     } catch (...) {
       pending_cxx = std::current_exception();
@@ -861,7 +861,7 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pairhmm_IntelPairHmm_computeLikelihood
       const int64_t t0 = now_ns();
       RangeTask* d = sl->pipe->take_done(true);   // NULL: no helper is marshalling any more and nothing is finished right now
       ns_wait += now_ns() - t0;
-      if (d) { try { retire(d); } catch (...) { if (!pending_cxx) pending_cxx = std::current_exception(); finished++; } continue; }
+      if (d) { try { retire(d); } catch (...) { if (!pending_cxx) pending_cxx = std::current_exception(); } continue; }   // (retire counts the range first thing)
       if (finished >= submitted.load()) break;
       // (helpers are done, ranges are still computing: wait for one)
       const int64_t t1 = now_ns();
