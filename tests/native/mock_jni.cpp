@@ -44,8 +44,9 @@ constexpr int kMaxFields = 8;
 
 // A Java-heap object: an 8-byte header with the payload right behind it, bump-allocated from the VM's heap chunks in the
 // order the harness creates them -- a read's holder and its five byte[] lie next to each other like objects a Java thread
-// allocates in its TLAB (r06: the first slot-based mock still kept every object as a ~280-byte struct of std::vectors, a
-// 150 MB graph for the C2 batch whose cache and TLB misses were most of the "marshalling" time; this heap is 10 MB).
+// allocates in its TLAB (the first slot-based mock of this round still kept every object as a ~280-byte struct of
+// std::vectors, a 150 MB graph for the C2 batch whose cache and TLB misses were most of the "marshalling" time; this
+// heap is 10 MB: docs/NOTES.md 54).
 struct ClassInfo { std::string name; std::set<std::string> fields; };
 struct Obj {
   enum Kind : uint32_t { CLASS, BYTES, DOUBLES, LONGS, INTS, OBJARRAY, HOLDER } kind;
