@@ -24,6 +24,7 @@ struct EnvSwitches {
   const int fb_wanted_jobs = integer("GKLHIP_FB_WANTED_JOBS");
   const int plan_blocks = integer("GKLHIP_PLAN_BLOCKS");
   const int finalize_threads = integer("GKL_HIP_FINALIZE_THREADS");
+  const int finalize_min = integer("GKL_HIP_FINALIZE_MIN");   // one-pass host log10: pairs from which it is spread over the workers (0: the built-in 8192)
   const bool combine = [] { const char* v = getenv("GKL_HIP_COMBINE"); return !(v && v[0] == '0'); }();
   const bool quiet = getenv("GKL_HIP_QUIET") != nullptr;
   const bool one_device_engine = integer("GKL_HIP_DEVICE_ENGINES") == 1;

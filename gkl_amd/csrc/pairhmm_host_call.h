@@ -304,6 +304,10 @@ int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
   // the early pass skips every word that is not fp32-tagged, whatever it holds at that moment).
   const HostCallInFlight in_flight;
   const int threads = finalize_threads(c, in_flight.share);
+  // one-pass finalisation (calls up to kOnePassPairs): a region of 400 reads x 40 haplotypes is 16 000 log10's = 0.08 ms
+  // on one thread, a fifth of the call -- spread over the workers from 8192 pairs on (400 x 40: 0.416 -> 0.378 ms; at 4096
+  // the hand-off costs a 150 x 30 call more than it saves: 0.236 -> 0.245; tools/mid_finalize_ab.py)
+  const int64_t one_pass_min = g_env.finalize_min > 0 ? g_env.finalize_min : 8192;
   HostFinalizer fin;
   // (a context with an asynchronous device-resident call still in flight keeps the stream-ordered path)
   SmallLaunch small;
@@ -316,7 +320,7 @@ int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
     const int64_t t_staged = SmallCombiner::now_ns();
     if ((rc = k->run(small, s))) return rc;
     const int64_t t_done = SmallCombiner::now_ns();
-    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads, one_pass_min);
     k->ns_stage.fetch_add(t_staged - t_call, std::memory_order_relaxed);
     k->ns_run.fetch_add(t_done - t_staged, std::memory_order_relaxed);
     k->ns_finalize.fetch_add(SmallCombiner::now_ns() - t_done, std::memory_order_relaxed);
@@ -326,7 +330,7 @@ int dev_compute_host_impl(DevCtx* c, const gklhip_batch* hb, double* out_host) {
     // all-fp64 mode, or a GATK-sized call (the fp64 stage of a region without underflowed pairs -- the usual case --
     // is two launches that find nothing to do): one pass over the words once the last kernel is done
     HIP_TRY(hipStreamSynchronize(s));
-    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads);
+    c->stats.n_fallback = fin.all(&c->workers, c->res_pin.as<uint64_t>(), out_host, n_pairs, threads, one_pass_min);
     return GKLHIP_OK;
   }
   HIP_TRY(hipEventSynchronize(c->policy_done));

@@ -127,7 +127,7 @@ struct HostFinalizer {
     return log10(d) - ld;
   }
 
-  int64_t all(WorkerPool* pool, const uint64_t* packed, double* out, int64_t n, int threads) const {
+  int64_t all(WorkerPool* pool, const uint64_t* packed, double* out, int64_t n, int threads, int64_t min_n = 16384) const {
     std::atomic<int64_t> n64{0};
     const std::function<void(int64_t, int64_t)> work = [&](int64_t lo, int64_t hi) {
       int64_t cnt = 0;
@@ -138,7 +138,7 @@ struct HostFinalizer {
       }
       n64 += cnt;
     };
-    pool->parallel_for(n, threads, work);
+    pool->parallel_for(n, threads, work, min_n);
     return n64.load();
   }
   void early(WorkerPool* pool, const uint64_t* packed, double* out, int64_t n, int threads) {
