@@ -146,16 +146,17 @@ def jni_records(batch, c1, host_ms, host_ms_4=None):
     from tests import mockjni
     rec = {}
 
-    def one(b, iters, warm, threads=1, max_threads=1):
+    def one(b, iters, warm, threads=1, max_threads=1, call_cost_ns=0.0):
         t, calls, k = [], [], []
-        rc, _, cls, msg, wall = mockjni.run_concurrent(b, threads, iters=iters, warm=warm, timing=t, max_threads=max_threads, calls=calls, counters=k)
+        rc, _, cls, msg, wall = mockjni.run_concurrent(b, threads, iters=iters, warm=warm, timing=t, max_threads=max_threads, calls=calls, counters=k,
+                                                       call_cost_ns=call_cost_ns)
         if rc != 0:
             raise RuntimeError(f"mock JNI run failed: {cls} {msg}")
         return wall, t, max(t[4], 1), calls, k
 
-    def big(max_threads, host):
-        iters, warm = 36, 6   # (the first pipelined calls of a slot still grow its pinned arenas and start its helper threads)
-        wall, t, calls, per_call, k = one(batch, iters, warm, max_threads=max_threads)
+    def big(max_threads, host, call_cost_ns=0.0, iters=36):
+        warm = 6   # (the first pipelined calls of a slot still grow its pinned arenas and start its helper threads)
+        wall, t, calls, per_call, k = one(batch, iters, warm, max_threads=max_threads, call_cost_ns=call_cost_ns)
         ms = np.array([c[0] for c in per_call])
         med = float(np.median(ms))
         return {"ms_per_call": round(med, 3), "p10_ms": round(float(np.percentile(ms, 10)), 3), "p90_ms": round(float(np.percentile(ms, 90)), 3),
@@ -169,6 +170,9 @@ def jni_records(batch, c1, host_ms, host_ms_4=None):
                 "over_host_path": round(med / host, 3) if host else None}
     rec["c2"] = big(1, host_ms)
     rec["c2_max_threads_4"] = big(4, host_ms_4)
+    # the same with every JNI function costing 25 ns more -- the order of a HotSpot function's thread-state transitions, which
+    # the mock does not have: 131 000 calls = 3.3 ms more marshalling per call, on one thread or spread over four
+    rec["c2_jni_calls_25ns_slower"] = {"max_threads_1": big(1, host_ms, call_cost_ns=25.0, iters=20), "max_threads_4": big(4, host_ms_4, call_cost_ns=25.0, iters=20)}
     wall, t, calls, _, _ = one(c1, 200, 30)
     ms = wall / 200
     rec["c1"] = {"ms_per_call": round(ms, 4), "gcups": round(c1.cells / ms / 1e6, 1),
@@ -177,7 +181,11 @@ def jni_records(batch, c1, host_ms, host_ms_4=None):
     try:
         lib = C.CDLL(mockjni.SO)
         lib.mockjni_selfbench.restype = C.c_double
+        lib.mockjni_set_call_cost_ns.restype = C.c_double
         rec["mock_ns_per_jni_call"] = round(min(lib.mockjni_selfbench(4000, 150) for _ in range(3)), 1)
+        lib.mockjni_set_call_cost_ns(C.c_double(25.0))
+        rec["c2_jni_calls_25ns_slower"]["mock_ns_per_jni_call"] = round(min(lib.mockjni_selfbench(4000, 150) for _ in range(3)), 1)
+        lib.mockjni_set_call_cost_ns(C.c_double(0.0))
     except (OSError, AttributeError):
         pass
     conc = {}

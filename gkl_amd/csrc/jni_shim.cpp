@@ -427,10 +427,13 @@ MarshalError marshal_haps(JNIEnv* env, jobjectArray haps, const FieldIds& f, Pin
 // What the schedule trades (measured on the 10 000 x 128 batch, tools/jni_marshal_probe.py, docs/NOTES.md 54): the first
 // range's marshalling is the only part nothing overlaps with -- small first range; a range is one gklhip_compute, and
 // small ones use the chip badly (nine ranges of 150k pairs: 13.7 ms of GPU time for 11.7 ms of work) -- few, big
-// ranges; what follows the last kernel (the fp64 pairs' log10 on the host, the write-back) is proportional to the last
-// range, and with ONE marshalling thread the big ranges arrive late anyway -- a descending tail there.
-//   marshalling threads >= 3:  4 / 32 / 32 / 32 per cent of the reads          (10k x 128: 13.0-13.1 ms per call)
-//   fewer:                     4 / 12 / 28 / 36 / 14 / 6                       (14.1-14.3 ms; r05's equal 150k ranges: 14.9-15.3)
+// ranges; the GPU must not run dry while the big ranges are still being marshalled -- sizes that GROW (a thread marshals
+// whole ranges, so helpers shorten the queue of ranges, not one range); what follows the last kernel (the fp64 pairs'
+// log10 on the host, the write-back) is proportional to the last range -- a descending tail:
+//   4 / 12 / 28 / 36 / 14 / 6 per cent of the reads, whatever the number of marshalling threads.
+// With the mock JVM's 5 ns JNI functions every schedule of 4-8 ranges measures the same (13.3-13.4 ms at four threads,
+// 13.7-14.0 at one); with 25 ns more per function -- a real JVM's order -- this one holds (13.3-13.9 / 13.9-14.2) where
+// 4 / 32 / 32 / 32 leaves the GPU waiting for its second range (14.0-14.3 / 15.2-16.6).  r05's equal 150k ranges: 14.9-15.3.
 // A range below 40 000 pairs (the first) / 60 000 pairs (the others) is merged with its neighbour: a call of 200k pairs
 // becomes two ranges.  GKL_HIP_JNI_RANGE_SHARES="a,b,c" sets the per cents, GKL_HIP_JNI_RANGE_PAIRS=n asks for equal
 // ranges of n pairs (tests force many small ranges with it); both are read per call.
@@ -459,9 +462,9 @@ std::vector<jsize> plan_ranges(jsize n_reads, jsize n_haps, int marshal_threads)
   }
   if (shares.empty()) {
     floors = true;
-    if (marshal_threads >= 3) shares = {4, 32, 32, 32};
-    else shares = {4, 12, 28, 36, 14, 6};
+    shares = {4, 12, 28, 36, 14, 6};
   }
+  (void)marshal_threads;
   double total = 0;
   for (double v : shares) total += v;
   const double floor_first = 40000.0 / std::max<jsize>(1, n_haps), floor_rest = 60000.0 / std::max<jsize>(1, n_haps);   // in reads

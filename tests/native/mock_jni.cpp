@@ -73,6 +73,10 @@ int field_index(const char* name) {
   return (int)g_names.size() - 1;
 }
 
+// What a JNI function costs on top of the mock's own few nanoseconds: 0 by default; bench.py also measures with 25 ns -- the
+// order of a HotSpot JNI function's native -> VM -> native transition -- to show what a real JVM's slower calls do to the call.
+uint64_t g_call_cost_ticks = 0;
+
 struct Mock;
 struct MockVM {
   JavaVM_ vm;                  // must be first: JavaVM* == MockVM*
@@ -151,6 +155,10 @@ struct Mock {
   void violation(const std::string& what) { vm->violation(what); }
   void enter(const char* fn, bool pending_ok = false) {
     jni_calls++;
+    if (g_call_cost_ticks) {   // mockjni_set_call_cost_ns: every JNI function costs at least this (a JVM's thread-state transition)
+      const uint64_t until = __builtin_ia32_rdtsc() + g_call_cost_ticks;
+      while (__builtin_ia32_rdtsc() < until) {}
+    }
     if (std::this_thread::get_id() != owner) violation(std::string(fn) + ": JNIEnv used on a thread it does not belong to");
     if (detached) violation(std::string(fn) + ": JNIEnv of a detached thread");
     if (pending && !pending_ok) violation(std::string(fn) + " called with an exception pending (" + exc_class + ")");
@@ -591,6 +599,19 @@ std::vector<CallRecord> g_last_calls;   // every timed call of the last mockjni_
 bool g_measure_clock = false;           // mockjni_measure_clock: sample the calling core's clock around every timed call
 std::vector<int> g_affinity;            // mockjni_set_affinity: CPUs the caller threads are bound to (empty: wherever the scheduler puts them)
 void mockjni_set_warm_iters(int n) { g_warm_iters = n < 0 ? 0 : n; }
+// every JNI function of the mock takes at least `ns` nanoseconds from now on (0: off); returns the TSC ticks per nanosecond it measured
+double mockjni_set_call_cost_ns(double ns) {
+  static double ticks_per_ns = 0.0;
+  if (ticks_per_ns == 0.0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint64_t c0 = __builtin_ia32_rdtsc();
+    while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 2000.0) {}
+    const uint64_t c1 = __builtin_ia32_rdtsc();
+    ticks_per_ns = (double)(c1 - c0) / std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+  }
+  g_call_cost_ticks = ns > 0 ? (uint64_t)(ns * ticks_per_ns) : 0;
+  return ticks_per_ns;
+}
 void mockjni_measure_clock(int on) { g_measure_clock = on != 0; }
 void mockjni_last_timing(int64_t* out) { for (int i = 0; i < 6; i++) out[i] = g_last_timing[i]; }
 void mockjni_last_counters(long* out) { for (int i = 0; i < 11; i++) out[i] = g_last_counters[i]; }

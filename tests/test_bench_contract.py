@@ -55,6 +55,10 @@ def test_bench_line_single_gpu():
         assert j[k]["calls"] >= 30 and j[k]["p10_ms"] <= j[k]["ms_per_call"] <= j[k]["p90_ms"]
         assert j[k]["jni_calls_per_read"] <= 14 and j[k]["xcheck_violations"] == 0
     assert 0 < j["mock_ns_per_jni_call"] < 100
+    # ... and what a JVM's slower JNI functions (+25 ns each) would do to the same call: still pipelined behind the kernels
+    slow = j["c2_jni_calls_25ns_slower"]
+    assert slow["mock_ns_per_jni_call"] >= 25 and slow["max_threads_1"]["ms_per_call"] > 0 and slow["max_threads_4"]["ms_per_call"] > 0
+    assert slow["max_threads_1"]["marshal_ms"] > j["c2"]["marshal_ms"]
     # BASELINE config 5 (PDHMM) and SURVEY 8 f4 (Smith-Waterman) in the same line, each with its kernel time, a roofline
     # fraction that follows from it, and the reference's own kernel on the host beside it
     pd = d["pdhmm"]

@@ -71,7 +71,7 @@ def test_pipelined_call_with_and_without_helper_threads(stub, monkeypatch, max_t
         assert rc == 0 and out.tobytes() == mockjni.stub_expected(big).tobytes() and k[VIOLATIONS] == 0, (cls, msg)
         assert k[HELPER_JNI_CALLS] > 13 * 300, k
         assert k[ATTACHES] == k[DETACHES] == 3 and k[GLOBALS_CREATED] == k[GLOBALS_DELETED] == 8
-    # the default schedules (4/32/32/32 with helpers, 4/12/28/36/14/6 without; small ranges merged) and explicit shares
+    # the default schedule (4/12/28/36/14/6; small ranges merged) and explicit shares
     monkeypatch.delenv("GKL_HIP_JNI_RANGE_PAIRS")
     for sh in (None, "6,47,47", "1,1,1,1,96", "100"):
         if sh:
@@ -80,14 +80,14 @@ def test_pipelined_call_with_and_without_helper_threads(stub, monkeypatch, max_t
         assert rc == 0 and out.tobytes() == exp.tobytes() and k[VIOLATIONS] == 0, (sh, cls, msg)
 
 
-def test_default_range_schedule_follows_the_marshalling_threads(stub, monkeypatch):
-    """plan_ranges (jni_shim.cpp): 10 000 x 128 -> four ranges with helper threads, six without; a 2000 x 100 call (200k
-    pairs) -> three / two ranges (ranges below 40k / 60k pairs are merged with their neighbour)."""
+def test_default_range_schedule(stub, monkeypatch):
+    """plan_ranges (jni_shim.cpp): 10 000 x 128 -> six ranges (4 / 12 / 28 / 36 / 14 / 6 per cent) with or without helper
+    threads; a 2000 x 100 call (200k pairs) -> two ranges (ranges below 40k / 60k pairs are merged with their neighbour)."""
     monkeypatch.setenv("GKL_HIP_JNI_PIPELINE_PAIRS", "1")
     stub.stub_skip_arithmetic(1)
     try:
         n = (mockjni.C.c_long * 4)()
-        for reads, haps, mt, ranges in ((10000, 128, 4, 4), (10000, 128, 1, 6), (10000, 128, 2, 6), (2000, 100, 4, 3), (2000, 100, 1, 2), (300, 100, 1, 1)):
+        for reads, haps, mt, ranges in ((10000, 128, 4, 6), (10000, 128, 1, 6), (2000, 100, 4, 2), (2000, 100, 1, 2), (300, 100, 1, 1)):
             b = make_batch("hc", reads, haps, seed=11)
             stub.stub_reset()
             stub.stub_skip_arithmetic(1)

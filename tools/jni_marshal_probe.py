@@ -42,7 +42,7 @@ def measure(tag, iters=30, warm=6, max_threads=1, affinity=None, env=None):
     try:
         t, calls, k, clocks = [], [], [], []
         rc, _, cls, msg, wall = mockjni.run_concurrent(b, 1, iters=iters, warm=warm, max_threads=max_threads, timing=t, calls=calls, counters=k,
-                                                       affinity=affinity, clocks=clocks)
+                                                       affinity=affinity, clocks=clocks, call_cost_ns=float(os.environ.get("PROBE_CALL_COST_NS", "0")))
     finally:
         for kk, v in old.items():
             if v is None:
@@ -98,6 +98,13 @@ if "spin" in what:
     # (one process per setting: the flag is read when the device is first opened -- run as  GKL_HIP_SCHEDULE=blocking tools/jni_marshal_probe.py spin)
     for rep in range(8):
         measure(f"GKL_HIP_SCHEDULE={os.environ.get('GKL_HIP_SCHEDULE', 'default (spin)')} #{rep}", iters=20, warm=4, env={"GKL_HIP_JNI_MARSHAL_THREADS": 1})
+if "cost" in what:
+    # schedules against what a JNI function costs (PROBE_CALL_COST_NS: every mock function at least that long)
+    lists = ("4,32,32,32", "4,12,28,36,14,6", "3,6,12,24,30,17,8", "2,4,8,16,28,26,12,4")
+    for rep in range(2):
+        for mt in (1, 4):
+            for sh in lists:
+                measure(f"cost {os.environ.get('PROBE_CALL_COST_NS', '0')} ns, shares {sh}", max_threads=mt, iters=20, warm=4, env={"GKL_HIP_JNI_RANGE_SHARES": sh})
 if "shards" in what:
     # ranges of >= 400k pairs are cut in two by the C ABI's twin engines (GKL_HIP_HOST_SHARDS, default 2): good or bad inside a pipelined call?
     for rep in range(3):
