@@ -105,6 +105,11 @@ if "cost" in what:
         for mt in (1, 4):
             for sh in lists:
                 measure(f"cost {os.environ.get('PROBE_CALL_COST_NS', '0')} ns, shares {sh}", max_threads=mt, iters=20, warm=4, env={"GKL_HIP_JNI_RANGE_SHARES": sh})
+if "plain" in what:
+    # nothing varied: the default call, a few times (compare processes started with different runtime settings, e.g. GPU_MAX_HW_QUEUES=8)
+    for rep in range(3):
+        for mt in (1, 4):
+            measure(f"plain, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}", max_threads=mt, iters=24, warm=4)
 if "shards" in what:
     # ranges of >= 400k pairs are cut in two by the C ABI's twin engines (GKL_HIP_HOST_SHARDS, default 2): good or bad inside a pipelined call?
     for rep in range(3):
