@@ -283,6 +283,17 @@ def pdhmm_records(dev_index, fixture_x=32):
         rec["region_276x48_single_call"] = {"workload": "ONE computeLikelihoodsNative call of the fixture: 276 reads x 48 haplotypes = 13 248 pairs",
                                             "cells": cells1, "ms_per_call": round(ms1, 4), "gcups": round(cells1 / ms1 / 1e6, 1),
                                             "kernel_ms": round(k1, 4), "roofline": roof("pdhmm_fwd_tab_kernel", k1, cells1)}
+    # ... and through IntelPDHMM.computeLikelihoodsNative itself (mock JVM): marshalling of the 276 + 48 holders included
+    try:
+        from tests import mockjni
+        _, jout, jms, jcalls = mockjni.time_pdhmm_holders(r1, hb, iters=60)
+        _, _, jms25, _ = mockjni.time_pdhmm_holders(r1, hb, iters=40, call_cost_ns=25.0)
+        rec["jni_region_276x48"] = {"ms_per_call": round(jms, 4), "jni_calls_per_call": round(jcalls, 1), "gcups": round(cells1 / jms / 1e6, 1),
+                                    "ms_per_call_with_25ns_more_per_jni_call": round(jms25, 4),
+                                    "note": "IntelPDHMM.computeLikelihoodsNative on the fixture's holders through the mock JVM: 13 JNI calls per read, "
+                                            "7 per haplotype (r05: 40 and 16), one local frame per 32 holders"}
+    except Exception as e:
+        rec["jni_region_276x48"] = {"error": repr(e)}
     # the same pairs as padded 1:1 arrays (computePDHMMNative): pair (r, h) = read r with its own copy of haplotype h
     ri, hi = np.repeat(np.arange(r1.batch), hb.batch), np.tile(np.arange(hb.batch), r1.batch)
     hsub, rsub = hb.subset(hi), r1.subset(ri)

@@ -1,7 +1,10 @@
 // JNI drop-in layer of libgkl_pdhmm.so: the four natives of com.intel.gkl.pdhmm.IntelPDHMM
 // (include/gkl_pdhmm_jni.h) over the C ABI of include/gkl_hip_pdhmm.h.  Replaces the reference's
 // IntelPDHMM.cc + JavaData.h; arrays are copied with Get<T>ArrayRegion (no critical sections held
-// across GPU work), every pair goes through the same (vector-arithmetic) kernel.
+// across GPU work), every pair goes through the same (vector-arithmetic) kernel.  The holders of
+// computeLikelihoodsNative are marshalled like the PairHMM shim's (jni_shim.cpp: marshal_reads): 13 JNI calls per
+// read and 7 per haplotype inside a local frame per 32 holders (r05: 40 and 16, plus seven heap vectors per holder --
+// for the fixture's 276 x 48 region more JNI time in a real JVM than the 0.3 ms the call itself takes).
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -24,6 +27,8 @@ inline jint ThrowNew(JNIEnv* e, jclass c, const char* m) { return e->ThrowNew(c,
 inline void ExceptionClear(JNIEnv* e) { e->ExceptionClear(); }
 inline jboolean ExceptionCheck(JNIEnv* e) { return e->ExceptionCheck(); }
 inline void DeleteLocalRef(JNIEnv* e, jobject o) { e->DeleteLocalRef(o); }
+inline jint PushLocalFrame(JNIEnv* e, jint capacity) { return e->PushLocalFrame(capacity); }
+inline jobject PopLocalFrame(JNIEnv* e, jobject result) { return e->PopLocalFrame(result); }
 inline jfieldID GetFieldID(JNIEnv* e, jclass c, const char* n, const char* s) { return e->GetFieldID(c, n, s); }
 inline jobject GetObjectField(JNIEnv* e, jobject o, jfieldID f) { return e->GetObjectField(o, f); }
 inline jsize GetArrayLength(JNIEnv* e, jarray a) { return e->GetArrayLength(a); }
@@ -96,19 +101,54 @@ std::shared_ptr<gklhip_pdhmm_ctx> context(JNIEnv* env, const char* who) {
   return g.ctx;
 }
 
-// holder[i].<field> -> bytes; false after throwing
-bool read_field(JNIEnv* env, jobjectArray arr, jsize i, jfieldID fid, std::vector<int8_t>& dst) {
-  jobject holder = gkljni::GetObjectArrayElement(env, arr, i);
-  if (gkljni::ExceptionCheck(env)) return false;
-  if (!holder) { throw_java(env, kIAE, "null element in data holder array"); return false; }
-  jbyteArray bytes = (jbyteArray)gkljni::GetObjectField(env, holder, fid);
-  if (!bytes) { gkljni::DeleteLocalRef(env, holder); throw_java(env, kIAE, "null byte[] field in data holder"); return false; }
-  const jsize len = gkljni::GetArrayLength(env, bytes);
-  dst.resize((size_t)len);
-  if (len > 0) gkljni::GetByteArrayRegion(env, bytes, 0, len, reinterpret_cast<jbyte*>(dst.data()));
-  gkljni::DeleteLocalRef(env, bytes);
-  gkljni::DeleteLocalRef(env, holder);
-  return !gkljni::ExceptionCheck(env);
+// PushLocalFrame / PopLocalFrame around a block of holders (also when a C++ exception passes through)
+struct LocalFrame {
+  JNIEnv* env;
+  bool pushed;
+  LocalFrame(JNIEnv* e, jint capacity) : env(e), pushed(gkljni::PushLocalFrame(e, capacity) == 0) {
+    if (!pushed) gkljni::ExceptionClear(env);   // (PushLocalFrame raised OutOfMemoryError)
+  }
+  ~LocalFrame() { if (pushed) gkljni::PopLocalFrame(env, nullptr); }
+  LocalFrame(const LocalFrame&) = delete;
+};
+constexpr jsize kFrameHolders = 32;
+
+// The byte[] fields `fids[0..n_fields)` of holders[0..n): field f of holder i -> flat[f][off[i] .. off[i+1]) (unpadded, one
+// growing array per field), the length of a holder = the length of its FIRST field (JavaData.h:190-196: readBases /
+// haplotypeBases); an array shorter than that surfaces as the region copy's ArrayIndexOutOfBoundsException and is
+// reported as IllegalArgumentException(`short_msg`), an empty first field as `empty_msg`.  Per holder: the element,
+// n_fields fields, one length, n_fields region copies, one exception check.  False after throwing.
+bool marshal_holders(JNIEnv* env, jobjectArray holders, jsize n, const jfieldID* fids, int n_fields, std::vector<int8_t>* flat,
+                     std::vector<int64_t>& off, const char* empty_msg, const char* short_msg) {
+  off.assign((size_t)n + 1, 0);
+  for (int f = 0; f < n_fields; f++) flat[f].clear();
+  for (jsize b0 = 0; b0 < n; b0 += kFrameHolders) {
+    const jsize b1 = std::min<jsize>(n, b0 + kFrameHolders);
+    const char* err = nullptr;
+    {
+      LocalFrame frame(env, 8 * kFrameHolders);
+      if (!frame.pushed) { throw_java(env, kOOM, "Memory allocation issue."); return false; }
+      for (jsize i = b0; i < b1 && !err; i++) {
+        jobject holder = gkljni::GetObjectArrayElement(env, holders, i);
+        if (!holder) { err = "null element in data holder array"; break; }
+        jbyteArray arr[8];
+        for (int f = 0; f < n_fields; f++) {
+          arr[f] = (jbyteArray)gkljni::GetObjectField(env, holder, fids[f]);
+          if (!arr[f]) err = "null byte[] field in data holder";
+        }
+        if (err) break;
+        const jsize len = gkljni::GetArrayLength(env, arr[0]);
+        if (len == 0) { err = empty_msg; break; }
+        const size_t at = (size_t)off[(size_t)i];
+        for (int f = 0; f < n_fields; f++) flat[f].resize(at + (size_t)len);   // (space for all first: see jni_shim.cpp)
+        for (int f = 0; f < n_fields; f++) gkljni::GetByteArrayRegion(env, arr[f], 0, len, reinterpret_cast<jbyte*>(flat[f].data() + at));
+        if (gkljni::ExceptionCheck(env)) { gkljni::ExceptionClear(env); err = short_msg; break; }
+        off[(size_t)i + 1] = off[(size_t)i] + len;
+      }
+    }
+    if (err) { throw_java(env, kIAE, err); return false; }
+  }
+  return true;
 }
 }  // namespace
 
@@ -159,27 +199,18 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNat
       throw_java(env, kIAE, "likelihoodArray length must be equal to readDataArray length * haplotypeDataArray length");
       return;
     }
-    std::vector<std::vector<int8_t>> rb(n_reads), rq(n_reads), ri(n_reads), rd(n_reads), rc(n_reads), hb(n_haps), hp(n_haps);
+    std::vector<int8_t> rflat[5], hflat[2];
+    std::vector<int64_t> roff, hoff;
+    const jfieldID rf[5] = {g.readBases, g.readQuals, g.insertionGOP, g.deletionGOP, g.overallGCP};
+    const jfieldID hf[2] = {g.haplotypeBases, g.haplotypePDBases};
+    if (!marshal_holders(env, readDataArray, n_reads, rf, 5, rflat, roff, "empty read or read quality array shorter than readBases",
+                         "empty read or read quality array shorter than readBases") ||
+        !marshal_holders(env, haplotypeDataArray, n_haps, hf, 2, hflat, hoff, "empty haplotype or haplotypePDBases shorter than haplotypeBases",
+                         "empty haplotype or haplotypePDBases shorter than haplotypeBases"))
+      return;
     int max_r = 0, max_h = 0;
-    for (jsize r = 0; r < n_reads; r++) {
-      if (!read_field(env, readDataArray, r, g.readBases, rb[r]) || !read_field(env, readDataArray, r, g.readQuals, rq[r]) ||
-          !read_field(env, readDataArray, r, g.insertionGOP, ri[r]) || !read_field(env, readDataArray, r, g.deletionGOP, rd[r]) ||
-          !read_field(env, readDataArray, r, g.overallGCP, rc[r]))
-        return;
-      const size_t len = rb[r].size();
-      if (len == 0 || rq[r].size() < len || ri[r].size() < len || rd[r].size() < len || rc[r].size() < len) {
-        throw_java(env, kIAE, "empty read or read quality array shorter than readBases");
-        return;
-      }
-      max_r = (int)std::max<size_t>(max_r, len);
-    }
-    for (jsize h = 0; h < n_haps; h++) {
-      if (!read_field(env, haplotypeDataArray, h, g.haplotypeBases, hb[h]) ||
-          !read_field(env, haplotypeDataArray, h, g.haplotypePDBases, hp[h]))
-        return;
-      if (hb[h].empty() || hp[h].size() < hb[h].size()) { throw_java(env, kIAE, "empty haplotype or haplotypePDBases shorter than haplotypeBases"); return; }
-      max_h = (int)std::max<size_t>(max_h, hb[h].size());
-    }
+    for (jsize r = 0; r < n_reads; r++) max_r = (int)std::max<int64_t>(max_r, roff[(size_t)r + 1] - roff[(size_t)r]);
+    for (jsize h = 0; h < n_haps; h++) max_h = (int)std::max<int64_t>(max_h, hoff[(size_t)h + 1] - hoff[(size_t)h]);
     // The reference expands the cross product into padded PAIRS, in batches of min(total, maxMemoryInMB /
     // memoryPerPair) pairs (JavaData.h:83-101,177-242), because computePDHMM takes pairs; every batch ends in its own
     // scalar tail.  Here every read and every haplotype is staged once and the device walks the cross product itself;
@@ -194,15 +225,15 @@ JNIEXPORT void JNICALL Java_com_intel_gkl_pdhmm_IntelPDHMM_computeLikelihoodsNat
         b_rc((size_t)n_reads * max_r, 0);
     std::vector<int64_t> hl((size_t)n_haps), rl((size_t)n_reads);
     for (jsize r = 0; r < n_reads; r++) {
-      const size_t R = rb[r].size();
-      memcpy(&b_rb[(size_t)r * max_r], rb[r].data(), R); memcpy(&b_rq[(size_t)r * max_r], rq[r].data(), R);
-      memcpy(&b_ri[(size_t)r * max_r], ri[r].data(), R); memcpy(&b_rd[(size_t)r * max_r], rd[r].data(), R);
-      memcpy(&b_rc[(size_t)r * max_r], rc[r].data(), R);
+      const size_t at = (size_t)roff[(size_t)r], R = (size_t)(roff[(size_t)r + 1] - roff[(size_t)r]);
+      memcpy(&b_rb[(size_t)r * max_r], rflat[0].data() + at, R); memcpy(&b_rq[(size_t)r * max_r], rflat[1].data() + at, R);
+      memcpy(&b_ri[(size_t)r * max_r], rflat[2].data() + at, R); memcpy(&b_rd[(size_t)r * max_r], rflat[3].data() + at, R);
+      memcpy(&b_rc[(size_t)r * max_r], rflat[4].data() + at, R);
       rl[(size_t)r] = (int64_t)R;
     }
     for (jsize h = 0; h < n_haps; h++) {
-      const size_t H = hb[h].size();
-      memcpy(&b_hb[(size_t)h * max_h], hb[h].data(), H); memcpy(&b_hp[(size_t)h * max_h], hp[h].data(), H);
+      const size_t at = (size_t)hoff[(size_t)h], H = (size_t)(hoff[(size_t)h + 1] - hoff[(size_t)h]);
+      memcpy(&b_hb[(size_t)h * max_h], hflat[0].data() + at, H); memcpy(&b_hp[(size_t)h * max_h], hflat[1].data() + at, H);
       hl[(size_t)h] = (int64_t)H;
     }
     std::vector<double> out((size_t)total);

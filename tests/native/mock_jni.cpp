@@ -781,6 +781,8 @@ int mockjni_run_concurrent(const char* lib_path, int use_double, int max_threads
 
 
 // ---- PDHMM: IntelPDHMM natives (include/gkl_pdhmm_jni.h) ----
+double g_last_pd_ms = 0.0, g_last_pd_jni_calls = 0.0;
+void mockjni_last_pd_call(double* ms, double* jni_calls) { *ms = g_last_pd_ms; *jni_calls = g_last_pd_jni_calls; }
 typedef void (*pd_init_fn)(JNIEnv*, jclass, jclass, jclass, jint, jint, jint, jint);
 typedef jdoubleArray (*pd_flat_fn)(JNIEnv*, jobject, jbyteArray, jbyteArray, jbyteArray, jbyteArray, jbyteArray, jbyteArray,
                                    jbyteArray, jlongArray, jlongArray, jint, jint, jint);
@@ -842,6 +844,24 @@ int mockjni_run_pdhmm(const char* lib_path, int n_a, int n_b, int max_hap, int m
     m->native_return();
     if (m->pending) rc_ = 2;
     memcpy(out, lik->doubles(), sizeof(double) * (size_t)out_len);
+    // MOCKJNI_PD_ITERS=n: the same call n more times, timed one by one (mockjni_last_pd_call: median ms, JNI calls per call)
+    const char* iv = getenv("MOCKJNI_PD_ITERS");
+    if (rc_ == 0 && iv && atoi(iv) > 0) {
+      std::vector<double> ms;
+      const long calls0 = m->jni_calls;
+      for (int k = 0; k < atoi(iv) && !m->pending; k++) {
+        const auto a = std::chrono::steady_clock::now();
+        f_cl(env, nullptr, (jobjectArray)m->arg(reads), (jobjectArray)m->arg(haps), (jdoubleArray)m->arg(lik));
+        m->native_return();
+        ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count());
+      }
+      if (!ms.empty()) {
+        std::sort(ms.begin(), ms.end());
+        g_last_pd_ms = ms[ms.size() / 2];
+        g_last_pd_jni_calls = (double)(m->jni_calls - calls0) / (double)ms.size();
+      }
+      if (m->pending) rc_ = 2;
+    }
   } else if (rc_ == 0) {
     const int batch = n_a;
     Obj* arrs[7];

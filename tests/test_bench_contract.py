@@ -69,6 +69,10 @@ def test_bench_line_single_gpu():
         assert abs(r["achieved"] - 12 * pd[k]["cells"] / pd[k]["kernel_ms"] / 1e9) < 0.02 * r["achieved"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert pd["cross"]["cells"] == pd["paired"]["cells"] == 32 * pd["region_276x48_single_call"]["cells"]
     assert pd["cpu_baseline"]["kind"] == "reference" and pd["cpu_baseline"]["value"] > 0 and pd["cpu_baseline"]["cores"] >= 1
+    # the region call through IntelPDHMM.computeLikelihoodsNative itself: 13 JNI calls per read + 7 per haplotype + a few
+    jr = pd["jni_region_276x48"]
+    assert "error" not in jr, jr
+    assert jr["ms_per_call"] > 0 and jr["jni_calls_per_call"] < 276 * 13 + 48 * 7 + 40 and jr["ms_per_call_with_25ns_more_per_jni_call"] > jr["ms_per_call"]
     # GATK calls PDHMM per region from many JVMs, like PairHMM: P processes x one caller of fixture-sized regions
     rp = pd["region_processes"]
     assert "error" not in rp, rp
