@@ -117,9 +117,9 @@ if "shards" in what:
             for hs in (2, 1):
                 measure(f"GKL_HIP_HOST_SHARDS={hs}", max_threads=mt, iters=24, warm=4, env={"GKL_HIP_HOST_SHARDS": hs})
 if "shares" in what:
-    lists = ("4,12,28,36,14,6", "6,30,40,18,6", "5,25,35,25,10", "8,40,40,12", "3,9,22,30,22,10,4", "4,32,32,32", "4,20,36,30,10", "10,30,30,20,10")
-    for mt in (1, 4):
-        for rep in range(2):
+    lists = ("4,12,28,36,14,6", "6,12,26,36,14,6", "8,14,26,32,14,6", "2,6,14,28,30,14,6", "4,12,28,36,20")
+    for rep in range(3):
+        for mt in (1, 4):
             for sh in lists:
                 measure(f"shares {sh}", max_threads=mt, iters=24, warm=4, env={"GKL_HIP_JNI_RANGE_SHARES": sh})
 if "threads" in what:
